@@ -1,0 +1,111 @@
+// ORACLE (test infrastructure).  Circle FFT on canonic domains, bit-reversed evaluations.
+// Restates Stwo `core::backend::cpu::circle::{interpolate, evaluate, eval_at_point}` and
+// `core::poly::circle::poly` (PARITY UNPINNED, Stwo not vendored).  Reached in the reference from
+// `tree_builder.extend_evals` / `.commit` (crates/prover/src/prover.rs:71-73, 80-82, 100-102).
+//
+// Basis: coefficient index bit 0 <-> y, bit 1 <-> x, bit k>=2 <-> pi^{k-1}(x), pi(x)=2x^2-1.
+// Twiddles are recomputed per call from the group law (no shared tables with the product).
+#pragma once
+#include "ocircle.hpp"
+
+namespace orc {
+
+// Twiddles of layer `layer` (0 = circle/y layer, i>=1 = line layers) for the canonic domain of
+// log size n:  tw[h] for butterfly group h.
+inline std::vector<M31> layer_twiddles(uint32_t n, uint32_t layer) {
+  Coset half = CanonicCoset(n).half_coset();  // size 2^(n-1)
+  if (layer == 0) {
+    size_t cnt = (size_t)1 << (n - 1);
+    std::vector<M31> t(cnt);
+    // sequential walk of the coset, then bit-reverse
+    PointM p = half.initial(), s = half.step();
+    std::vector<M31> nat(cnt);
+    for (size_t j = 0; j < cnt; j++) { nat[j] = p.y; p = p + s; }
+    for (size_t h = 0; h < cnt; h++) t[h] = nat[bit_reverse_index(h, n - 1)];
+    return t;
+  }
+  Coset c = half;
+  for (uint32_t i = 1; i < layer; i++) c = c.dbl();
+  // coset c has size 2^(n-layer); first half, bit-reversed
+  size_t cnt = (size_t)1 << (n - 1 - layer);
+  std::vector<M31> nat(cnt), t(cnt);
+  PointM p = c.initial(), s = c.step();
+  for (size_t j = 0; j < cnt; j++) { nat[j] = p.x; p = p + s; }
+  for (size_t h = 0; h < cnt; h++) t[h] = nat[bit_reverse_index(h, n - 1 - layer)];
+  return t;
+}
+
+// values: bit-reversed evaluations on CanonicCoset(n).circle_domain(); returns coefficients.
+inline std::vector<M31> interpolate(std::vector<M31> values) {
+  size_t N = values.size();
+  uint32_t n = 0;
+  while (((size_t)1 << n) < N) n++;
+  assert(n >= 1);
+  for (uint32_t layer = 0; layer < n; layer++) {
+    std::vector<M31> tw = layer_twiddles(n, layer);
+    for (auto& t : tw) t = t.inverse();
+    size_t stride = (size_t)1 << layer;
+    for (size_t h = 0; h < (N >> (layer + 1)); h++) {
+      for (size_t l = 0; l < stride; l++) {
+        size_t i0 = (h << (layer + 1)) + l, i1 = i0 + stride;
+        M31 a = values[i0], b = values[i1];
+        values[i0] = a + b;
+        values[i1] = (a - b) * tw[h];
+      }
+    }
+  }
+  M31 inv = M31((uint32_t)N).inverse();
+  for (auto& v : values) v = v * inv;
+  return values;
+}
+
+// coeffs of log size m; evaluate on CanonicCoset(n).circle_domain(), n >= m. Bit-reversed output.
+inline std::vector<M31> evaluate(const std::vector<M31>& coeffs, uint32_t n) {
+  size_t N = (size_t)1 << n;
+  std::vector<M31> values(N);
+  for (size_t i = 0; i < coeffs.size(); i++) values[i] = coeffs[i];
+  for (int layer = (int)n - 1; layer >= 0; layer--) {
+    std::vector<M31> tw = layer_twiddles(n, (uint32_t)layer);
+    size_t stride = (size_t)1 << layer;
+    for (size_t h = 0; h < (N >> (layer + 1)); h++) {
+      for (size_t l = 0; l < stride; l++) {
+        size_t i0 = (h << (layer + 1)) + l, i1 = i0 + stride;
+        M31 a = values[i0], b = values[i1] * tw[h];
+        values[i0] = a + b;
+        values[i1] = a - b;
+      }
+    }
+  }
+  return values;
+}
+
+// Stwo `CirclePoly::eval_at_point` (fold with mappings [.., pi(x), x, y]).
+inline QM31 eval_at_point(const std::vector<M31>& coeffs, PointQ p) {
+  size_t N = coeffs.size();
+  uint32_t n = 0;
+  while (((size_t)1 << n) < N) n++;
+  if (n == 0) return QM31(coeffs[0]);
+  std::vector<QM31> maps;  // maps[k] multiplies index bit k
+  maps.push_back(p.y);
+  QM31 x = p.x;
+  for (uint32_t i = 1; i < n; i++) { maps.push_back(x); x = double_x(x); }
+  std::vector<QM31> cur(N);
+  for (size_t i = 0; i < N; i++) cur[i] = QM31(coeffs[i]);
+  for (uint32_t k = 0; k < n; k++) {
+    size_t half = cur.size() / 2;
+    std::vector<QM31> nxt(half);
+    // bit 0 of the (current) index pairs adjacent elements
+    for (size_t i = 0; i < half; i++) nxt[i] = cur[2 * i] + maps[k] * cur[2 * i + 1];
+    cur.swap(nxt);
+  }
+  return cur[0];
+}
+
+// Direct O(N) evaluation of the basis polynomial sum at a base-field point (test helper).
+inline M31 eval_at_base_point(const std::vector<M31>& coeffs, PointM p) {
+  PointQ q = into_ef(p);
+  QM31 r = eval_at_point(coeffs, q);
+  return r.a.a;
+}
+
+}  // namespace orc
