@@ -1,0 +1,181 @@
+// extern "C" boundary of libcairom_hip.so (declared in include/cairom_hip.h).
+// Thin wrappers: translate opaque handles into device pointers, upload pointer arrays, call the
+// engine, map C++ exceptions to status codes + a thread-local error string.
+#include "../../include/cairom_hip.h"
+#include "engine.hpp"
+#include "merkle_tree.hpp"
+#include <string.h>
+#include <string>
+#include <mutex>
+
+using namespace cm;
+
+namespace {
+thread_local std::string g_last_error;
+std::mutex g_init_mu;
+bool g_inited = false;
+
+inline hipStream_t S(cm_stream_t s) { return (hipStream_t)(uintptr_t)s; }
+inline uint32_t* P32(cm_handle h) { return (uint32_t*)(uintptr_t)h; }
+
+template <class F>
+int32_t guard(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const CmError& e) {
+    g_last_error = e.what();
+    return e.code ? e.code : 1;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return 1;
+  } catch (...) {
+    g_last_error = "unknown error";
+    return 1;
+  }
+}
+std::vector<uint32_t*> ptrs(const cm_handle* hs, uint32_t n) {
+  std::vector<uint32_t*> v(n);
+  for (uint32_t i = 0; i < n; i++) v[i] = P32(hs[i]);
+  return v;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t cm_last_error(char* buf, size_t buf_len) {
+  if (!buf || !buf_len) return (int32_t)g_last_error.size();
+  size_t n = g_last_error.size() < buf_len - 1 ? g_last_error.size() : buf_len - 1;
+  memcpy(buf, g_last_error.data(), n);
+  buf[n] = 0;
+  return (int32_t)n;
+}
+
+int32_t cm_init(int32_t device) {
+  return guard([&] {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+      throw CmError(3, "cm_init: no HIP device available (libcairom_hip has no CPU fallback)");
+    CM_CHECK(device >= 0 && device < ndev, "cm_init: device index out of range");
+    CM_HIP(hipSetDevice(device));
+    g_inited = true;
+  });
+}
+int32_t cm_shutdown(void) {
+  return guard([&] {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (g_inited) CM_HIP(hipDeviceSynchronize());
+    g_inited = false;
+  });
+}
+int32_t cm_stream_create(cm_stream_t* out) {
+  return guard([&] {
+    hipStream_t st;
+    CM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *out = (cm_stream_t)(uintptr_t)st;
+  });
+}
+int32_t cm_stream_destroy(cm_stream_t s) {
+  return guard([&] { if (s) CM_HIP(hipStreamDestroy(S(s))); });
+}
+int32_t cm_stream_sync(cm_stream_t s) {
+  return guard([&] { CM_HIP(hipStreamSynchronize(S(s))); });
+}
+
+int32_t cm_col_alloc(uint64_t n_u32, cm_handle* out) {
+  return guard([&] {
+    void* p = nullptr;
+    CM_HIP(hipMalloc(&p, (n_u32 ? n_u32 : 1) * 4));
+    *out = (cm_handle)(uintptr_t)p;
+  });
+}
+int32_t cm_col_free(cm_handle h) {
+  return guard([&] { if (h) CM_HIP(hipFree(P32(h))); });
+}
+int32_t cm_col_h2d(cm_handle h, const uint32_t* src, uint64_t n, cm_stream_t s) {
+  return guard([&] {
+    CM_HIP(hipMemcpyAsync(P32(h), src, n * 4, hipMemcpyHostToDevice, S(s)));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_col_d2h(cm_handle h, uint32_t* dst, uint64_t n, cm_stream_t s) {
+  return guard([&] {
+    CM_HIP(hipMemcpyAsync(dst, P32(h), n * 4, hipMemcpyDeviceToHost, S(s)));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_bit_reverse(const cm_handle* cols, uint32_t n_cols, uint32_t log_n, cm_stream_t s) {
+  return guard([&] {
+    DevBuf d = upload(ptrs(cols, n_cols), S(s));
+    bit_reverse_columns(d.as<uint32_t*>(), n_cols, log_n, S(s));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+
+int32_t cm_twiddles_precompute(uint32_t log_size, cm_handle* tw_out) {
+  return guard([&] {
+    Twiddles* t = twiddles_create(log_size, 0);
+    CM_HIP(hipStreamSynchronize(0));
+    *tw_out = (cm_handle)(uintptr_t)t;
+  });
+}
+int32_t cm_twiddles_free(cm_handle tw) {
+  return guard([&] { twiddles_destroy((Twiddles*)(uintptr_t)tw); });
+}
+int32_t cm_interpolate(const cm_handle* cols, uint32_t n_cols, uint32_t log_n, cm_handle tw, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(tw, "cm_interpolate: null twiddles");
+    DevBuf d = upload(ptrs(cols, n_cols), S(s));
+    interpolate(d.as<uint32_t*>(), n_cols, log_n, *(Twiddles*)(uintptr_t)tw, S(s));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_evaluate(const cm_handle* coeffs, uint32_t n_cols, uint32_t log_n, uint32_t log_out, cm_handle tw,
+                    const cm_handle* out, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(tw, "cm_evaluate: null twiddles");
+    DevBuf ds = upload(ptrs(coeffs, n_cols), S(s));
+    DevBuf dd = upload(ptrs(out, n_cols), S(s));
+    evaluate(ds.as<const uint32_t*>(), dd.as<uint32_t*>(), n_cols, log_n, log_out, *(Twiddles*)(uintptr_t)tw, S(s));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_eval_at_point(const cm_handle* coeffs, uint32_t n_cols, uint32_t log_n, const uint32_t pt_xy[8],
+                         uint32_t* out, cm_stream_t s) {
+  return guard([&] {
+    DevBuf ds = upload(ptrs(coeffs, n_cols), S(s));
+    DevBuf scratch(eval_at_point_scratch_words(n_cols, log_n) * 4);
+    DevBuf dout((size_t)n_cols * 16);
+    eval_at_point_batch(ds.as<const uint32_t*>(), n_cols, log_n, QM31::from_u32(pt_xy), QM31::from_u32(pt_xy + 4),
+                        scratch.u32(), dout.u32(), S(s));
+    CM_HIP(hipMemcpyAsync(out, dout.p, (size_t)n_cols * 16, hipMemcpyDeviceToHost, S(s)));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+
+int32_t cm_merkle_commit_layer(uint32_t log_size, cm_handle prev_layer, const cm_handle* cols, uint32_t n_cols,
+                               cm_handle out_hashes, cm_stream_t s) {
+  return guard([&] {
+    DevBuf dc = upload(ptrs(cols, n_cols), S(s));
+    merkle_layer(log_size, P32(prev_layer), dc.as<const uint32_t*>(), n_cols, P32(out_hashes), S(s));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_merkle_commit(const cm_handle* cols, const uint32_t* col_logs, uint32_t n_cols, uint8_t root[32],
+                         cm_stream_t s) {
+  return guard([&] {
+    std::vector<const uint32_t*> c(n_cols);
+    std::vector<uint32_t> logs(col_logs, col_logs + n_cols);
+    for (uint32_t i = 0; i < n_cols; i++) c[i] = P32(cols[i]);
+    MerkleTree t;
+    t.commit(c, logs, S(s));
+    t.root(root, S(s));
+  });
+}
+int32_t cm_grind(const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce_out) {
+  return guard([&] { *nonce_out = grind_gpu(digest, pow_bits, 0); });
+}
+
+}  // extern "C"

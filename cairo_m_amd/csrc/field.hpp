@@ -1,0 +1,185 @@
+// M31 / CM31 / QM31 arithmetic for host and gfx950 device code (product path).
+// Values are canonical u32 in [0, P).  Layout of QM31 = ((a,b),(c,d)) as 4 u32, matching the
+// reference's use of Stwo's SecureField (crates/prover/src/public_data.rs:146-149).
+// All reductions use the Mersenne fold (no division); results are bit-identical to `x mod P`.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CM_HD __host__ __device__ __forceinline__
+#else
+#define CM_HD inline
+#endif
+
+namespace cm {
+
+constexpr uint32_t P = 0x7fffffffu;
+
+struct M31 {
+  uint32_t v;
+  CM_HD M31() : v(0) {}
+  CM_HD explicit M31(uint32_t x) : v(x) {}  // x must already be < P
+  static CM_HD M31 reduce(uint64_t x) {     // any x < 2^62
+    uint32_t lo = (uint32_t)(x & P), hi = (uint32_t)(x >> 31);
+    uint32_t s = lo + (hi & P) + (uint32_t)(x >> 62);
+    s = (s & P) + (s >> 31);
+    return M31(s >= P ? s - P : s);
+  }
+  static CM_HD M31 from_u32(uint32_t x) {  // any u32
+    uint32_t s = (x & P) + (x >> 31);
+    return M31(s >= P ? s - P : s);
+  }
+  CM_HD bool is_zero() const { return v == 0; }
+};
+CM_HD M31 operator+(M31 a, M31 b) {
+  uint32_t s = a.v + b.v;
+  return M31(s >= P ? s - P : s);
+}
+CM_HD M31 operator-(M31 a, M31 b) {
+  uint32_t s = a.v - b.v;
+  return M31(a.v < b.v ? s + P : s);
+}
+CM_HD M31 operator-(M31 a) { return M31(a.v ? P - a.v : 0); }
+CM_HD M31 operator*(M31 a, M31 b) {
+  uint64_t t = (uint64_t)a.v * b.v;
+  uint32_t s = (uint32_t)(t & P) + (uint32_t)(t >> 31);
+  return M31(s >= P ? s - P : s);
+}
+CM_HD M31& operator+=(M31& a, M31 b) { a = a + b; return a; }
+CM_HD M31& operator-=(M31& a, M31 b) { a = a - b; return a; }
+CM_HD M31& operator*=(M31& a, M31 b) { a = a * b; return a; }
+CM_HD bool operator==(M31 a, M31 b) { return a.v == b.v; }
+CM_HD bool operator!=(M31 a, M31 b) { return a.v != b.v; }
+
+template <int N>
+CM_HD M31 sqn(M31 x) {
+#pragma unroll
+  for (int i = 0; i < N; i++) x = x * x;
+  return x;
+}
+// x^(P-2); inverse(0) = 0 (callers that need Stwo's panic check for zero themselves).
+CM_HD M31 inv(M31 v) {
+  M31 t0 = sqn<2>(v) * v;
+  M31 t1 = sqn<1>(t0) * t0;
+  M31 t2 = sqn<3>(t1) * t0;
+  M31 t3 = sqn<1>(t2) * t0;
+  M31 t4 = sqn<8>(t3) * t3;
+  M31 t5 = sqn<8>(t4) * t3;
+  return sqn<7>(t5) * t2;
+}
+
+struct CM31 {
+  M31 a, b;
+  CM_HD CM31() {}
+  CM_HD CM31(M31 a_, M31 b_) : a(a_), b(b_) {}
+  CM_HD explicit CM31(M31 a_) : a(a_), b() {}
+};
+CM_HD CM31 operator+(CM31 x, CM31 y) { return CM31(x.a + y.a, x.b + y.b); }
+CM_HD CM31 operator-(CM31 x, CM31 y) { return CM31(x.a - y.a, x.b - y.b); }
+CM_HD CM31 operator-(CM31 x) { return CM31(-x.a, -x.b); }
+CM_HD CM31 operator*(CM31 x, CM31 y) { return CM31(x.a * y.a - x.b * y.b, x.a * y.b + x.b * y.a); }
+CM_HD CM31 operator*(CM31 x, M31 y) { return CM31(x.a * y, x.b * y); }
+CM_HD CM31 inv(CM31 x) {
+  M31 n = inv(x.a * x.a + x.b * x.b);
+  return CM31(x.a * n, -(x.b * n));
+}
+// multiply by R = 2 + i
+CM_HD CM31 mul_R(CM31 x) { return CM31(x.a + x.a - x.b, x.a + x.b + x.b); }
+
+struct QM31 {
+  CM31 a, b;
+  CM_HD QM31() {}
+  CM_HD QM31(CM31 a_, CM31 b_) : a(a_), b(b_) {}
+  CM_HD explicit QM31(M31 x) : a(x), b() {}
+  CM_HD QM31(M31 x0, M31 x1, M31 x2, M31 x3) : a(x0, x1), b(x2, x3) {}
+  static CM_HD QM31 from_u32(const uint32_t* w) { return QM31(M31(w[0]), M31(w[1]), M31(w[2]), M31(w[3])); }
+  CM_HD void to_u32(uint32_t* w) const { w[0] = a.a.v; w[1] = a.b.v; w[2] = b.a.v; w[3] = b.b.v; }
+  CM_HD M31 coord(int i) const { return i == 0 ? a.a : i == 1 ? a.b : i == 2 ? b.a : b.b; }
+  CM_HD bool is_zero() const { return (a.a.v | a.b.v | b.a.v | b.b.v) == 0; }
+};
+CM_HD QM31 operator+(QM31 x, QM31 y) { return QM31(x.a + y.a, x.b + y.b); }
+CM_HD QM31 operator-(QM31 x, QM31 y) { return QM31(x.a - y.a, x.b - y.b); }
+CM_HD QM31 operator-(QM31 x) { return QM31(-x.a, -x.b); }
+CM_HD QM31 operator*(QM31 x, QM31 y) {
+  return QM31(x.a * y.a + mul_R(x.b * y.b), x.a * y.b + x.b * y.a);
+}
+CM_HD QM31 operator*(QM31 x, M31 y) { return QM31(x.a * y, x.b * y); }
+CM_HD QM31 operator*(M31 y, QM31 x) { return QM31(x.a * y, x.b * y); }
+CM_HD QM31 operator+(QM31 x, M31 y) { return QM31(CM31(x.a.a + y, x.a.b), x.b); }
+CM_HD QM31 operator-(QM31 x, M31 y) { return QM31(CM31(x.a.a - y, x.a.b), x.b); }
+CM_HD QM31 mul_cm31(QM31 x, CM31 y) { return QM31(x.a * y, x.b * y); }
+CM_HD QM31& operator+=(QM31& a, QM31 b) { a = a + b; return a; }
+CM_HD QM31& operator-=(QM31& a, QM31 b) { a = a - b; return a; }
+CM_HD QM31& operator*=(QM31& a, QM31 b) { a = a * b; return a; }
+CM_HD bool operator==(QM31 x, QM31 y) {
+  return x.a.a.v == y.a.a.v && x.a.b.v == y.a.b.v && x.b.a.v == y.b.a.v && x.b.b.v == y.b.b.v;
+}
+CM_HD bool operator!=(QM31 x, QM31 y) { return !(x == y); }
+CM_HD QM31 conj_u(QM31 x) { return QM31(x.a, -x.b); }  // a - b*u ("complex_conjugate" in Stwo)
+CM_HD QM31 inv(QM31 x) {
+  CM31 den = x.a * x.a - mul_R(x.b * x.b);
+  CM31 di = inv(den);
+  return QM31(x.a * di, -(x.b * di));
+}
+CM_HD QM31 qpow(QM31 x, uint64_t e) {
+  QM31 r(M31(1));
+  while (e) {
+    if (e & 1) r = r * x;
+    x = x * x;
+    e >>= 1;
+  }
+  return r;
+}
+
+// ---- circle group over a field F (M31 or QM31) ----
+template <class F>
+struct CPoint {
+  F x, y;
+};
+template <class F>
+CM_HD CPoint<F> cadd(CPoint<F> p, CPoint<F> q) {
+  return CPoint<F>{p.x * q.x - p.y * q.y, p.x * q.y + p.y * q.x};
+}
+template <class F>
+CM_HD CPoint<F> cconj(CPoint<F> p) { return CPoint<F>{p.x, -p.y}; }
+CM_HD M31 double_x(M31 x) { M31 s = x * x; return s + s - M31(1); }
+CM_HD QM31 double_x(QM31 x) { QM31 s = x * x; return s + s - M31(1); }
+
+constexpr uint32_t CIRCLE_GEN_X = 2u, CIRCLE_GEN_Y = 1268011823u;
+
+// G^idx (idx mod 2^31) by double-and-add; host or device.
+CM_HD CPoint<M31> point_at_index(uint32_t idx) {
+  idx &= 0x7fffffffu;
+  CPoint<M31> res{M31(1), M31(0)};
+  CPoint<M31> cur{M31(CIRCLE_GEN_X), M31(CIRCLE_GEN_Y)};
+  while (idx) {
+    if (idx & 1) res = cadd(res, cur);
+    cur = cadd(cur, cur);
+    idx >>= 1;
+  }
+  return res;
+}
+CM_HD uint32_t subgroup_gen_index(uint32_t log_size) { return 1u << (31 - log_size); }
+// index (exponent of G) of point i (natural order) of CanonicCoset(log).circle_domain()
+CM_HD uint32_t domain_index_at(uint32_t log, uint32_t i) {
+  uint32_t half = 1u << (log - 1);
+  uint32_t init = subgroup_gen_index(log + 1);  // half_odds(log-1).initial = G_{2^(log+1)}
+  uint32_t step = subgroup_gen_index(log - 1);
+  if (log == 1) step = 0;
+  if (i < half) return (init + step * i) & 0x7fffffffu;
+  return (0x80000000u - ((init + step * (i - half)) & 0x7fffffffu)) & 0x7fffffffu;
+}
+CM_HD uint32_t bit_reverse(uint32_t i, uint32_t log) {
+  if (log == 0) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(i) >> (32 - log);
+#else
+  uint32_t r = 0;
+  for (uint32_t b = 0; b < log; b++) r |= ((i >> b) & 1u) << (log - 1 - b);
+  return r;
+#endif
+}
+
+}  // namespace cm

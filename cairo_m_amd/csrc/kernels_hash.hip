@@ -1,0 +1,160 @@
+// Blake2s kernels for gfx950: mixed-degree Merkle layer hashing and proof-of-work grinding.
+//
+// Replaces (reference call sites): MerkleOps<Blake2sMerkleHasher>::commit_on_layer reached from
+// `tree_builder.commit(channel)` (crates/prover/src/prover.rs:73, 82, 102) and
+// `SimdBackend::grind` (prover.rs:90 and inside stwo `prove`, prover.rs:131).
+//
+// One thread = one tree node.  Column values of a node are read column-major: lane i reads
+// cols[c][i], so a wave's 64 lanes read 256 contiguous bytes per column (coalesced); column
+// pointers are wave-uniform (scalar loads).  Hash framing: state = 0; optional F(state, left||right);
+// then one F per 16 column words (zero padded); t = f = 0 (see DESIGN.md "Merkle node framing").
+#include "field.hpp"
+#include "device_common.hpp"
+#include "engine.hpp"
+
+namespace cm {
+
+__device__ __constant__ uint32_t B2S_IV_D[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                                                0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __funnelshift_r(x, x, n); }
+
+#define CM_G(a, b, c, d, x, y)                 \
+  a = a + b + (x); d = rotr(d ^ a, 16);        \
+  c = c + d;       b = rotr(b ^ c, 12);        \
+  a = a + b + (y); d = rotr(d ^ a, 8);         \
+  c = c + d;       b = rotr(b ^ c, 7);
+
+#define CM_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+  CM_G(v0, v4, v8, v12, m[s0], m[s1])                                                  \
+  CM_G(v1, v5, v9, v13, m[s2], m[s3])                                                  \
+  CM_G(v2, v6, v10, v14, m[s4], m[s5])                                                 \
+  CM_G(v3, v7, v11, v15, m[s6], m[s7])                                                 \
+  CM_G(v0, v5, v10, v15, m[s8], m[s9])                                                 \
+  CM_G(v1, v6, v11, v12, m[s10], m[s11])                                               \
+  CM_G(v2, v7, v8, v13, m[s12], m[s13])                                                \
+  CM_G(v3, v4, v9, v14, m[s14], m[s15])
+
+// h <- F(h, m, t0=0, t1=0, f0=0, f1=0)
+__device__ __forceinline__ void b2s_compress(uint32_t (&h)[8], const uint32_t (&m)[16]) {
+  uint32_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+  uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
+  uint32_t v12 = 0x510E527Fu, v13 = 0x9B05688Cu, v14 = 0x1F83D9ABu, v15 = 0x5BE0CD19u;
+  CM_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  CM_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+  CM_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+  CM_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+  CM_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+  CM_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+  CM_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+  CM_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+  CM_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+  CM_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+  h[0] ^= v0 ^ v8;  h[1] ^= v1 ^ v9;  h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11;
+  h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
+}
+
+// hashes[i] = hash_node(children (prev[2i], prev[2i+1]) if prev != null, cols[*][i])
+__global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const uint32_t* __restrict__ prev,
+                                                      const uint32_t* const* __restrict__ cols, uint32_t n_cols,
+                                                      uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << log_size)) return;
+  uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t m[16];
+  if (prev) {
+    const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
+    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+    m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+    m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+    m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+    b2s_compress(h, m);
+  }
+  for (uint32_t c0 = 0; c0 < n_cols; c0 += 16) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? cols[c0 + k][i] : 0u;
+    b2s_compress(h, m);
+  }
+  uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+  o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+  o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+// Proof of work: smallest nonce in [base, base + n) with trailing_zeros(F(digest, [lo,hi,0..])[0..16B]) >= bits.
+// result initialised to ~0ull; atomicMin keeps the smallest hit.
+__global__ void __launch_bounds__(256) k_grind(const uint32_t* __restrict__ digest, uint32_t bits, uint64_t base,
+                                               unsigned long long* result) {
+  const uint64_t nonce = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t h[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) h[k] = digest[k];
+  uint32_t m[16] = {0};
+  m[0] = (uint32_t)nonce;
+  m[1] = (uint32_t)(nonce >> 32);
+  b2s_compress(h, m);
+  // trailing zeros of the first 16 bytes as LE u128
+  uint32_t tz;
+  if (h[0]) tz = __ffs(h[0]) - 1;
+  else if (h[1]) tz = 32 + __ffs(h[1]) - 1;
+  else if (h[2]) tz = 64 + __ffs(h[2]) - 1;
+  else if (h[3]) tz = 96 + __ffs(h[3]) - 1;
+  else tz = 128;
+  if (tz >= bits) atomicMin(result, (unsigned long long)nonce);
+}
+
+// Gather 32-byte hashes / single u32 values at arbitrary positions (decommitment).
+__global__ void k_gather_hashes(const uint32_t* const* layers, const uint32_t* layer_idx, const uint32_t* node_idx,
+                                uint32_t n, uint32_t* out) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 8) return;
+  uint32_t q = t >> 3, w = t & 7;
+  out[t] = layers[layer_idx[q]][(size_t)node_idx[q] * 8 + w];
+}
+__global__ void k_gather_values(const uint32_t* const* cols, const uint32_t* col_idx, const uint32_t* row_idx,
+                                uint32_t n, uint32_t* out) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  out[t] = cols[col_idx[t]][row_idx[t]];
+}
+
+
+// ================================================================= host wrappers
+void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
+                  uint32_t* d_out, hipStream_t st) {
+  uint32_t n = 1u << log_size;
+  hipLaunchKernelGGL(k_merkle_layer, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
+  CM_HIP(hipGetLastError());
+}
+uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st) {
+  DevBuf d_digest(32), d_res(8);
+  CM_HIP(hipMemcpyAsync(d_digest.p, digest, 32, hipMemcpyHostToDevice, st));
+  const uint64_t batch = 1ull << 22;
+  for (uint64_t base = 0;; base += batch) {
+    unsigned long long init = ~0ull;
+    CM_HIP(hipMemcpyAsync(d_res.p, &init, 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_grind, dim3(batch / 256), dim3(256), 0, st, d_digest.u32(), bits, base,
+                       (unsigned long long*)d_res.p);
+    CM_HIP(hipGetLastError());
+    unsigned long long res;
+    CM_HIP(hipMemcpyAsync(&res, d_res.p, 8, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    if (res != ~0ull) return res;
+    CM_CHECK(base < (1ull << 40), "grind: no nonce found");
+  }
+}
+void gather_hashes(const uint32_t* const* d_layers, const uint32_t* d_layer_idx, const uint32_t* d_node_idx, uint32_t n,
+                   uint32_t* d_out, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_gather_hashes, dim3((n * 8 + 255) / 256), dim3(256), 0, st, d_layers, d_layer_idx, d_node_idx, n,
+                     d_out);
+  CM_HIP(hipGetLastError());
+}
+void gather_values(const uint32_t* const* d_cols, const uint32_t* d_col_idx, const uint32_t* d_row_idx, uint32_t n,
+                   uint32_t* d_out, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_gather_values, dim3((n + 255) / 256), dim3(256), 0, st, d_cols, d_col_idx, d_row_idx, n, d_out);
+  CM_HIP(hipGetLastError());
+}
+
+}  // namespace cm

@@ -1,0 +1,311 @@
+// Circle-FFT kernels for gfx950: twiddle precompute, multi-layer LDS-staged butterfly passes
+// (interpolate / evaluate / LDE), bit-reversal, and OODS point evaluation.
+//
+// Replaces (reference call sites): `SimdBackend::precompute_twiddles` (crates/prover/src/prover.rs:56-60),
+// `tree_builder.extend_evals` -> PolyOps::interpolate and `.commit` -> PolyOps::evaluate
+// (prover.rs:71-73, 80-82, 100-102), PolyOps::eval_at_point (inside stwo `prove`, prover.rs:131).
+//
+// Data layout: one column = contiguous u32[2^log] in HBM holding canonical M31 values, evaluations in
+// bit-reversed order of the canonic circle domain (Stwo `BitReversedOrder`).  Batches of equal-size
+// columns are addressed through a device array of column pointers (blockIdx.y = column).
+#include "field.hpp"
+#include "device_common.hpp"
+#include "engine.hpp"
+
+namespace cm {
+
+// ---------------------------------------------------------------- twiddles
+// Layout for root log size R (largest domain):
+//   xtw  : line-layer twiddles of the root half coset, layer L at offset 2^(R-1) - 2^(R-1-L),
+//          2^(R-2-L) entries: x( half_odds(R-1-L).at(bitrev(h)) )
+//   ytw  : circle-layer twiddles of EVERY log size n (1..R) at offset 2^(n-1):
+//          y( half_odds(n-1).at(bitrev(h)) ), 2^(n-1) entries
+// ixtw/iytw hold the element-wise inverses.
+__global__ void k_twiddles_x(uint32_t* xtw, uint32_t* ixtw, uint32_t R) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t total = (1u << (R - 1)) - 1;
+  if (t >= total) return;
+  // find layer L with offset(L) <= t < offset(L+1); offset(L) = 2^(R-1) - 2^(R-1-L)
+  uint32_t rem = (1u << (R - 1)) - t;            // in (2^(R-2-L), 2^(R-1-L)]
+  uint32_t L = (R - 1) - (32 - __clz(rem - 1));  // 2^(R-1-L) >= rem > 2^(R-2-L)
+  if (rem == 1) L = R - 2;                       // last layer has a single entry
+  uint32_t off = (1u << (R - 1)) - (1u << (R - 1 - L));
+  uint32_t h = t - off;
+  uint32_t bits = R - 2 - L;
+  uint32_t j = bit_reverse(h, bits);
+  uint32_t init = subgroup_gen_index(R + 1 - L);
+  uint32_t step = subgroup_gen_index(R - 1 - L);
+  CPoint<M31> p = point_at_index(init + step * j);
+  xtw[t] = p.x.v;
+  ixtw[t] = inv(p.x).v;
+}
+__global__ void k_twiddles_y(uint32_t* ytw, uint32_t* iytw, uint32_t R) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // t in [1, 2^R)
+  if (t == 0 || t >= (1u << R)) return;
+  uint32_t n = 32 - __clz(t);  // offset 2^(n-1) <= t < 2^n
+  uint32_t h = t - (1u << (n - 1));
+  uint32_t j = bit_reverse(h, n - 1);
+  uint32_t init = subgroup_gen_index(n + 1);
+  uint32_t step = (n >= 2) ? subgroup_gen_index(n - 1) : 0;
+  CPoint<M31> p = point_at_index(init + step * j);
+  ytw[t] = p.y.v;
+  iytw[t] = inv(p.y).v;
+}
+
+// ---------------------------------------------------------------- butterfly passes
+// One launch applies butterfly layers [lo, hi) of a size-2^n transform to every column.
+// Tile = 2^W values of index bits [lo,hi)  x  2^M consecutive low indices (M = 0 when lo == 0).
+// INVERSE: ibutterfly (a+b, (a-b)*itw), layers ascending.  Forward: (a+b*tw, a-b*tw), descending.
+// in_len: logical input length; reads at index >= in_len return 0 (zero-extension => LDE).
+struct FftPassArgs {
+  const uint32_t* const* src;
+  uint32_t* const* dst;
+  const uint32_t* xtw;  // (i)xtw table
+  const uint32_t* ytw;  // (i)ytw table
+  uint32_t R;           // root log of the twiddle tables
+  uint32_t n;           // transform log size
+  uint32_t lo, hi;      // layer range
+  uint32_t M;           // log of contiguous low run per tile
+  uint32_t in_len;      // logical input length per column
+  uint32_t scale;       // multiply outputs by this (1 = none); used for 1/N on the last inverse pass
+};
+
+template <bool INVERSE>
+__global__ void __launch_bounds__(256) k_fft_pass(FftPassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
+  const uint32_t W = a.hi - a.lo;
+  const uint32_t M = a.M;
+  const uint32_t tile_log = W + M;
+  const uint32_t tile_sz = 1u << tile_log;
+  const uint32_t* src = a.src[blockIdx.y];
+  uint32_t* dst = a.dst[blockIdx.y];
+  // decompose tile id into (high bits above hi, fixed low bits [M, lo))
+  const uint32_t low_fixed_bits = a.lo - M;  // 0 when lo == 0 (then M == 0)
+  const uint32_t tid = blockIdx.x;
+  const uint32_t lowf = tid & ((1u << low_fixed_bits) - 1);
+  const uint32_t high = tid >> low_fixed_bits;
+  const uint32_t base = (high << a.hi) | (lowf << M);
+  // global index of tile element (mid, l):  base | mid << lo | l
+  for (uint32_t e = threadIdx.x; e < tile_sz; e += blockDim.x) {
+    uint32_t l = e & ((1u << M) - 1), mid = e >> M;
+    uint32_t g = base | (mid << a.lo) | l;
+    tile[e] = (g < a.in_len) ? src[g] : 0u;
+  }
+  __syncthreads();
+  const uint32_t nbf = tile_sz >> 1;
+  for (uint32_t k = 0; k < W; k++) {
+    const uint32_t j = INVERSE ? k : (W - 1 - k);  // bit of `mid` being paired
+    const uint32_t layer = a.lo + j;
+    const uint32_t s = j + M;                      // LDS stride log
+    for (uint32_t b = threadIdx.x; b < nbf; b += blockDim.x) {
+      uint32_t e0 = ((b >> s) << (s + 1)) | (b & ((1u << s) - 1));
+      uint32_t e1 = e0 | (1u << s);
+      uint32_t l = e0 & ((1u << M) - 1), mid = e0 >> M;
+      uint32_t g0 = base | (mid << a.lo) | l;
+      uint32_t h = g0 >> (layer + 1);
+      uint32_t tw;
+      if (layer == 0) {
+        tw = a.ytw[(1u << (a.n - 1)) + h];
+      } else {
+        uint32_t L = a.R - a.n + layer - 1;
+        tw = a.xtw[(1u << (a.R - 1)) - (1u << (a.R - 1 - L)) + h];
+      }
+      M31 x(tile[e0]), y(tile[e1]), t(tw);
+      if (INVERSE) {
+        tile[e0] = (x + y).v;
+        tile[e1] = ((x - y) * t).v;
+      } else {
+        M31 yt = y * t;
+        tile[e0] = (x + yt).v;
+        tile[e1] = (x - yt).v;
+      }
+    }
+    __syncthreads();
+  }
+  const M31 sc(a.scale);
+  for (uint32_t e = threadIdx.x; e < tile_sz; e += blockDim.x) {
+    uint32_t l = e & ((1u << M) - 1), mid = e >> M;
+    uint32_t g = base | (mid << a.lo) | l;
+    uint32_t v = tile[e];
+    if (a.scale != 1u) v = (M31(v) * sc).v;
+    dst[g] = v;
+  }
+}
+
+// ---------------------------------------------------------------- bit reversal (in place)
+__global__ void k_bit_reverse(uint32_t* const* cols, uint32_t log_n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << log_n)) return;
+  uint32_t j = bit_reverse(i, log_n);
+  if (j > i) {
+    uint32_t* c = cols[blockIdx.y];
+    uint32_t a = c[i], b = c[j];
+    c[i] = b;
+    c[j] = a;
+  }
+}
+
+// ---------------------------------------------------------------- eval_at_point
+// value = sum_i coeff[i] * prod_{bits k of i} m_k,  m_0 = y, m_1 = x, m_k = pi^{k-1}(x).
+// Split i = (hi, lo) with lo = LOW_BITS bits: the per-point table lowtab[lo] (QM31, built by
+// k_point_table) is shared by every column of the batch; each block reduces one 2^LOW_BITS chunk
+// and multiplies by hightab[hi].  partial[col][chunk] -> k_reduce_partials sums chunks.
+constexpr uint32_t EAP_LOW_BITS = 10;
+
+// tab[i] = prod_{bits k of i} maps[first_bit + k], i < 2^nbits   (maps given as 4 u32 each)
+__global__ void k_point_table(const uint32_t* maps, uint32_t first_bit, uint32_t nbits, uint32_t* tab) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << nbits)) return;
+  QM31 r(M31(1));
+  for (uint32_t k = 0; k < nbits; k++)
+    if ((i >> k) & 1u) r = r * QM31::from_u32(maps + 4 * (first_bit + k));
+  r.to_u32(tab + 4 * i);
+}
+
+__global__ void __launch_bounds__(256) k_eval_at_point_partial(const uint32_t* const* coeffs, uint32_t log_n,
+                                                               const uint32_t* lowtab, const uint32_t* hightab,
+                                                               uint32_t* partial /*[ncols][nchunks][4]*/) {
+  const uint32_t low_bits = log_n < EAP_LOW_BITS ? log_n : EAP_LOW_BITS;
+  const uint32_t chunk = blockIdx.x, nchunks = gridDim.x;
+  const uint32_t* c = coeffs[blockIdx.y] + ((size_t)chunk << low_bits);
+  QM31 acc;
+  for (uint32_t i = threadIdx.x; i < (1u << low_bits); i += blockDim.x) {
+    QM31 t = QM31::from_u32(lowtab + 4 * i);
+    acc += t * M31(c[i]);
+  }
+  acc = block_reduce_qm31(acc);
+  if (threadIdx.x == 0) {
+    acc = acc * QM31::from_u32(hightab + 4 * chunk);
+    acc.to_u32(partial + 4 * ((size_t)blockIdx.y * nchunks + chunk));
+  }
+}
+__global__ void __launch_bounds__(256) k_reduce_partials(const uint32_t* partial, uint32_t nchunks, uint32_t* out) {
+  QM31 acc;
+  const uint32_t* p = partial + 4 * (size_t)blockIdx.x * nchunks;
+  for (uint32_t i = threadIdx.x; i < nchunks; i += blockDim.x) acc += QM31::from_u32(p + 4 * i);
+  acc = block_reduce_qm31(acc);
+  if (threadIdx.x == 0) acc.to_u32(out + 4 * blockIdx.x);
+}
+
+
+// ================================================================= host wrappers
+Twiddles* twiddles_create(uint32_t R, hipStream_t st) {
+  CM_CHECK(R >= 2 && R <= 30, "twiddles: log size out of range");
+  Twiddles* t = new Twiddles();
+  t->R = R;
+  size_t nx = (size_t)1 << (R - 1), ny = (size_t)1 << R;
+  CM_HIP(hipMalloc(&t->xtw, nx * 4));
+  CM_HIP(hipMalloc(&t->ixtw, nx * 4));
+  CM_HIP(hipMalloc(&t->ytw, ny * 4));
+  CM_HIP(hipMalloc(&t->iytw, ny * 4));
+  CM_HIP(hipMemsetAsync(t->ytw, 0, 4, st));
+  CM_HIP(hipMemsetAsync(t->iytw, 0, 4, st));
+  CM_HIP(hipMemsetAsync(t->xtw + (nx - 1), 0, 4, st));
+  CM_HIP(hipMemsetAsync(t->ixtw + (nx - 1), 0, 4, st));
+  hipLaunchKernelGGL(k_twiddles_x, dim3((nx + 255) / 256), dim3(256), 0, st, t->xtw, t->ixtw, R);
+  hipLaunchKernelGGL(k_twiddles_y, dim3((ny + 255) / 256), dim3(256), 0, st, t->ytw, t->iytw, R);
+  CM_HIP(hipGetLastError());
+  return t;
+}
+void twiddles_destroy(Twiddles* t) {
+  if (!t) return;
+  (void)hipFree(t->xtw); (void)hipFree(t->ixtw); (void)hipFree(t->ytw); (void)hipFree(t->iytw);
+  delete t;
+}
+
+constexpr uint32_t FFT_TILE_LOG = 11;   // 8 KiB of LDS per block
+constexpr uint32_t FFT_MAX_STRIDED_W = 7;
+
+// Plan: layers [0, k0) in one contiguous pass, the rest in strided passes of <= 7 layers.
+static void plan_passes(uint32_t n, std::vector<std::pair<uint32_t, uint32_t>>& passes) {
+  uint32_t k0 = n < FFT_TILE_LOG ? n : FFT_TILE_LOG;
+  passes.push_back({0, k0});
+  uint32_t rest = n - k0;
+  if (rest == 0) return;
+  uint32_t np = (rest + FFT_MAX_STRIDED_W - 1) / FFT_MAX_STRIDED_W;
+  uint32_t lo = k0;
+  for (uint32_t i = 0; i < np; i++) {
+    uint32_t w = (rest - (lo - k0) + (np - i) - 1) / (np - i);
+    passes.push_back({lo, lo + w});
+    lo += w;
+  }
+}
+template <bool INV>
+static void launch_pass(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n, uint32_t lo,
+                        uint32_t hi, uint32_t in_len, uint32_t scale, const Twiddles& tw, hipStream_t st) {
+  FftPassArgs a;
+  a.src = d_src; a.dst = d_dst;
+  a.xtw = INV ? tw.ixtw : tw.xtw;
+  a.ytw = INV ? tw.iytw : tw.ytw;
+  a.R = tw.R; a.n = n; a.lo = lo; a.hi = hi;
+  uint32_t W = hi - lo;
+  uint32_t M = 0;
+  if (lo > 0) { M = FFT_TILE_LOG - W; if (M > lo) M = lo; }
+  a.M = M; a.in_len = in_len; a.scale = scale;
+  uint32_t tile_log = W + M;
+  uint32_t ntiles = 1u << (n - tile_log);
+  size_t lds = (size_t)4 << tile_log;
+  hipLaunchKernelGGL(k_fft_pass<INV>, dim3(ntiles, ncols), dim3(256), lds, st, a);
+}
+void interpolate(uint32_t* const* d_cols, uint32_t ncols, uint32_t n, const Twiddles& tw, hipStream_t st) {
+  CM_CHECK(n >= 1 && n <= tw.R, "interpolate: log size exceeds twiddle table");
+  if (ncols == 0) return;
+  std::vector<std::pair<uint32_t, uint32_t>> passes;
+  plan_passes(n, passes);
+  uint32_t inv_n = inv(M31::from_u32(1u << n)).v;
+  for (size_t i = 0; i < passes.size(); i++) {
+    bool last = i + 1 == passes.size();
+    launch_pass<true>(d_cols, d_cols, ncols, n, passes[i].first, passes[i].second, 1u << n, last ? inv_n : 1u, tw, st);
+  }
+  CM_HIP(hipGetLastError());
+}
+void evaluate(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n_in, uint32_t n_out,
+              const Twiddles& tw, hipStream_t st) {
+  CM_CHECK(n_out >= n_in && n_out <= tw.R && n_out >= 1, "evaluate: bad log sizes");
+  if (ncols == 0) return;
+  std::vector<std::pair<uint32_t, uint32_t>> passes;
+  plan_passes(n_out, passes);
+  for (size_t k = passes.size(); k-- > 0;) {
+    bool first = k + 1 == passes.size();
+    launch_pass<false>(first ? d_src : (const uint32_t* const*)d_dst, d_dst, ncols, n_out, passes[k].first,
+                       passes[k].second, first ? (1u << n_in) : (1u << n_out), 1u, tw, st);
+  }
+  CM_HIP(hipGetLastError());
+}
+void bit_reverse_columns(uint32_t* const* d_cols, uint32_t ncols, uint32_t n, hipStream_t st) {
+  if (ncols == 0) return;
+  uint32_t N = 1u << n;
+  hipLaunchKernelGGL(k_bit_reverse, dim3((N + 255) / 256, ncols), dim3(256), 0, st, d_cols, n);
+  CM_HIP(hipGetLastError());
+}
+
+size_t eval_at_point_scratch_words(uint32_t ncols, uint32_t n) {
+  uint32_t low = n < EAP_LOW_BITS ? n : EAP_LOW_BITS;
+  uint32_t high = n - low;
+  return 32 * 4 + 4 * ((size_t)1 << low) + 4 * ((size_t)1 << high) + 4 * (size_t)ncols * ((size_t)1 << high);
+}
+void eval_at_point_batch(const uint32_t* const* d_coeffs, uint32_t ncols, uint32_t n, const QM31& px, const QM31& py,
+                         uint32_t* d_scratch, uint32_t* d_out, hipStream_t st) {
+  if (ncols == 0) return;
+  uint32_t low = n < EAP_LOW_BITS ? n : EAP_LOW_BITS;
+  uint32_t high = n - low;
+  // maps[k]: factor of index bit k
+  uint32_t maps[32 * 4] = {0};
+  py.to_u32(maps);
+  QM31 x = px;
+  for (uint32_t k = 1; k < n; k++) { x.to_u32(maps + 4 * k); x = double_x(x); }
+  uint32_t* d_maps = d_scratch;
+  uint32_t* d_low = d_maps + 32 * 4;
+  uint32_t* d_high = d_low + 4 * ((size_t)1 << low);
+  uint32_t* d_partial = d_high + 4 * ((size_t)1 << high);
+  CM_HIP(hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_point_table, dim3(((1u << low) + 255) / 256), dim3(256), 0, st, d_maps, 0u, low, d_low);
+  hipLaunchKernelGGL(k_point_table, dim3(((1u << high) + 255) / 256), dim3(256), 0, st, d_maps, low, high, d_high);
+  uint32_t nchunks = 1u << high;
+  hipLaunchKernelGGL(k_eval_at_point_partial, dim3(nchunks, ncols), dim3(256), 0, st, d_coeffs, n, d_low, d_high,
+                     d_partial);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(ncols), dim3(256), 0, st, d_partial, nchunks, d_out);
+  CM_HIP(hipGetLastError());
+}
+
+}  // namespace cm

@@ -1,0 +1,192 @@
+/*
+ * cairom_hip.h — C ABI of libcairom_hip.so, the MI355X (gfx950) proving backend for Cairo-M.
+ *
+ * Drop-in boundary for ONE path of kkrt-labs/cairo-m: `prove_cairo_m::<Blake2sMerkleChannel>`
+ * (crates/prover/src/prover.rs:23-147) and the Stwo backend-trait surface it drives
+ * (ColumnOps / PolyOps / MerkleOps / GrindOps / QuotientOps / FriOps / AccumulationOps), plus the
+ * Cairo-M component operations that are NOT reachable through those traits in the reference
+ * (trace generation, LogUp interaction trace, constraint-quotient evaluation).
+ *
+ * Conventions
+ *   - every function returns int32_t status: 0 = OK, non-zero = error; the message is available
+ *     through cm_last_error() (thread-local).
+ *   - cm_handle is an opaque 64-bit handle to library-owned device memory (a column = u32[n] of
+ *     canonical M31 values; evaluations are stored in Stwo's BitReversedOrder).  Handles are freed
+ *     by the caller with the matching cm_*_free.
+ *   - QM31 / SecureField values cross the boundary as uint32_t[4] = to_m31_array()
+ *     (reference layout: crates/prover/src/public_data.rs:146-149).
+ *   - all functions take a cm_stream_t (0 = the library's default stream) and are safe to call
+ *     concurrently from several host threads on different streams (the reference calls backend ops
+ *     from rayon workers).
+ *   - plain pointers and sizes only; no torch / C++ types.
+ */
+#ifndef CAIROM_HIP_H
+#define CAIROM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t cm_handle;
+typedef uint64_t cm_stream_t;
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+int32_t cm_init(int32_t device);
+int32_t cm_shutdown(void);
+int32_t cm_last_error(char* buf, size_t buf_len);
+int32_t cm_stream_create(cm_stream_t* out);
+int32_t cm_stream_destroy(cm_stream_t s);
+int32_t cm_stream_sync(cm_stream_t s);
+
+/* ---- Column<T> / ColumnOps (Stwo core::backend::{Column, ColumnOps}; used through
+ *      `ComponentTrace::to_evals`, crates/prover/src/components/mod.rs:168-177) ----------------- */
+int32_t cm_col_alloc(uint64_t n_u32, cm_handle* out);
+int32_t cm_col_free(cm_handle h);
+int32_t cm_col_h2d(cm_handle h, const uint32_t* src, uint64_t n_u32, cm_stream_t s);
+int32_t cm_col_d2h(cm_handle h, uint32_t* dst, uint64_t n_u32, cm_stream_t s);
+/* ColumnOps::bit_reverse_column, in place, on n_cols columns of 2^log_n */
+int32_t cm_bit_reverse(const cm_handle* cols, uint32_t n_cols, uint32_t log_n, cm_stream_t s);
+
+/* ---- PolyOps (Stwo core::poly::circle::PolyOps) --------------------------------------------- */
+/* PolyOps::precompute_twiddles for CanonicCoset(log_size).circle_domain().half_coset
+ * (reference: crates/prover/src/prover.rs:56-60). */
+int32_t cm_twiddles_precompute(uint32_t log_size, cm_handle* tw_out);
+int32_t cm_twiddles_free(cm_handle tw);
+/* PolyOps::interpolate_columns (reference: tree_builder.extend_evals, prover.rs:72, 81, 101):
+ * bit-reversed evaluations on CanonicCoset(log_n).circle_domain() -> coefficients, in place. */
+int32_t cm_interpolate(const cm_handle* cols, uint32_t n_cols, uint32_t log_n, cm_handle tw, cm_stream_t s);
+/* PolyOps::evaluate / evaluate_polynomials (reference: tree_builder.commit, prover.rs:73, 82, 102):
+ * coefficients of 2^log_n -> bit-reversed evaluations on CanonicCoset(log_out).circle_domain(). */
+int32_t cm_evaluate(const cm_handle* coeffs, uint32_t n_cols, uint32_t log_n, uint32_t log_out, cm_handle tw,
+                    const cm_handle* out, cm_stream_t s);
+/* PolyOps::eval_at_point for n_cols polynomials at one QM31 circle point (x[4], y[4]);
+ * out = n_cols * 4 u32 (host). */
+int32_t cm_eval_at_point(const cm_handle* coeffs, uint32_t n_cols, uint32_t log_n, const uint32_t pt_xy[8],
+                         uint32_t* out, cm_stream_t s);
+
+/* ---- MerkleOps<Blake2sMerkleHasher>::commit_on_layer (reached from tree_builder.commit) ----- */
+/* out_hashes: handle of 8 * 2^log_size u32.  prev_layer = 0 for the largest layer. */
+int32_t cm_merkle_commit_layer(uint32_t log_size, cm_handle prev_layer, const cm_handle* cols, uint32_t n_cols,
+                               cm_handle out_hashes, cm_stream_t s);
+/* Whole mixed-degree tree (Stwo MerkleProver::commit): columns in commitment order with their
+ * log sizes; writes the 32-byte root. */
+int32_t cm_merkle_commit(const cm_handle* cols, const uint32_t* col_logs, uint32_t n_cols, uint8_t root[32],
+                         cm_stream_t s);
+
+/* ---- GrindOps<Blake2sChannel>::grind (reference: prover.rs:90) ------------------------------- */
+int32_t cm_grind(const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce_out);
+
+/* ---- FieldOps::batch_inverse ---------------------------------------------------------------- */
+int32_t cm_batch_inverse_m31(cm_handle in, cm_handle out, uint64_t n, cm_stream_t s);
+int32_t cm_batch_inverse_qm31(const cm_handle in[4], const cm_handle out[4], uint64_t n, cm_stream_t s);
+
+/* ---- FriOps (Stwo core::fri::FriOps), SecureColumnByCoords = 4 coordinate handles ------------ */
+/* dst (line evaluation, 2^(log_n-1)) = dst * alpha^2 + fold(src circle evaluation of 2^log_n) */
+int32_t cm_fri_fold_circle_into_line(const cm_handle dst[4], const cm_handle src[4], const uint32_t alpha[4],
+                                     uint32_t log_n, cm_handle tw, cm_stream_t s);
+/* out (2^(log_n-1)) = fold_line(in (2^log_n), alpha) */
+int32_t cm_fri_fold_line(const cm_handle in[4], const uint32_t alpha[4], uint32_t log_n, cm_handle tw,
+                         const cm_handle out[4], cm_stream_t s);
+
+/* ---- QuotientOps::accumulate_quotients ------------------------------------------------------ */
+/* One call per distinct LDE log size.  cols: the n_cols committed LDE columns of that size.
+ * Sample batches (Stwo ColumnSampleBatch): batch b has point pts[b] (x[4],y[4]) and the entries
+ * batch_cols[batch_off[b] .. batch_off[b+1]) = (column index, sampled value[4]).
+ * out: 4 coordinate columns of 2^log_size. */
+typedef struct {
+  uint32_t n_batches;
+  const uint32_t* points;       /* n_batches * 8 */
+  const uint32_t* batch_off;    /* n_batches + 1 */
+  const uint32_t* col_index;    /* total entries */
+  const uint32_t* values;       /* total entries * 4 */
+} cm_sample_batches;
+int32_t cm_accumulate_quotients(uint32_t log_size, const cm_handle* cols, uint32_t n_cols,
+                                const cm_sample_batches* batches, const uint32_t random_coeff[4],
+                                const cm_handle out[4], cm_stream_t s);
+
+/* ---- Cairo-M prover input (mirror of crates/prover/src/adapter/mod.rs:27-83 ProverInput) ----- */
+#define CM_N_OPCODE_COMPONENTS 26
+#define CM_N_COMPONENTS 34
+
+/* ExecutionBundle (crates/prover/src/adapter/memory.rs:95-124) flattened the way
+ * PackedExecutionBundle does (crates/prover/src/utils/execution_bundle.rs:12-31). */
+typedef struct {
+  uint32_t pc, fp, clock, inst_prev_clock;
+  uint32_t inst[6];      /* instruction words incl. opcode, zero padded */
+  uint32_t span_start;   /* AccessSpan.start into data_accesses */
+  uint32_t span_len;     /* AccessSpan.len */
+} cm_bundle;
+/* DataAccess (adapter/memory.rs:57-67) */
+typedef struct {
+  uint32_t address, prev_clock, prev_value, value;
+} cm_data_access;
+/* one boundary memory cell: (addr, value[4], clock, multiplicity) (adapter/memory.rs:186-193) */
+typedef struct {
+  uint32_t address, value[4], clock, multiplicity;
+} cm_memory_cell;
+/* clock_update_data entry (adapter/memory.rs:192) */
+typedef struct {
+  uint32_t address, prev_clock, value[4];
+} cm_clock_update;
+/* NodeData (adapter/merkle.rs:92-104) */
+typedef struct {
+  uint32_t index, depth, left_value, right_value, parent_value, left_mult, right_mult, parent_mult;
+} cm_merkle_node;
+
+typedef struct {
+  /* Instructions (adapter/mod.rs:69-83) */
+  uint32_t initial_pc, initial_fp, final_pc, final_fp;
+  /* bundles grouped by opcode COMPONENT, in the macro order of
+   * crates/prover/src/components/opcodes/mod.rs:223-268 */
+  const cm_bundle* bundles[CM_N_OPCODE_COMPONENTS];
+  uint64_t n_bundles[CM_N_OPCODE_COMPONENTS];
+  const cm_data_access* data_accesses;
+  uint64_t n_data_accesses;
+  /* Memory (adapter/memory.rs:186-193): rows are given in the order the memory component must
+   * emit them (the reference iterates HashMaps; the caller fixes the order — SURVEY F3). */
+  const cm_memory_cell* initial_memory;
+  uint64_t n_initial_memory;
+  const cm_memory_cell* final_memory;
+  uint64_t n_final_memory;
+  const cm_clock_update* clock_updates;
+  uint64_t n_clock_updates;
+  /* MerkleTrees (adapter/mod.rs:47-58) */
+  const cm_merkle_node* initial_tree;
+  uint64_t n_initial_tree;
+  const cm_merkle_node* final_tree;
+  uint64_t n_final_tree;
+  uint32_t initial_root, final_root;
+  /* PublicAddressRanges (crates/common/src/program.rs:111-122): [start, end) */
+  uint32_t program_range[2], input_range[2], output_range[2];
+} cm_prover_input;
+
+/* PcsConfig (crates/prover/src/prover_config.rs:13-20) */
+typedef struct {
+  uint32_t pow_bits;
+  uint32_t log_blowup_factor;
+  uint32_t log_last_layer_degree_bound;
+  uint32_t n_queries;
+} cm_pcs_config;
+
+/* Proof object: opaque; serialised with cm_proof_json (serde layout of `Proof<Blake2sHash>`,
+ * crates/prover/src/lib.rs:61-73 + main.rs:86-91). */
+typedef struct cm_proof cm_proof;
+
+/* prove_cairo_m::<Blake2sMerkleChannel> (crates/prover/src/prover.rs:23-147).
+ * config == NULL selects REGULAR_96_BITS. */
+int32_t cm_prove_segment(const cm_prover_input* input, const cm_pcs_config* config, cm_proof** out);
+int32_t cm_proof_free(cm_proof* p);
+/* JSON text of the proof; *len_out = length without the terminating NUL; the buffer is owned by
+ * the proof object. */
+int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out);
+/* The four commitment roots (trees 0..3), 32 bytes each. */
+int32_t cm_proof_commitments(const cm_proof* p, uint8_t roots[4][32]);
+/* cells = sum over committed columns of trees 0,1,2 of 2^log_size. */
+int32_t cm_proof_stats(const cm_proof* p, uint64_t* cells, uint64_t* steps, double* phase_ms, uint32_t n_phases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAIROM_HIP_H */

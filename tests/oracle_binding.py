@@ -1,0 +1,82 @@
+"""ctypes binding of oracle/liboracle.so — the CPU restatement used as the parity checker."""
+import ctypes as C
+import numpy as np
+
+_u32p = C.POINTER(C.c_uint32)
+
+
+def _p(a):
+    return a.ctypes.data_as(_u32p)
+
+
+class Oracle:
+    def __init__(self, so):
+        self.L = C.CDLL(so)
+        self.L.orc_grind.restype = C.c_uint64
+
+    def interpolate(self, vals):
+        v = np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        self.L.orc_interpolate(_p(v), C.c_uint32(int(np.log2(v.size))))
+        return v
+
+    def evaluate(self, coeffs, log_out):
+        c = np.ascontiguousarray(coeffs, dtype=np.uint32)
+        out = np.empty(1 << log_out, dtype=np.uint32)
+        self.L.orc_evaluate(_p(c), C.c_uint32(int(np.log2(c.size))), _p(out), C.c_uint32(log_out))
+        return out
+
+    def eval_at_point(self, coeffs, pt_xy):
+        c = np.ascontiguousarray(coeffs, dtype=np.uint32)
+        pt = np.ascontiguousarray(pt_xy, dtype=np.uint32)
+        out = np.empty(4, dtype=np.uint32)
+        self.L.orc_eval_at_point(_p(c), C.c_uint32(int(np.log2(c.size))), _p(pt), _p(out))
+        return out
+
+    def domain_point(self, log, i):
+        xy = np.zeros(2, dtype=np.uint32)
+        self.L.orc_domain_point(C.c_uint32(log), C.c_uint64(i), _p(xy))
+        return int(xy[0]), int(xy[1])
+
+    def blake2s(self, data):
+        out = (C.c_uint8 * 32)()
+        self.L.orc_blake2s256(data, C.c_size_t(len(data)), out)
+        return bytes(out)
+
+    def merkle_commit(self, cols):
+        """cols: list of 1-D uint32 arrays (power-of-two lengths). Returns (root, layers bytes)."""
+        data = np.concatenate([np.ascontiguousarray(c, dtype=np.uint32) for c in cols])
+        logs = np.array([int(np.log2(c.size)) for c in cols], dtype=np.uint32)
+        mx = int(logs.max())
+        root = (C.c_uint8 * 32)()
+        layers = np.zeros(((2 << mx) - 1) * 8, dtype=np.uint32)
+        self.L.orc_merkle_commit(_p(data), _p(logs), C.c_size_t(len(cols)), root,
+                                 layers.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return bytes(root), layers
+
+    def grind(self, digest, bits):
+        d = (C.c_uint8 * 32)(*digest)
+        return int(self.L.orc_grind(d, C.c_uint32(bits)))
+
+    def m31_mul(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)
+        o = np.empty_like(a)
+        self.L.orc_m31_mul(_p(a), _p(b), _p(o), C.c_size_t(a.size))
+        return o
+
+    def m31_inv(self, a):
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        o = np.empty_like(a)
+        self.L.orc_m31_inv(_p(a), _p(o), C.c_size_t(a.size))
+        return o
+
+    def qm31_mul(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)
+        o = np.empty_like(a)
+        self.L.orc_qm31_mul(_p(a), _p(b), _p(o), C.c_size_t(a.size // 4))
+        return o
+
+    def qm31_inv(self, a):
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        o = np.empty_like(a)
+        self.L.orc_qm31_inv(_p(a), _p(o), C.c_size_t(a.size // 4))
+        return o

@@ -1,0 +1,90 @@
+"""GPU parity (through the C ABI) for the commit path: circle IFFT / LDE, eval_at_point,
+Blake2s Merkle layers, grind — bit-exact against the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+
+P = 2**31 - 1
+pytestmark = pytest.mark.gpu
+
+
+def rand_cols(rng, ncols, log_n):
+    return [rng.integers(0, P, size=1 << log_n, dtype=np.uint32) for _ in range(ncols)]
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 4, 5, 10, 11, 12, 13, 16, 18])
+def test_interpolate_evaluate_parity(backend, oracle, log_n):
+    rng = np.random.default_rng(100 + log_n)
+    tw = backend.twiddles(log_n + 1)
+    cols = rand_cols(rng, 3, log_n)
+    hs = [backend.upload(c) for c in cols]
+    backend.interpolate(hs, log_n, tw)
+    for h, c in zip(hs, cols):
+        got = backend.download(h, 1 << log_n)
+        assert np.array_equal(got, oracle.interpolate(c))
+    outs = [backend.col_alloc(2 << log_n) for _ in cols]
+    backend.evaluate(hs, log_n, log_n + 1, tw, outs)
+    for h, o, c in zip(hs, outs, cols):
+        coeffs = backend.download(h, 1 << log_n)
+        assert np.array_equal(backend.download(o, 2 << log_n), oracle.evaluate(coeffs, log_n + 1))
+    # same-size evaluate is the inverse of interpolate (round trip)
+    outs2 = [backend.col_alloc(1 << log_n) for _ in cols]
+    backend.evaluate(hs, log_n, log_n, tw, outs2)
+    for o, c in zip(outs2, cols):
+        assert np.array_equal(backend.download(o, 1 << log_n), c)
+    for h in hs + outs + outs2:
+        backend.col_free(h)
+    backend.twiddles_free(tw)
+
+
+def test_lde_roundtrip_large(backend):
+    """Full-size property check (no oracle): 2^22 -> LDE 2^23 -> every even-half restriction
+    interpolates back; here: interpolate(evaluate(c, n), n) == c and linearity."""
+    log_n = 22
+    rng = np.random.default_rng(7)
+    tw = backend.twiddles(log_n + 1)
+    a = rng.integers(0, P, size=1 << log_n, dtype=np.uint32)
+    b = rng.integers(0, P, size=1 << log_n, dtype=np.uint32)
+    s = ((a.astype(np.uint64) + b) % P).astype(np.uint32)
+    ha, hb, hs_ = backend.upload(a), backend.upload(b), backend.upload(s)
+    oa, ob, os_ = (backend.col_alloc(2 << log_n) for _ in range(3))
+    backend.evaluate([ha, hb, hs_], log_n, log_n + 1, tw, [oa, ob, os_])
+    ea, eb, es = (backend.download(o, 2 << log_n) for o in (oa, ob, os_))
+    assert np.array_equal(((ea.astype(np.uint64) + eb) % P).astype(np.uint32), es)
+    backend.interpolate([oa], log_n + 1, tw)
+    back = backend.download(oa, 2 << log_n)
+    assert np.array_equal(back[: 1 << log_n], a) and not back[1 << log_n:].any()
+    for h in (ha, hb, hs_, oa, ob, os_):
+        backend.col_free(h)
+    backend.twiddles_free(tw)
+
+
+@pytest.mark.parametrize("log_n", [3, 9, 10, 11, 15])
+def test_eval_at_point_parity(backend, oracle, log_n):
+    rng = np.random.default_rng(5 + log_n)
+    cols = rand_cols(rng, 4, log_n)
+    hs = [backend.upload(c) for c in cols]
+    pt = rng.integers(0, P, size=8, dtype=np.uint32)
+    got = backend.eval_at_point(hs, log_n, pt)
+    for g, c in zip(got, cols):
+        assert np.array_equal(g, oracle.eval_at_point(c, pt))
+    for h in hs:
+        backend.col_free(h)
+
+
+@pytest.mark.parametrize("logs", [[6, 6, 6], [8] * 17 + [5] * 3 + [3], [10] * 40 + [9] * 16 + [4] * 5, [1], [12, 3]])
+def test_merkle_commit_parity(backend, oracle, logs):
+    rng = np.random.default_rng(len(logs))
+    cols = [rng.integers(0, P, size=1 << l, dtype=np.uint32) for l in logs]
+    hs = [backend.upload(c) for c in cols]
+    root = backend.merkle_commit(hs, logs)
+    want, _ = oracle.merkle_commit(cols)
+    assert root == want
+    for h in hs:
+        backend.col_free(h)
+
+
+def test_grind_parity(backend, oracle):
+    rng = np.random.default_rng(3)
+    for bits in (2, 8, 16):
+        digest = bytes(rng.integers(0, 256, size=32, dtype=np.uint8))
+        assert backend.grind(digest, bits) == oracle.grind(digest, bits)
