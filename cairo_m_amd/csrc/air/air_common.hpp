@@ -158,5 +158,17 @@ AIR_HD Access access_at(const Bundle& b, const Access* acc, uint32_t k) {
 constexpr uint32_t RC20_LIMIT = (1u << 20) - 1;  // adapter/memory.rs:15
 constexpr uint32_t TREE_HEIGHT = 30;             // adapter/merkle.rs:63
 constexpr uint32_t M31_P = 0x7fffffffu;
+// compile-time M31 inverse (x^(P-2)) for AIR constants such as (44-8)^-1
+constexpr uint32_t m31_mul_const(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % M31_P); }
+constexpr uint32_t m31_inv_const(uint32_t x) {
+  uint32_t r = 1, b = x % M31_P;
+  uint32_t e = M31_P - 2;
+  while (e) {
+    if (e & 1) r = m31_mul_const(r, b);
+    b = m31_mul_const(b, b);
+    e >>= 1;
+  }
+  return r;
+}
 
 }  // namespace air

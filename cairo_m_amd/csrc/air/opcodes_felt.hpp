@@ -294,4 +294,251 @@ struct CallAbsImm {
   }
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// assert_eq_fp_imm.rs (opcode 50) — 9 columns.  witness: assert_eq_fp_imm.rs:105-190, eval: :300-417
+struct AssertEqFpImm {
+  static constexpr int N_TRACE = 9;
+  template <class O>
+  static AIR_HD void witness(const Bundle& b, const Access* acc, uint32_t enabler, typename O::M* o) {
+    Access a0 = access_at(b, acc, 0);
+    o[0] = O::mk(enabler); o[1] = O::mk(b.pc); o[2] = O::mk(b.fp); o[3] = O::mk(b.clock); o[4] = O::mk(b.inst_prev_clock);
+    o[5] = O::mk(b.inst[1]); o[6] = O::mk(b.inst[2]); o[7] = O::mk(a0.prev_clock); o[8] = O::mk(a0.value);
+  }
+  template <class E>
+  static AIR_HD void eval(E& e) {
+    using F = typename E::F;
+    F one = e.c(1), opc = e.c(OP_ASSERT_EQ_FP_IMM);
+    F enabler = e.next(), pc = e.next(), fp = e.next(), clock = e.next(), inst_prev_clock = e.next();
+    F src0_off = e.next(), imm = e.next(), op0_prev_clock = e.next(), op0_val = e.next();
+    e.constraint(enabler * (one - enabler));
+    e.constraint(op0_val - imm);
+    e.rel(REL_REGISTERS, -enabler, pc, fp, clock);
+    e.rel(REL_REGISTERS, enabler, pc + one, fp, clock + one);
+    e.rel(REL_MEMORY, -enabler, pc, inst_prev_clock, opc, src0_off, imm);
+    e.rel(REL_MEMORY, enabler, pc, clock, opc, src0_off, imm);
+    e.rel(REL_MEMORY, -enabler, fp + src0_off, op0_prev_clock, op0_val);
+    e.rel(REL_MEMORY, enabler, fp + src0_off, clock, op0_val);
+    F m1 = e.c(M31_P - 1);
+    e.rel(REL_RC20, m1, clock - inst_prev_clock - enabler);
+    e.rel(REL_RC20, m1, clock - op0_prev_clock - enabler);
+    e.finalize_pairs();
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// store_frame_pointer.rs (opcode 43) — 9 columns.  witness: store_frame_pointer.rs:107-190, eval: :300-417
+struct StoreFramePointer {
+  static constexpr int N_TRACE = 9;
+  template <class O>
+  static AIR_HD void witness(const Bundle& b, const Access* acc, uint32_t enabler, typename O::M* o) {
+    Access a0 = access_at(b, acc, 0);
+    o[0] = O::mk(enabler); o[1] = O::mk(b.pc); o[2] = O::mk(b.fp); o[3] = O::mk(b.clock); o[4] = O::mk(b.inst_prev_clock);
+    o[5] = O::mk(b.inst[1]); o[6] = O::mk(b.inst[2]); o[7] = O::mk(a0.prev_value); o[8] = O::mk(a0.prev_clock);
+  }
+  template <class E>
+  static AIR_HD void eval(E& e) {
+    using F = typename E::F;
+    F one = e.c(1), opc = e.c(OP_STORE_FRAME_POINTER);
+    F enabler = e.next(), pc = e.next(), fp = e.next(), clock = e.next(), inst_prev_clock = e.next();
+    F imm = e.next(), dst_off = e.next(), dst_prev_val = e.next(), dst_prev_clock = e.next();
+    e.constraint(enabler * (one - enabler));
+    e.rel(REL_REGISTERS, -enabler, pc, fp, clock);
+    e.rel(REL_REGISTERS, enabler, pc + one, fp, clock + one);
+    e.rel(REL_MEMORY, -enabler, pc, inst_prev_clock, opc, imm, dst_off);
+    e.rel(REL_MEMORY, enabler, pc, clock, opc, imm, dst_off);
+    e.rel(REL_MEMORY, -enabler, fp + dst_off, dst_prev_clock, dst_prev_val);
+    e.rel(REL_MEMORY, enabler, fp + dst_off, clock, fp + imm);
+    F m1 = e.c(M31_P - 1);
+    e.rel(REL_RC20, m1, clock - inst_prev_clock - enabler);
+    e.rel(REL_RC20, m1, clock - dst_prev_clock - enabler);
+    e.finalize_pairs();
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// double_deref_fp_imm.rs (opcodes 8 StoreDoubleDerefFp, 44 StoreToDoubleDerefFpImm) — 17 columns
+// witness: double_deref_fp_imm.rs:139-250, eval: :378-509
+struct DoubleDerefFpImm {
+  static constexpr int N_TRACE = 17;
+  static constexpr uint32_t DELTA_INV = m31_inv_const(OP_STORE_TO_DOUBLE_DEREF_FP_IMM - OP_STORE_DOUBLE_DEREF_FP);
+  template <class O>
+  static AIR_HD void witness(const Bundle& b, const Access* acc, uint32_t enabler, typename O::M* o) {
+    using M = typename O::M;
+    M opc = O::mk(b.inst[0] == OP_RET ? OP_STORE_DOUBLE_DEREF_FP : b.inst[0]);
+    Access a0 = access_at(b, acc, 0), a1 = access_at(b, acc, 1), a2 = access_at(b, acc, 2);
+    M one = O::mk(1), fp = O::mk(b.fp), off1 = O::mk(b.inst[2]), off2 = O::mk(b.inst[3]), val0 = O::mk(a0.value);
+    M write_lhs = (opc - O::mk(OP_STORE_DOUBLE_DEREF_FP)) * O::mk(DELTA_INV);
+    M addr1 = write_lhs * (fp + off2) + (one - write_lhs) * (val0 + off1);
+    M addr2 = write_lhs * (val0 + off1) + (one - write_lhs) * (fp + off2);
+    o[0] = O::mk(enabler); o[1] = O::mk(b.pc); o[2] = fp; o[3] = O::mk(b.clock); o[4] = O::mk(b.inst_prev_clock);
+    o[5] = opc; o[6] = O::mk(b.inst[1]); o[7] = off1; o[8] = off2; o[9] = val0; o[10] = O::mk(a0.prev_clock);
+    o[11] = addr1; o[12] = O::mk(a1.value); o[13] = O::mk(a1.prev_clock); o[14] = addr2;
+    o[15] = O::mk(a2.prev_value); o[16] = O::mk(a2.prev_clock);
+  }
+  template <class E>
+  static AIR_HD void eval(E& e) {
+    using F = typename E::F;
+    F one = e.c(1);
+    F enabler = e.next(), pc = e.next(), fp = e.next(), clock = e.next(), inst_prev_clock = e.next();
+    F opc = e.next(), off0 = e.next(), off1 = e.next(), off2 = e.next(), val0 = e.next(), prev_clock0 = e.next();
+    F addr1 = e.next(), val1 = e.next(), prev_clock1 = e.next(), addr2 = e.next(), prev_val2 = e.next(), prev_clock2 = e.next();
+    F write_lhs = (opc - e.c(OP_STORE_DOUBLE_DEREF_FP)) * e.c(DELTA_INV);
+    e.constraint(enabler * (one - enabler));
+    e.constraint(write_lhs * (one - write_lhs));
+    e.constraint(enabler * (addr1 - write_lhs * (fp + off2) - (one - write_lhs) * (val0 + off1)));
+    e.constraint(enabler * (addr2 - write_lhs * (val0 + off1) - (one - write_lhs) * (fp + off2)));
+    e.rel(REL_REGISTERS, -enabler, pc, fp, clock);
+    e.rel(REL_REGISTERS, enabler, pc + one, fp, clock + one);
+    e.rel(REL_MEMORY, -enabler, pc, inst_prev_clock, opc, off0, off1, off2);
+    e.rel(REL_MEMORY, enabler, pc, clock, opc, off0, off1, off2);
+    e.rel(REL_MEMORY, -enabler, fp + off0, prev_clock0, val0);
+    e.rel(REL_MEMORY, enabler, fp + off0, clock, val0);
+    e.rel(REL_MEMORY, -enabler, addr1, prev_clock1, val1);
+    e.rel(REL_MEMORY, enabler, addr1, clock, val1);
+    e.rel(REL_MEMORY, -enabler, addr2, prev_clock2, prev_val2);
+    e.rel(REL_MEMORY, enabler, addr2, clock, val1);
+    F m1 = e.c(M31_P - 1);
+    e.rel(REL_RC20, m1, clock - inst_prev_clock - enabler);
+    e.rel(REL_RC20, m1, clock - prev_clock0 - enabler);
+    e.rel(REL_RC20, m1, clock - prev_clock1 - enabler);
+    e.rel(REL_RC20, m1, clock - prev_clock2 - enabler);
+    e.finalize_pairs();
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// double_deref_fp_fp.rs (opcodes 42 StoreDoubleDerefFpFp, 45 StoreToDoubleDerefFpFp) — 19 columns
+// witness: double_deref_fp_fp.rs:145-265, eval: :410-562
+struct DoubleDerefFpFp {
+  static constexpr int N_TRACE = 19;
+  static constexpr uint32_t DELTA_INV = m31_inv_const(OP_STORE_TO_DOUBLE_DEREF_FP_FP - OP_STORE_DOUBLE_DEREF_FP_FP);
+  template <class O>
+  static AIR_HD void witness(const Bundle& b, const Access* acc, uint32_t enabler, typename O::M* o) {
+    using M = typename O::M;
+    M opc = O::mk(b.inst[0] == OP_RET ? OP_STORE_DOUBLE_DEREF_FP_FP : b.inst[0]);
+    Access a0 = access_at(b, acc, 0), a1 = access_at(b, acc, 1), a2 = access_at(b, acc, 2), a3 = access_at(b, acc, 3);
+    M one = O::mk(1), fp = O::mk(b.fp), off2 = O::mk(b.inst[3]), val0 = O::mk(a0.value), val1 = O::mk(a1.value);
+    M write_lhs = (opc - O::mk(OP_STORE_DOUBLE_DEREF_FP_FP)) * O::mk(DELTA_INV);
+    M addr2 = write_lhs * (fp + off2) + (one - write_lhs) * (val0 + val1);
+    M addr3 = write_lhs * (val0 + val1) + (one - write_lhs) * (fp + off2);
+    o[0] = O::mk(enabler); o[1] = O::mk(b.pc); o[2] = fp; o[3] = O::mk(b.clock); o[4] = O::mk(b.inst_prev_clock);
+    o[5] = opc; o[6] = O::mk(b.inst[1]); o[7] = O::mk(b.inst[2]); o[8] = off2;
+    o[9] = val0; o[10] = O::mk(a0.prev_clock); o[11] = val1; o[12] = O::mk(a1.prev_clock);
+    o[13] = addr2; o[14] = O::mk(a2.value); o[15] = O::mk(a2.prev_clock);
+    o[16] = addr3; o[17] = O::mk(a3.prev_value); o[18] = O::mk(a3.prev_clock);
+  }
+  template <class E>
+  static AIR_HD void eval(E& e) {
+    using F = typename E::F;
+    F one = e.c(1);
+    F enabler = e.next(), pc = e.next(), fp = e.next(), clock = e.next(), inst_prev_clock = e.next();
+    F opc = e.next(), off0 = e.next(), off1 = e.next(), off2 = e.next();
+    F val0 = e.next(), prev_clock0 = e.next(), val1 = e.next(), prev_clock1 = e.next();
+    F addr2 = e.next(), val2 = e.next(), prev_clock2 = e.next(), addr3 = e.next(), prev_val3 = e.next(), prev_clock3 = e.next();
+    F write_lhs = (opc - e.c(OP_STORE_DOUBLE_DEREF_FP_FP)) * e.c(DELTA_INV);
+    e.constraint(enabler * (one - enabler));
+    e.constraint(write_lhs * (one - write_lhs));
+    e.constraint(enabler * (addr2 - write_lhs * (fp + off2) - (one - write_lhs) * (val0 + val1)));
+    e.constraint(enabler * (addr3 - write_lhs * (val0 + val1) - (one - write_lhs) * (fp + off2)));
+    e.rel(REL_REGISTERS, -enabler, pc, fp, clock);
+    e.rel(REL_REGISTERS, enabler, pc + one, fp, clock + one);
+    e.rel(REL_MEMORY, -enabler, pc, inst_prev_clock, opc, off0, off1, off2);
+    e.rel(REL_MEMORY, enabler, pc, clock, opc, off0, off1, off2);
+    e.rel(REL_MEMORY, -enabler, fp + off0, prev_clock0, val0);
+    e.rel(REL_MEMORY, enabler, fp + off0, clock, val0);
+    e.rel(REL_MEMORY, -enabler, fp + off1, prev_clock1, val1);
+    e.rel(REL_MEMORY, enabler, fp + off1, clock, val1);
+    e.rel(REL_MEMORY, -enabler, addr2, prev_clock2, val2);
+    e.rel(REL_MEMORY, enabler, addr2, clock, val2);
+    e.rel(REL_MEMORY, -enabler, addr3, prev_clock3, prev_val3);
+    e.rel(REL_MEMORY, enabler, addr3, clock, val2);
+    F m1 = e.c(M31_P - 1);
+    e.rel(REL_RC20, m1, clock - inst_prev_clock - enabler);
+    e.rel(REL_RC20, m1, clock - prev_clock0 - enabler);
+    e.rel(REL_RC20, m1, clock - prev_clock1 - enabler);
+    e.rel(REL_RC20, m1, clock - prev_clock2 - enabler);
+    e.rel(REL_RC20, m1, clock - prev_clock3 - enabler);
+    e.finalize_pairs();
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// store_le_fp_imm.rs (opcode 48) — 22 columns.  witness: store_le_fp_imm.rs:225-400, eval: :520-747
+struct StoreLeFpImm {
+  static constexpr int N_TRACE = 22;
+  static constexpr uint32_t PRIME_OVER_3_HIGH = ((M31_P / 3) >> 16) + 1;  // store_le_fp_imm.rs:132
+  static constexpr uint32_t PRIME_OVER_2_HIGH = ((M31_P / 2) >> 16) + 1;  // :133
+  template <class O>
+  static AIR_HD void witness(const Bundle& b, const Access* acc, uint32_t enabler, typename O::M* o) {
+    Access a0 = access_at(b, acc, 0), a1 = access_at(b, acc, 1);
+    uint32_t src = a0.value, imm = b.inst[2];
+    uint32_t is_le = src <= imm ? 1u : 0u;
+    uint32_t a = is_le ? src : imm, bb = is_le ? imm : src;
+    // three arcs, stable sort by length (store_le_fp_imm.rs:303-315)
+    uint32_t len[3] = {a, bb >= a ? bb - a : 0u, M31_P - 1 - bb};
+    uint32_t idx[3] = {0, 1, 2};
+    for (int i = 1; i < 3; i++)
+      for (int j = i; j > 0 && len[j - 1] > len[j]; j--) {
+        uint32_t t = len[j]; len[j] = len[j - 1]; len[j - 1] = t;
+        t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t;
+      }
+    uint32_t exclude = idx[2];
+    uint32_t k01 = 0, k02 = 0, k12 = 0;
+    if (enabler == 1) { k01 = exclude == 2; k02 = exclude == 1; k12 = exclude == 0; }
+    o[0] = O::mk(enabler); o[1] = O::mk(b.pc); o[2] = O::mk(b.fp); o[3] = O::mk(b.clock); o[4] = O::mk(b.inst_prev_clock);
+    o[5] = O::mk(b.inst[1]); o[6] = O::mk(imm); o[7] = O::mk(b.inst[3]);
+    o[8] = O::mk(src); o[9] = O::mk(a0.prev_clock); o[10] = O::mk(a1.prev_value); o[11] = O::mk(a1.prev_clock);
+    o[12] = O::mk(a); o[13] = O::mk(bb); o[14] = O::mk(k01); o[15] = O::mk(k02); o[16] = O::mk(k12);
+    o[17] = O::mk(len[0] % PRIME_OVER_3_HIGH); o[18] = O::mk(len[0] / PRIME_OVER_3_HIGH);
+    o[19] = O::mk(len[1] % PRIME_OVER_2_HIGH); o[20] = O::mk(len[1] / PRIME_OVER_2_HIGH);
+    o[21] = O::mk(is_le);
+  }
+  template <class E>
+  static AIR_HD void eval(E& e) {
+    using F = typename E::F;
+    F one = e.c(1), opc = e.c(OP_STORE_LE_FP_IMM), p3 = e.c(PRIME_OVER_3_HIGH), p2 = e.c(PRIME_OVER_2_HIGH);
+    F enabler = e.next(), pc = e.next(), fp = e.next(), clock = e.next(), inst_prev_clock = e.next();
+    F src_off = e.next(), imm = e.next(), dst_off = e.next(), src_val = e.next(), src_prev_clock = e.next();
+    F dst_prev_val = e.next(), dst_prev_clock = e.next(), a = e.next(), b = e.next();
+    F keep_0_1 = e.next(), keep_0_2 = e.next(), keep_1_2 = e.next();
+    F arc_short_lo = e.next(), arc_short_hi = e.next(), arc_long_lo = e.next(), arc_long_hi = e.next(), is_le = e.next();
+    e.constraint(enabler * (one - enabler));
+    e.constraint(keep_0_1 * (one - keep_0_1));
+    e.constraint(keep_0_2 * (one - keep_0_2));
+    e.constraint(keep_1_2 * (one - keep_1_2));
+    e.constraint(enabler * (keep_0_1 + keep_0_2 + keep_1_2 - one));
+    e.constraint(is_le * (one - is_le));
+    F arc_short = arc_short_lo + arc_short_hi * p3;
+    F arc_long = arc_long_lo + arc_long_hi * p2;
+    F arc_sum = arc_short + arc_long;
+    F arc_prod = arc_short * arc_long;
+    e.constraint(keep_0_1 * (arc_sum - (a + b - a)));
+    e.constraint(keep_0_1 * (arc_prod - a * (b - a)));
+    e.constraint(keep_0_2 * (arc_sum - (a - one - b)));
+    e.constraint(keep_0_2 * (arc_prod - a * (-one - b)));
+    e.constraint(keep_1_2 * (arc_sum - (b - a - one - b)));
+    e.constraint(keep_1_2 * (arc_prod - (b - a) * (-one - b)));
+    e.constraint(enabler * (a - is_le * src_val - (one - is_le) * imm));
+    e.constraint(enabler * (b - is_le * imm - (one - is_le) * src_val));
+    e.rel(REL_REGISTERS, -enabler, pc, fp, clock);
+    e.rel(REL_REGISTERS, enabler, pc + one, fp, clock + one);
+    e.rel(REL_MEMORY, -enabler, pc, inst_prev_clock, opc, src_off, imm, dst_off);
+    e.rel(REL_MEMORY, enabler, pc, clock, opc, src_off, imm, dst_off);
+    e.rel(REL_MEMORY, -enabler, fp + src_off, src_prev_clock, src_val);
+    e.rel(REL_MEMORY, enabler, fp + src_off, clock, src_val);
+    e.rel(REL_MEMORY, -enabler, fp + dst_off, dst_prev_clock, dst_prev_val);
+    e.rel(REL_MEMORY, enabler, fp + dst_off, clock, is_le);
+    F m1 = e.c(M31_P - 1);
+    e.rel(REL_RC16, m1, arc_short_lo);
+    e.rel(REL_RC16, m1, arc_short_hi);
+    e.rel(REL_RC16, m1, arc_long_lo);
+    e.rel(REL_RC16, m1, arc_long_hi);
+    e.rel(REL_RC20, m1, clock - inst_prev_clock - enabler);
+    e.rel(REL_RC20, m1, clock - src_prev_clock - enabler);
+    e.rel(REL_RC20, m1, clock - dst_prev_clock - enabler);
+    e.finalize_pairs();
+  }
+};
+
 }  // namespace air
