@@ -43,6 +43,11 @@ std::vector<uint32_t*> ptrs(const cm_handle* hs, uint32_t n) {
 
 extern "C" {
 
+int32_t cm_set_last_error(const char* msg) {
+  g_last_error = msg;
+  return 1;
+}
+
 int32_t cm_last_error(char* buf, size_t buf_len) {
   if (!buf || !buf_len) return (int32_t)g_last_error.size();
   size_t n = g_last_error.size() < buf_len - 1 ? g_last_error.size() : buf_len - 1;

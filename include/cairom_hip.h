@@ -162,6 +162,24 @@ typedef struct {
   uint32_t program_range[2], input_range[2], output_range[2];
 } cm_prover_input;
 
+/* ---- host-side input pipeline (no GPU needed) ------------------------------------------------------
+ * Synthetic VM + adapter: runs a CASM program (instruction = 1..6 M31 words, opcode first; encodings of
+ * crates/common/src/instruction.rs:314-577) from `entry_pc` with the runner's calling convention
+ * (crates/runner/src/vm/mod.rs:249-281), cuts segments every max_steps like vm/mod.rs:158-240, and
+ * converts segment `segment_index` with `import_from_runner_output`
+ * (crates/prover/src/adapter/mod.rs:251-266).  Memory rows are emitted in ascending address order. */
+typedef struct cm_host_input cm_host_input;
+int32_t cm_vm_run(const uint32_t* instr_words, const uint32_t* instr_lens, uint32_t n_instr, uint32_t entry_pc,
+                  const uint32_t* args, uint32_t n_args, uint32_t n_returns, uint64_t max_steps,
+                  uint32_t segment_index, cm_host_input** out, uint32_t* n_segments_out);
+/* The hand-assembled fibonacci_loop of SURVEY §8d: 10*n + 12 steps. */
+int32_t cm_synth_fibonacci(uint32_t n, uint64_t max_steps, uint32_t segment_index, cm_host_input** out);
+const cm_prover_input* cm_host_input_view(const cm_host_input* h);
+uint64_t cm_host_input_steps(const cm_host_input* h);
+int32_t cm_host_input_free(cm_host_input* h);
+/* Poseidon2-M31 t=16 permutation in place (reference KAT: crates/prover/tests/poseidon2.rs:14-34). */
+int32_t cm_poseidon2_permute(uint32_t state[16]);
+
 /* PcsConfig (crates/prover/src/prover_config.rs:13-20) */
 typedef struct {
   uint32_t pow_bits;
