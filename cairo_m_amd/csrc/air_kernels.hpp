@@ -1,0 +1,42 @@
+// Host-visible declarations of the per-component AIR kernels (kernels_air.hip).
+#pragma once
+#include "engine.hpp"
+
+namespace cm {
+
+struct DevRelations;
+struct HistPtrs;
+
+struct ConstraintArgs {
+  const uint32_t* const* tr;    // tree-1 LDE columns of the component (device array)
+  const uint32_t* const* it;    // tree-2 LDE columns of the component
+  const uint32_t* const* pp;    // tree-0 LDE columns by PreprocId
+  const DevRelations* rels;
+  const uint32_t* coeff;        // random-coefficient powers of this component's constraints (4 u32 each)
+  uint32_t* const* acc;         // 4 accumulator columns of 2^(log_size+1)
+  uint32_t log_size;            // trace log size
+  int n_base;                   // number of add_constraint constraints
+  uint32_t cumsum_shift[4];
+  uint32_t denom_inv[2];        // 1 / coset_vanishing on the two cosets of the evaluation domain
+};
+
+void launch_opcode_trace(int cid, const void* bundles, uint32_t n, const void* acc, uint32_t log_size, uint32_t* const* d_cols,
+                         hipStream_t st);
+void launch_memory_trace(const void* init, uint32_t ni, const void* fin, uint32_t nf, uint32_t root_i, uint32_t root_f,
+                         uint32_t log_size, uint32_t* const* d_cols, hipStream_t st);
+void launch_merkle_trace(const void* init, uint32_t ni, const void* fin, uint32_t nf, uint32_t root_i, uint32_t root_f,
+                         uint32_t log_size, uint32_t* const* d_cols, hipStream_t st);
+void launch_clock_update_trace(const void* rows, uint32_t n, uint32_t log_size, uint32_t* const* d_cols, hipStream_t st);
+void launch_poseidon2_trace(const void* init, uint32_t ni, const void* fin, uint32_t nf, uint32_t log_size,
+                            uint32_t* const* d_cols, hipStream_t st);
+void launch_hist(int cid, const uint32_t* const* d_cols, uint32_t log_size, const HistPtrs& h, hipStream_t st);
+void launch_logup(int cid, const uint32_t* const* d_cols, const uint32_t* const* d_pp, uint32_t log_size,
+                  const DevRelations* d_rels, uint32_t* const* d_out, hipStream_t st);
+void launch_constraints(int cid, const ConstraintArgs& a, hipStream_t st);
+size_t logup_finalize_scratch_words(uint32_t log_size);
+void logup_finalize_last(uint32_t* const* d_cols4, uint32_t log_size, uint32_t* d_scratch, uint32_t* h_claimed_sum,
+                         hipStream_t st);
+void launch_preproc(int pp_id, uint32_t log_size, uint32_t* d_col, hipStream_t st);
+void add_columns(uint32_t* const* d_dst, const uint32_t* const* d_src, uint32_t ncols, uint32_t n, hipStream_t st);
+
+}  // namespace cm

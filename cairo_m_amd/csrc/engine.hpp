@@ -19,6 +19,8 @@ void twiddles_destroy(Twiddles* t);
 
 // in-place IFFT of ncols columns of 2^n (bit-reversed evals -> coefficients)
 void interpolate(uint32_t* const* d_cols, uint32_t ncols, uint32_t n, const Twiddles& tw, hipStream_t st);
+void interpolate_oop(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n, const Twiddles& tw,
+                     hipStream_t st);
 // coefficients (2^n_in each) -> evaluations on the canonic domain of log n_out (n_out >= n_in)
 void evaluate(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n_in, uint32_t n_out,
               const Twiddles& tw, hipStream_t st);

@@ -1,0 +1,138 @@
+// Device-side evaluators over the shared AIR descriptions (air/*.hpp): one thread = one row.
+//   TraceGen   — Claim::write_trace row closures -> column-major stores (coalesced per column)
+//   HistEval   — range-check / bitwise multiplicities (global atomics; reference: relaxed AtomicU32,
+//                range_check_macro.rs:72-79, bitwise.rs:86-109)
+//   LogupEval  — LogUp interaction columns (write_interaction_trace + LogupTraceGenerator::finalize_col)
+//   DomainEval — FrameworkComponent::evaluate_constraint_quotients_on_domain (hot loop A)
+// Relations / random-coefficient powers are wave-uniform and come through scalar loads.
+#pragma once
+#include "field.hpp"
+#include "air/components.hpp"
+
+namespace cm {
+
+struct DevOps {
+  using M = M31;
+  static CM_HD M mk(uint32_t v) { return M31(v); }
+  static CM_HD M inv(M x) { return cm::inv(x); }
+};
+
+struct DevRelations {
+  uint32_t z[air::N_RELATIONS][4];
+  uint32_t alpha_pow[air::N_RELATIONS][air::MAX_REL_SIZE][4];
+};
+
+__device__ __forceinline__ QM31 dev_combine(const DevRelations* __restrict__ rel, int r, const M31* v, int n) {
+  QM31 acc = QM31::from_u32(rel->alpha_pow[r][0]) * v[0];
+  for (int i = 1; i < n; i++) acc += QM31::from_u32(rel->alpha_pow[r][i]) * v[i];
+  return acc - QM31::from_u32(rel->z[r]);
+}
+
+struct EmptyEF {};
+__device__ __forceinline__ EmptyEF operator*(EmptyEF, EmptyEF) { return {}; }
+__device__ __forceinline__ EmptyEF operator*(EmptyEF, M31) { return {}; }
+__device__ __forceinline__ EmptyEF operator+(EmptyEF, EmptyEF) { return {}; }
+
+struct HistPtrs { uint32_t *rc8, *rc16, *rc20, *bitwise; uint32_t* error_flag; };
+
+struct HistEval : air::LogupStream<HistEval, M31, EmptyEF> {
+  const uint32_t* const* cols;
+  uint32_t row;
+  int ci = 0;
+  HistPtrs h;
+  __device__ M31 next() { return M31(cols[ci++][row]); }
+  __device__ M31 preproc(int) { return M31(); }
+  __device__ M31 c(uint32_t v) { return M31(v); }
+  __device__ void constraint(M31) {}
+  __device__ EmptyEF combine(int, const M31*, int) { return {}; }
+  __device__ EmptyEF ef_from(M31) { return {}; }
+  __device__ void bump(uint32_t* t, uint32_t idx, uint32_t size) {
+    if (idx < size) atomicAdd(t + idx, 1u);
+    else atomicOr(h.error_flag, 1u);
+  }
+  __device__ void on_entry(int rel, M31, const M31* v, int) {
+    if (rel == air::REL_RC8) bump(h.rc8, v[0].v, 1u << 8);
+    else if (rel == air::REL_RC16) bump(h.rc16, v[0].v, 1u << 16);
+    else if (rel == air::REL_RC20) bump(h.rc20, v[0].v, 1u << 20);
+    else if (rel == air::REL_BITWISE) {
+      uint32_t ok = (v[0].v < 3u) & (v[1].v < 256u) & (v[2].v < 256u);
+      bump(h.bitwise, ok ? v[0].v * 65536u + (v[1].v << 8) + v[2].v : 0xffffffffu, 1u << 18);
+    }
+  }
+  __device__ void emit_batch(bool, EmptyEF, EmptyEF) {}
+};
+
+struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
+  const uint32_t* const* cols;   // tree-1 trace-domain columns of the component
+  const uint32_t* const* pp;     // preprocessed trace-domain columns by PreprocId
+  uint32_t* const* out;          // interaction columns (trace domain)
+  const DevRelations* rels;
+  uint32_t row;
+  int ci = 0, batch = 0;
+  QM31 prev;
+  __device__ M31 next() { return M31(cols[ci++][row]); }
+  __device__ M31 preproc(int id) { return M31(pp[id][row]); }
+  __device__ M31 c(uint32_t v) { return M31(v); }
+  __device__ void constraint(M31) {}
+  __device__ QM31 combine(int r, const M31* v, int n) { return dev_combine(rels, r, v, n); }
+  __device__ QM31 ef_from(M31 m) { return QM31(m); }
+  __device__ void on_entry(int, M31, const M31*, int) {}
+  __device__ void emit_batch(bool, QM31 num, QM31 den) {
+    QM31 v = prev + num * inv(den);
+    out[4 * batch + 0][row] = v.a.a.v;
+    out[4 * batch + 1][row] = v.a.b.v;
+    out[4 * batch + 2][row] = v.b.a.v;
+    out[4 * batch + 3][row] = v.b.b.v;
+    prev = v;
+    batch++;
+  }
+};
+
+struct DomainEval : air::LogupStream<DomainEval, M31, QM31> {
+  const uint32_t* const* tr;   // tree-1 LDE columns
+  const uint32_t* const* it;   // tree-2 LDE columns
+  const uint32_t* const* pp;   // tree-0 LDE columns by PreprocId
+  const DevRelations* rels;
+  const uint32_t* coeff;       // 4 u32 per constraint
+  uint32_t row, prev_row;
+  int n_base;
+  QM31 cumsum_shift;
+  int ci = 0, ii = 0, kb = 0, kl = 0;
+  QM31 prev_col, acc;
+  __device__ M31 next() { return M31(tr[ci++][row]); }
+  __device__ M31 preproc(int id) { return M31(pp[id][row]); }
+  __device__ M31 c(uint32_t v) { return M31(v); }
+  __device__ void constraint(M31 x) { acc += QM31::from_u32(coeff + 4 * (kb++)) * x; }
+  __device__ void constraint_q(QM31 x) { acc += QM31::from_u32(coeff + 4 * (n_base + kl++)) * x; }
+  __device__ QM31 combine(int r, const M31* v, int n) { return dev_combine(rels, r, v, n); }
+  __device__ QM31 ef_from(M31 m) { return QM31(m); }
+  __device__ void on_entry(int, M31, const M31*, int) {}
+  __device__ QM31 mask(uint32_t r) { return QM31(M31(it[ii][r]), M31(it[ii + 1][r]), M31(it[ii + 2][r]), M31(it[ii + 3][r])); }
+  __device__ void emit_batch(bool last, QM31 num, QM31 den) {
+    if (!last) {
+      QM31 cur = mask(row);
+      ii += 4;
+      QM31 diff = cur - prev_col;
+      prev_col = cur;
+      constraint_q(diff * den - num);
+    } else {
+      QM31 pr = mask(prev_row), cur = mask(row);
+      ii += 4;
+      constraint_q((cur - pr - prev_col + cumsum_shift) * den - num);
+    }
+  }
+};
+
+// Row `offset` trace-steps away on bit-reversed storage of log n (trace domain log = trace_log <= n).
+__device__ __forceinline__ uint32_t shifted_row(uint32_t r, uint32_t n, uint32_t trace_log, int offset) {
+  uint32_t i = bit_reverse(r, n);
+  uint32_t half = 1u << (n - 1);
+  uint32_t mod_mask = (n + 1 >= 32) ? 0xffffffffu : ((1u << (n + 1)) - 1);
+  uint32_t e = i < half ? (1u + 4u * i) : (0u - (1u + 4u * (i - half)));
+  e += (uint32_t)offset * (1u << (n + 1 - trace_log));
+  e &= mod_mask;
+  uint32_t j = ((e & 3u) == 1u) ? (e - 1u) / 4u : half + (((mod_mask + 1u) - e - 1u) & mod_mask) / 4u;
+  return bit_reverse(j, n);
+}
+
+}  // namespace cm

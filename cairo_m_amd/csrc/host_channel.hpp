@@ -1,0 +1,135 @@
+// Host side of the Fiat-Shamir transcript for the HIP prover: Blake2s (RFC 7693) and Stwo's
+// Blake2sChannel framing.  Reference call sites: crates/prover/src/prover.rs:33-36, 66, 73, 78, 90-91, 94,
+// 98 and the channel use inside stwo `prove` (prover.rs:131).  The transcript is tiny (a few hundred
+// hashes per proof) and inherently sequential, so it stays on the host; the heavy hashing (Merkle
+// layers, proof-of-work search) runs in kernels_hash.hip.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <array>
+#include <vector>
+#include "field.hpp"
+
+namespace cm {
+namespace hostch {
+
+using Hash32 = std::array<uint8_t, 32>;
+
+inline void compress(uint32_t h[8], const uint32_t m[16], uint64_t t, uint32_t f0) {
+  static const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+  static const uint8_t S[10][16] = {
+      {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+      {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+      {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+      {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+      {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+  uint32_t v[16];
+  for (int i = 0; i < 8; i++) { v[i] = h[i]; v[8 + i] = IV[i]; }
+  v[12] ^= (uint32_t)t; v[13] ^= (uint32_t)(t >> 32); v[14] ^= f0;
+  auto rot = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+  auto G = [&](int a, int b, int c, int d, uint32_t x, uint32_t y) {
+    v[a] += v[b] + x; v[d] = rot(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = rot(v[b] ^ v[c], 12);
+    v[a] += v[b] + y; v[d] = rot(v[d] ^ v[a], 8);  v[c] += v[d]; v[b] = rot(v[b] ^ v[c], 7);
+  };
+  for (int r = 0; r < 10; r++) {
+    const uint8_t* s = S[r];
+    G(0, 4, 8, 12, m[s[0]], m[s[1]]); G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+    G(2, 6, 10, 14, m[s[4]], m[s[5]]); G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+    G(0, 5, 10, 15, m[s[8]], m[s[9]]); G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+    G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+  }
+  for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
+}
+inline Hash32 blake2s256(const uint8_t* data, size_t len) {
+  uint32_t h[8] = {0x6A09E667u ^ 0x01010020u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+  uint64_t t = 0;
+  size_t off = 0;
+  uint32_t m[16];
+  while (len - off > 64) {
+    memcpy(m, data + off, 64);
+    t += 64;
+    compress(h, m, t, 0);
+    off += 64;
+  }
+  uint8_t block[64] = {0};
+  size_t rem = len - off;
+  if (rem) memcpy(block, data + off, rem);
+  t += rem;
+  memcpy(m, block, 64);
+  compress(h, m, t, 0xFFFFFFFFu);
+  Hash32 out;
+  memcpy(out.data(), h, 32);
+  return out;
+}
+
+struct Channel {
+  Hash32 digest{};
+  uint32_t n_challenges = 0, n_sent = 0;
+  void update(const Hash32& d) { digest = d; n_challenges++; n_sent = 0; }
+  uint32_t trailing_zeros() const {
+    uint32_t w[4];
+    memcpy(w, digest.data(), 16);
+    for (int i = 0; i < 4; i++) if (w[i]) return 32 * i + __builtin_ctz(w[i]);
+    return 128;
+  }
+  void mix_u32s(const uint32_t* w, size_t n) {
+    std::vector<uint8_t> buf(32 + 4 * n);
+    memcpy(buf.data(), digest.data(), 32);
+    if (n) memcpy(buf.data() + 32, w, 4 * n);
+    update(blake2s256(buf.data(), buf.size()));
+  }
+  void mix_felts(const QM31* f, size_t n) {
+    std::vector<uint32_t> w(4 * n);
+    for (size_t i = 0; i < n; i++) f[i].to_u32(&w[4 * i]);
+    mix_u32s(w.data(), w.size());
+  }
+  // raw compression F(digest, [lo, hi, 0...], t=0, f=0) — the form Stwo's SIMD grind searches over
+  void mix_u64(uint64_t v) {
+    uint32_t h[8], m[16] = {0};
+    memcpy(h, digest.data(), 32);
+    m[0] = (uint32_t)v; m[1] = (uint32_t)(v >> 32);
+    compress(h, m, 0, 0);
+    Hash32 d;
+    memcpy(d.data(), h, 32);
+    update(d);
+  }
+  void mix_root(const Hash32& root) {
+    uint8_t buf[64];
+    memcpy(buf, digest.data(), 32);
+    memcpy(buf + 32, root.data(), 32);
+    update(blake2s256(buf, 64));
+  }
+  Hash32 draw_random_bytes() {
+    uint8_t buf[65] = {0};
+    memcpy(buf, digest.data(), 32);
+    memcpy(buf + 32, &n_sent, 4);
+    n_sent++;
+    return blake2s256(buf, 65);
+  }
+  void draw_base_felts(M31 out[8]) {
+    for (;;) {
+      Hash32 b = draw_random_bytes();
+      uint32_t u[8];
+      memcpy(u, b.data(), 32);
+      bool ok = true;
+      for (int i = 0; i < 8; i++) ok = ok && u[i] < 2 * P;
+      if (!ok) continue;
+      for (int i = 0; i < 8; i++) out[i] = M31::from_u32(u[i]);
+      return;
+    }
+  }
+  QM31 draw_felt() {
+    M31 f[8];
+    draw_base_felts(f);
+    return QM31(f[0], f[1], f[2], f[3]);
+  }
+  void draw_two_felts(QM31& a, QM31& b) {  // draw_felts(2): one hash, 8 base felts
+    M31 f[8];
+    draw_base_felts(f);
+    a = QM31(f[0], f[1], f[2], f[3]);
+    b = QM31(f[4], f[5], f[6], f[7]);
+  }
+};
+
+}  // namespace hostch
+}  // namespace cm

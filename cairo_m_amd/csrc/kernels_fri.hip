@@ -1,0 +1,108 @@
+// DEEP/FRI kernels for gfx950.
+//   k_quotients      : QuotientOps::accumulate_quotients (hot loop C) — one thread per LDE row,
+//                      every committed column of the size group read exactly once, column-major.
+//   k_fold_circle / k_fold_line : FriOps::{fold_circle_into_line, fold_line}
+// Domain points come from the FFT twiddle tables (no per-row group exponentiation).
+#include "field.hpp"
+#include "device_common.hpp"
+#include "engine.hpp"
+#include "fri_kernels.hpp"
+
+namespace cm {
+
+// (x, y) of CanonicCoset(l).circle_domain() at bit-reversed storage row r
+__device__ __forceinline__ void domain_point_at_row(const TwiddleView& tw, uint32_t l, uint32_t r, M31& x, M31& y) {
+  uint32_t h = r >> 1;
+  M31 yy(tw.ytw[(1u << (l - 1)) + h]);
+  y = (r & 1u) ? -yy : yy;
+  uint32_t L = tw.R - l;
+  M31 xx(tw.xtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + (h >> 1)]);
+  x = (h & 1u) ? -xx : xx;
+}
+
+__global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= (1u << a.log_size)) return;
+  M31 px, py;
+  domain_point_at_row(a.tw, a.log_size, row, px, py);
+  QM31 acc;
+  for (uint32_t b = 0; b < a.n_batches; b++) {
+    const QuotientBatch& qb = a.batches[b];
+    QM31 num;
+    for (uint32_t k = qb.begin; k < qb.end; k++) {
+      M31 v(a.cols[a.col_index[k]][row]);
+      num += QM31::from_u32(a.coef_c + 4 * k) * v;
+    }
+    // sum_k (a_k * y + b_k) = A*y + B (A, B summed on the host; field arithmetic is exact)
+    num = num - (QM31::from_u32(qb.sum_a) * py + QM31::from_u32(qb.sum_b));
+    // denominator (Pr.x - p.x) * Pi.y - (Pr.y - p.y) * Pi.x in CM31
+    CM31 prx(M31(qb.point[0]), M31(qb.point[1])), pix(M31(qb.point[2]), M31(qb.point[3]));
+    CM31 pry(M31(qb.point[4]), M31(qb.point[5])), piy(M31(qb.point[6]), M31(qb.point[7]));
+    CM31 den = (prx - CM31(px)) * piy - (pry - CM31(py)) * pix;
+    acc = acc * QM31::from_u32(qb.batch_coeff) + mul_cm31(num, inv(den));
+  }
+  a.out[0][row] = acc.a.a.v; a.out[1][row] = acc.a.b.v; a.out[2][row] = acc.b.a.v; a.out[3][row] = acc.b.b.v;
+}
+
+__device__ __forceinline__ QM31 ld4(const uint32_t* const* c, uint32_t i) {
+  return QM31(M31(c[0][i]), M31(c[1][i]), M31(c[2][i]), M31(c[3][i]));
+}
+__device__ __forceinline__ void st4(uint32_t* const* c, uint32_t i, QM31 v) {
+  c[0][i] = v.a.a.v; c[1][i] = v.a.b.v; c[2][i] = v.b.a.v; c[3][i] = v.b.b.v;
+}
+struct Ptr4 { uint32_t* p[4]; };
+struct CPtr4 { const uint32_t* p[4]; };
+
+// dst[i] = dst[i] * alpha^2 + (f0 + f1) + alpha * (f0 - f1) / y_i,  (f0, f1) = src[2i], src[2i+1]
+__global__ void __launch_bounds__(256) k_fold_circle(Ptr4 dst, CPtr4 src, uint32_t log_n, TwiddleView tw, const uint32_t alpha4_0,
+                                                     const uint32_t alpha4_1, const uint32_t alpha4_2, const uint32_t alpha4_3,
+                                                     int accumulate) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << (log_n - 1))) return;
+  QM31 alpha = QM31(M31(alpha4_0), M31(alpha4_1), M31(alpha4_2), M31(alpha4_3));
+  M31 yinv(tw.iytw[(1u << (log_n - 1)) + i]);
+  QM31 f0 = ld4(src.p, 2 * i), f1 = ld4(src.p, 2 * i + 1);
+  QM31 v = (f0 + f1) + alpha * ((f0 - f1) * yinv);
+  if (accumulate) v = ld4(dst.p, i) * (alpha * alpha) + v;
+  st4(dst.p, i, v);
+}
+// out[i] = (f0 + f1) + alpha * (f0 - f1) / x_i on LineDomain(half_odds(log_n))
+__global__ void __launch_bounds__(256) k_fold_line(Ptr4 out, CPtr4 src, uint32_t log_n, TwiddleView tw, const uint32_t alpha4_0,
+                                                   const uint32_t alpha4_1, const uint32_t alpha4_2, const uint32_t alpha4_3) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << (log_n - 1))) return;
+  QM31 alpha = QM31(M31(alpha4_0), M31(alpha4_1), M31(alpha4_2), M31(alpha4_3));
+  uint32_t L = tw.R - (log_n + 1);
+  M31 xinv(tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + i]);
+  QM31 f0 = ld4(src.p, 2 * i), f1 = ld4(src.p, 2 * i + 1);
+  st4(out.p, i, (f0 + f1) + alpha * ((f0 - f1) * xinv));
+}
+
+// ================================================================= host wrappers
+void launch_quotients(const QuotientArgs& a, hipStream_t st) {
+  uint32_t n = 1u << a.log_size;
+  hipLaunchKernelGGL(k_quotients, dim3((n + 255) / 256), dim3(256), 0, st, a);
+  CM_HIP(hipGetLastError());
+}
+void fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw,
+                           const QM31& alpha, bool accumulate, hipStream_t st) {
+  CM_CHECK(log_n >= 2 && log_n <= tw.R, "fold_circle: bad log size");
+  Ptr4 d; CPtr4 s;
+  for (int i = 0; i < 4; i++) { d.p[i] = dst[i]; s.p[i] = src[i]; }
+  uint32_t n = 1u << (log_n - 1);
+  hipLaunchKernelGGL(k_fold_circle, dim3((n + 255) / 256), dim3(256), 0, st, d, s, log_n, view(tw), alpha.a.a.v, alpha.a.b.v,
+                     alpha.b.a.v, alpha.b.b.v, accumulate ? 1 : 0);
+  CM_HIP(hipGetLastError());
+}
+void fold_line(uint32_t* const out[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw, const QM31& alpha,
+               hipStream_t st) {
+  CM_CHECK(log_n >= 1 && log_n + 1 <= tw.R, "fold_line: bad log size");
+  Ptr4 d; CPtr4 s;
+  for (int i = 0; i < 4; i++) { d.p[i] = out[i]; s.p[i] = src[i]; }
+  uint32_t n = 1u << (log_n - 1);
+  hipLaunchKernelGGL(k_fold_line, dim3((n + 255) / 256), dim3(256), 0, st, d, s, log_n, view(tw), alpha.a.a.v, alpha.a.b.v,
+                     alpha.b.a.v, alpha.b.b.v);
+  CM_HIP(hipGetLastError());
+}
+
+}  // namespace cm

@@ -247,7 +247,8 @@ static void launch_pass(const uint32_t* const* d_src, uint32_t* const* d_dst, ui
   size_t lds = (size_t)4 << tile_log;
   hipLaunchKernelGGL(k_fft_pass<INV>, dim3(ntiles, ncols), dim3(256), lds, st, a);
 }
-void interpolate(uint32_t* const* d_cols, uint32_t ncols, uint32_t n, const Twiddles& tw, hipStream_t st) {
+void interpolate_oop(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n, const Twiddles& tw,
+                     hipStream_t st) {
   CM_CHECK(n >= 1 && n <= tw.R, "interpolate: log size exceeds twiddle table");
   if (ncols == 0) return;
   std::vector<std::pair<uint32_t, uint32_t>> passes;
@@ -255,9 +256,13 @@ void interpolate(uint32_t* const* d_cols, uint32_t ncols, uint32_t n, const Twid
   uint32_t inv_n = inv(M31::from_u32(1u << n)).v;
   for (size_t i = 0; i < passes.size(); i++) {
     bool last = i + 1 == passes.size();
-    launch_pass<true>(d_cols, d_cols, ncols, n, passes[i].first, passes[i].second, 1u << n, last ? inv_n : 1u, tw, st);
+    launch_pass<true>(i == 0 ? d_src : (const uint32_t* const*)d_dst, d_dst, ncols, n, passes[i].first, passes[i].second,
+                      1u << n, last ? inv_n : 1u, tw, st);
   }
   CM_HIP(hipGetLastError());
+}
+void interpolate(uint32_t* const* d_cols, uint32_t ncols, uint32_t n, const Twiddles& tw, hipStream_t st) {
+  interpolate_oop(d_cols, d_cols, ncols, n, tw, st);
 }
 void evaluate(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n_in, uint32_t n_out,
               const Twiddles& tw, hipStream_t st) {

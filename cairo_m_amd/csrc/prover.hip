@@ -1,0 +1,842 @@
+// Whole-segment HIP prover: `prove_cairo_m::<Blake2sMerkleChannel>`
+// (/root/reference/crates/prover/src/prover.rs:23-147; transcript order is normative) driving the gfx950
+// kernels.  Host code here only sequences launches, runs the Fiat-Shamir channel, and assembles the proof;
+// every pass over trace data (trace gen, LogUp, IFFT/LDE, Merkle, constraints, OODS sampling, DEEP
+// quotients, FRI folds, PoW search, decommit gathers) is a kernel.  No CPU fallback exists.
+#include "../../include/cairom_hip.h"
+#include "engine.hpp"
+#include "merkle_tree.hpp"
+#include "air_kernels.hpp"
+#include "fri_kernels.hpp"
+#include "gpu_air.hpp"
+#include "host_channel.hpp"
+#include "proof.hpp"
+#include <chrono>
+#include <memory>
+#include <map>
+#include <set>
+#include <algorithm>
+#include <functional>
+
+namespace cm {
+
+using hostch::Channel;
+
+static inline uint32_t log_size_for(uint64_t n) {  // max(LOG_N_LANES, ceil_log2(n))
+  uint32_t l = 4;
+  while ((1ull << l) < n) l++;
+  return l;
+}
+
+// ---- device-resident prover input ------------------------------------------------------------------------
+struct DeviceInput {
+  cm_prover_input meta;  // scalar fields + counts; pointers are replaced by device pointers below
+  DevBuf bundles[CM_N_OPCODE_COMPONENTS], data_accesses, init_mem, fin_mem, clock_updates, init_tree, fin_tree;
+  PublicData public_data;
+};
+
+static PublicData make_public_data(const cm_prover_input& in) {  // PublicData::new (public_data.rs:244-272)
+  PublicData d;
+  d.initial_pc = in.initial_pc; d.initial_fp = in.initial_fp; d.final_pc = in.final_pc; d.final_fp = in.final_fp;
+  uint64_t steps = 0;
+  for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) steps += in.n_bundles[i];
+  d.clock = M31::reduce(steps).v;
+  d.initial_root = in.initial_root; d.final_root = in.final_root;
+  std::map<uint32_t, const cm_memory_cell*> init, fin;
+  for (uint64_t i = 0; i < in.n_initial_memory; i++) init[in.initial_memory[i].address] = &in.initial_memory[i];
+  for (uint64_t i = 0; i < in.n_final_memory; i++) fin[in.final_memory[i].address] = &in.final_memory[i];
+  auto extract = [](const std::map<uint32_t, const cm_memory_cell*>& m, const uint32_t range[2]) {
+    std::vector<PublicEntry> v;
+    for (uint32_t a = range[0]; a < range[1]; a++) {
+      PublicEntry e{};
+      auto it = m.find(a);
+      if (it != m.end()) { e.present = 1; e.addr = a; for (int k = 0; k < 4; k++) e.value[k] = it->second->value[k]; e.clock = it->second->clock; }
+      v.push_back(e);
+    }
+    return v;
+  };
+  d.program = extract(init, in.program_range);
+  d.input = extract(init, in.input_range);
+  d.output = extract(fin, in.output_range);
+  return d;
+}
+
+DeviceInput* upload_input(const cm_prover_input& in) {
+  DeviceInput* d = new DeviceInput();
+  d->meta = in;
+  auto up = [](DevBuf& b, const void* p, size_t bytes) {
+    b.alloc(bytes);
+    if (bytes) CM_HIP(hipMemcpy(b.p, p, bytes, hipMemcpyHostToDevice));
+  };
+  for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) up(d->bundles[i], in.bundles[i], in.n_bundles[i] * sizeof(cm_bundle));
+  up(d->data_accesses, in.data_accesses, in.n_data_accesses * sizeof(cm_data_access));
+  up(d->init_mem, in.initial_memory, in.n_initial_memory * sizeof(cm_memory_cell));
+  up(d->fin_mem, in.final_memory, in.n_final_memory * sizeof(cm_memory_cell));
+  up(d->clock_updates, in.clock_updates, in.n_clock_updates * sizeof(cm_clock_update));
+  up(d->init_tree, in.initial_tree, in.n_initial_tree * sizeof(cm_merkle_node));
+  up(d->fin_tree, in.final_tree, in.n_final_tree * sizeof(cm_merkle_node));
+  d->public_data = make_public_data(in);
+  return d;
+}
+
+// ---- column sets -------------------------------------------------------------------------------------------
+struct ColumnSet {
+  std::vector<uint32_t> logs;
+  std::vector<uint32_t*> ptrs;
+  DevBuf buf, d_ptrs;
+  void alloc(const std::vector<uint32_t>& logs_, hipStream_t st) {
+    logs = logs_;
+    size_t total = 0;
+    for (auto l : logs) total += (size_t)1 << l;
+    buf.alloc(total * 4);
+    ptrs.resize(logs.size());
+    size_t off = 0;
+    for (size_t i = 0; i < logs.size(); i++) { ptrs[i] = buf.u32() + off; off += (size_t)1 << logs[i]; }
+    d_ptrs = upload(ptrs, st);
+  }
+  uint32_t* const* dev(size_t first = 0) const { return d_ptrs.as<uint32_t*>() + first; }
+  size_t size() const { return logs.size(); }
+};
+
+// groups column indices by log size (descending) — used to batch FFT launches
+static std::map<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> by_log(const std::vector<uint32_t>& logs) {
+  std::map<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> m;
+  for (uint32_t i = 0; i < logs.size(); i++) m[logs[i]].push_back(i);
+  return m;
+}
+
+struct CommittedTree {
+  ColumnSet coeffs, lde;
+  MerkleTree merkle;
+  hostch::Hash32 root;
+};
+
+struct Prover {
+  hipStream_t st = 0;
+  cm_pcs_config cfg;
+  Twiddles* tw = nullptr;
+  Channel ch;
+  CommittedTree trees[4];
+  std::vector<double> phase_ms;
+  std::chrono::steady_clock::time_point t0;
+
+  void tick(const char*) {
+    CM_HIP(hipStreamSynchronize(st));
+    auto t1 = std::chrono::steady_clock::now();
+    phase_ms.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+
+  // IFFT src(evals, trace domain) -> tree.coeffs; LDE -> tree.lde; Merkle; mix root.
+  // If `in_place`, coeffs aliases src (src is consumed).
+  void commit(CommittedTree& t, ColumnSet* evals, bool from_coeffs) {
+    const std::vector<uint32_t>& logs = from_coeffs ? t.coeffs.logs : evals->logs;
+    if (!from_coeffs) t.coeffs.alloc(logs, st);
+    std::vector<uint32_t> lde_logs(logs);
+    for (auto& l : lde_logs) l += cfg.log_blowup_factor;
+    t.lde.alloc(lde_logs, st);
+    for (auto& kv : by_log(logs)) {
+      std::vector<const uint32_t*> src;
+      std::vector<uint32_t*> co, ld;
+      for (auto i : kv.second) { if (!from_coeffs) src.push_back(evals->ptrs[i]); co.push_back(t.coeffs.ptrs[i]); ld.push_back(t.lde.ptrs[i]); }
+      DevBuf dco = upload(co, st), dld = upload(ld, st);
+      if (!from_coeffs) {
+        DevBuf dsrc = upload(src, st);
+        interpolate_oop(dsrc.as<const uint32_t*>(), dco.as<uint32_t*>(), (uint32_t)co.size(), kv.first, *tw, st);
+        evaluate(dco.as<const uint32_t*>(), dld.as<uint32_t*>(), (uint32_t)co.size(), kv.first, kv.first + cfg.log_blowup_factor, *tw, st);
+        CM_HIP(hipStreamSynchronize(st));  // pointer arrays are freed at scope exit
+      } else {
+        evaluate(dco.as<const uint32_t*>(), dld.as<uint32_t*>(), (uint32_t)co.size(), kv.first, kv.first + cfg.log_blowup_factor, *tw, st);
+        CM_HIP(hipStreamSynchronize(st));
+      }
+    }
+    std::vector<const uint32_t*> cols(t.lde.ptrs.begin(), t.lde.ptrs.end());
+    t.merkle.commit(cols, t.lde.logs, st);
+    t.merkle.root(t.root.data(), st);
+    ch.mix_root(t.root);
+  }
+};
+
+// ---- host point evaluator (stwo FrameworkComponent::evaluate_constraint_quotients_at_point) ------------
+struct HostRelations {
+  QM31 z[air::N_RELATIONS], alpha_pow[air::N_RELATIONS][air::MAX_REL_SIZE];
+};
+struct PointEvalH : air::LogupStream<PointEvalH, QM31, QM31> {
+  const QM31 *tr, *it, *pp;
+  const HostRelations* rels;
+  const QM31* coeff;
+  int n_base;
+  QM31 cumsum_shift, prev_col, acc;
+  int ci = 0, ii = 0, kb = 0, kl = 0;
+  QM31 next() { return tr[ci++]; }
+  QM31 preproc(int id) { return pp[id]; }
+  QM31 c(uint32_t v) { return QM31(M31(v)); }
+  void constraint(QM31 x) { acc += coeff[kb++] * x; }
+  void constraint_q(QM31 x) { acc += coeff[n_base + kl++] * x; }
+  QM31 combine(int r, const QM31* v, int n) {
+    QM31 a;
+    for (int i = 0; i < n; i++) a += rels->alpha_pow[r][i] * v[i];
+    return a - rels->z[r];
+  }
+  QM31 ef_from(QM31 m) { return m; }
+  void on_entry(int, QM31, const QM31*, int) {}
+  static QM31 combine_ef(const QM31* c4) {
+    return c4[0] + c4[1] * QM31(M31(0), M31(1), M31(0), M31(0)) + c4[2] * QM31(M31(0), M31(0), M31(1), M31(0)) +
+           c4[3] * QM31(M31(0), M31(0), M31(0), M31(1));
+  }
+  void emit_batch(bool last, QM31 num, QM31 den) {
+    if (!last) {
+      QM31 cur = combine_ef(it + ii);
+      ii += 4;
+      QM31 diff = cur - prev_col;
+      prev_col = cur;
+      constraint_q(diff * den - num);
+    } else {
+      QM31 pr[4], cu[4];
+      for (int k = 0; k < 4; k++) { pr[k] = it[ii + 2 * k]; cu[k] = it[ii + 2 * k + 1]; }
+      ii += 8;
+      constraint_q((combine_ef(cu) - combine_ef(pr) - prev_col + cumsum_shift) * den - num);
+    }
+  }
+};
+static QM31 point_eval(int cid, const QM31* tr, const QM31* it, const QM31* pp, const HostRelations& rel, const QM31* coeff,
+                       int n_base, QM31 shift) {
+  PointEvalH e;
+  e.tr = tr; e.it = it; e.pp = pp; e.rels = &rel; e.coeff = coeff; e.n_base = n_base; e.cumsum_shift = shift;
+  switch (cid) {
+#define CM_X(id, T) case air::id: air::T::eval(e); break;
+    AIR_ALL_COMPONENTS(CM_X)
+#undef CM_X
+  }
+  return e.acc;
+}
+
+// coset_vanishing of CanonicCoset(log).coset at p (QM31 or M31 point)
+template <class F>
+static F coset_vanishing_canonic(uint32_t log, CPoint<F> p) {
+  // shift = -initial + step/2 = 0 for a canonic (odds) coset: initial = G_{2^(log+1)} = step/2
+  F x = p.x;
+  for (uint32_t i = 1; i < log; i++) x = double_x(x);
+  return x;
+}
+
+struct Queries {
+  std::vector<uint32_t> positions;
+  uint32_t log_domain_size;
+  Queries fold(uint32_t n) const {
+    Queries q;
+    q.log_domain_size = log_domain_size - n;
+    for (auto p : positions) { uint32_t f = p >> n; if (q.positions.empty() || q.positions.back() != f) q.positions.push_back(f); }
+    return q;
+  }
+};
+
+// gather 4-coordinate values at positions from device columns
+static std::vector<QM31> gather_q(const uint32_t* const col4[4], const std::vector<uint32_t>& pos, hipStream_t st) {
+  std::vector<QM31> out(pos.size());
+  if (pos.empty()) return out;
+  std::vector<const uint32_t*> cols(col4, col4 + 4);
+  std::vector<uint32_t> ci, ri;
+  for (auto p : pos) for (uint32_t k = 0; k < 4; k++) { ci.push_back(k); ri.push_back(p); }
+  DevBuf dc = upload(cols, st), dci = upload(ci, st), dri = upload(ri, st), dout(ci.size() * 4);
+  gather_values(dc.as<const uint32_t*>(), dci.u32(), dri.u32(), (uint32_t)ci.size(), dout.u32(), st);
+  std::vector<uint32_t> w(ci.size());
+  CM_HIP(hipMemcpyAsync(w.data(), dout.p, w.size() * 4, hipMemcpyDeviceToHost, st));
+  CM_HIP(hipStreamSynchronize(st));
+  for (size_t i = 0; i < pos.size(); i++) out[i] = QM31::from_u32(&w[4 * i]);
+  return out;
+}
+static void decommit_positions(const uint32_t* const col4[4], const std::vector<uint32_t>& queries, std::vector<uint32_t>& positions,
+                               std::vector<QM31>& witness, hipStream_t st) {
+  std::vector<uint32_t> wpos;
+  size_t i = 0;
+  while (i < queries.size()) {
+    uint32_t start = (queries[i] >> 1) << 1;
+    size_t j = i;
+    while (j < queries.size() && (queries[j] >> 1) == (queries[i] >> 1)) j++;
+    size_t qi = i;
+    for (uint32_t pos = start; pos < start + 2; pos++) {
+      positions.push_back(pos);
+      if (qi < j && queries[qi] == pos) { qi++; continue; }
+      wpos.push_back(pos);
+    }
+    i = j;
+  }
+  std::vector<QM31> w = gather_q(col4, wpos, st);
+  witness.insert(witness.end(), w.begin(), w.end());
+}
+
+// =========================================================================================================
+ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
+  const cm_prover_input& in = din.meta;
+  std::unique_ptr<ProofData> out(new ProofData());
+  ProofData& pf = *out;
+  pf.config = cfg;
+  Prover P;
+  P.cfg = cfg;
+  hipStream_t st = P.st;
+  P.t0 = std::chrono::steady_clock::now();
+  auto t_start = P.t0;
+  Channel& ch = P.ch;
+
+  // ---- component log sizes (known from the input lengths) ----
+  uint32_t clog[air::N_COMPONENTS];
+  uint64_t nrows[air::N_COMPONENTS];
+  for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++) nrows[c] = in.n_bundles[c];
+  nrows[air::C_MEMORY] = in.n_initial_memory + in.n_final_memory;
+  nrows[air::C_MERKLE] = in.n_initial_tree + in.n_final_tree;
+  nrows[air::C_CLOCK_UPDATE] = in.n_clock_updates;
+  nrows[air::C_POSEIDON2] = in.n_initial_tree + in.n_final_tree;
+  for (int c = 0; c <= air::C_POSEIDON2; c++) clog[c] = log_size_for(nrows[c]);
+  clog[air::C_RC8] = 8; clog[air::C_RC16] = 16; clog[air::C_RC20] = 20; clog[air::C_BITWISE] = 18;
+  uint32_t max_log = 0;
+  for (int c = 0; c < air::N_COMPONENTS; c++) max_log = std::max(max_log, clog[c]);
+  for (int c = 0; c < air::N_COMPONENTS; c++) CM_CHECK(clog[c] <= 26, "component too large");
+  const uint32_t comp_log = max_log + 1;
+  P.tw = twiddles_create(comp_log + cfg.log_blowup_factor, st);
+  std::unique_ptr<Twiddles, void (*)(Twiddles*)> tw_guard(P.tw, twiddles_destroy);
+
+  // ---- transcript setup (prover.rs:33-36, 62-66) ----
+  ch.mix_u64(cfg.pow_bits);
+  ch.mix_u64(cfg.log_blowup_factor);
+  ch.mix_u64(cfg.n_queries);
+  ch.mix_u64(cfg.log_last_layer_degree_bound);
+  pf.public_data = din.public_data;
+  {
+    const PublicData& d = pf.public_data;
+    uint32_t w[7] = {d.initial_pc, d.initial_fp, d.final_pc, d.final_fp, d.clock, d.initial_root, d.final_root};
+    ch.mix_u32s(w, 7);
+    uint32_t lens[3] = {(uint32_t)d.program.size(), (uint32_t)d.input.size(), (uint32_t)d.output.size()};
+    ch.mix_u32s(lens, 3);
+    for (const auto* v : {&d.program, &d.input, &d.output}) {
+      std::vector<uint32_t> words;
+      for (auto& e : *v) if (e.present) { words.push_back(e.addr); for (int k = 0; k < 4; k++) words.push_back(e.value[k]); words.push_back(e.clock); }
+      ch.mix_u32s(words.data(), words.size());
+    }
+  }
+  P.tick("setup");
+
+  // ---- tree 0: preprocessed trace (prover.rs:70-73) ----
+  ColumnSet pp_evals;
+  {
+    std::vector<uint32_t> logs(air::PREPROC_LOG, air::PREPROC_LOG + air::N_PREPROC);
+    pp_evals.alloc(logs, st);
+    for (int i = 0; i < air::N_PREPROC; i++) launch_preproc(i, logs[i], pp_evals.ptrs[i], st);
+    P.commit(P.trees[0], &pp_evals, false);
+  }
+  P.tick("preprocessed");
+
+  // ---- tree 1: execution trace (prover.rs:77-82; Claim::write_trace) ----
+  std::vector<size_t> tr0(air::N_COMPONENTS), it0(air::N_COMPONENTS);
+  ColumnSet tr_evals;
+  {
+    std::vector<uint32_t> logs;
+    for (int c = 0; c < air::N_COMPONENTS; c++) {
+      tr0[c] = logs.size();
+      for (int k = 0; k < air::component_info(c).n_trace; k++) logs.push_back(clog[c]);
+    }
+    tr_evals.alloc(logs, st);
+  }
+  for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++)
+    launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), st);
+  launch_memory_trace(din.init_mem.p, (uint32_t)in.n_initial_memory, din.fin_mem.p, (uint32_t)in.n_final_memory, in.initial_root,
+                      in.final_root, clog[air::C_MEMORY], tr_evals.dev(tr0[air::C_MEMORY]), st);
+  launch_merkle_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree, in.initial_root,
+                      in.final_root, clog[air::C_MERKLE], tr_evals.dev(tr0[air::C_MERKLE]), st);
+  launch_clock_update_trace(din.clock_updates.p, (uint32_t)in.n_clock_updates, clog[air::C_CLOCK_UPDATE],
+                            tr_evals.dev(tr0[air::C_CLOCK_UPDATE]), st);
+  launch_poseidon2_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree,
+                         clog[air::C_POSEIDON2], tr_evals.dev(tr0[air::C_POSEIDON2]), st);
+  {
+    // multiplicity columns = histograms over every lookup of every opcode component (components/mod.rs:139-160)
+    DevBuf flag(4);
+    CM_HIP(hipMemsetAsync(flag.p, 0, 4, st));
+    HistPtrs h;
+    h.rc8 = tr_evals.ptrs[tr0[air::C_RC8]]; h.rc16 = tr_evals.ptrs[tr0[air::C_RC16]];
+    h.rc20 = tr_evals.ptrs[tr0[air::C_RC20]]; h.bitwise = tr_evals.ptrs[tr0[air::C_BITWISE]];
+    h.error_flag = flag.u32();
+    CM_HIP(hipMemsetAsync(h.rc8, 0, 4u << 8, st));
+    CM_HIP(hipMemsetAsync(h.rc16, 0, 4u << 16, st));
+    CM_HIP(hipMemsetAsync(h.rc20, 0, 4u << 20, st));
+    CM_HIP(hipMemsetAsync(h.bitwise, 0, 4u << 18, st));
+    for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++)
+      launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, st);
+    uint32_t f = 0;
+    CM_HIP(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    CM_CHECK(f == 0, "trace generation: a range-check / bitwise lookup value is out of range");
+  }
+  P.tick("trace_gen");
+  for (int c = 0; c < air::N_COMPONENTS; c++) { pf.claim_log_sizes.push_back(clog[c]); ch.mix_u64(clog[c]); }
+  P.commit(P.trees[1], &tr_evals, false);
+  P.tick("trace_commit");
+
+  // ---- interaction PoW + relations (prover.rs:90-94) ----
+  pf.interaction_pow = grind_gpu(ch.digest.data(), 2, st);
+  ch.mix_u64(pf.interaction_pow);
+  HostRelations hrel;
+  DevRelations drel_h;
+  for (int r = 0; r < air::N_RELATIONS; r++) {
+    QM31 z, alpha;
+    ch.draw_two_felts(z, alpha);
+    hrel.z[r] = z;
+    QM31 cur(M31(1));
+    for (int i = 0; i < air::MAX_REL_SIZE; i++) { hrel.alpha_pow[r][i] = cur; cur = cur * alpha; }
+    z.to_u32(drel_h.z[r]);
+    for (int i = 0; i < air::MAX_REL_SIZE; i++) hrel.alpha_pow[r][i].to_u32(drel_h.alpha_pow[r][i]);
+  }
+  DevBuf drel(sizeof(DevRelations));
+  CM_HIP(hipMemcpy(drel.p, &drel_h, sizeof(DevRelations), hipMemcpyHostToDevice));
+
+  // ---- tree 2: interaction trace (prover.rs:96-102) ----
+  ColumnSet it_evals;
+  {
+    std::vector<uint32_t> logs;
+    for (int c = 0; c < air::N_COMPONENTS; c++) {
+      it0[c] = logs.size();
+      for (int k = 0; k < air::component_info(c).n_interaction; k++) logs.push_back(clog[c]);
+    }
+    it_evals.alloc(logs, st);
+  }
+  {
+    DevBuf scratch(logup_finalize_scratch_words(max_log) * 4);
+    for (int c = 0; c < air::N_COMPONENTS; c++) {
+      const air::ComponentInfo& info = air::component_info(c);
+      launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
+                   drel.as<DevRelations>(), it_evals.dev(it0[c]), st);
+      uint32_t cs[4];
+      logup_finalize_last(it_evals.dev(it0[c] + info.n_interaction - 4), clog[c], scratch.u32(), cs, st);
+      pf.claimed_sums.push_back(QM31::from_u32(cs));
+    }
+  }
+  for (auto& cs : pf.claimed_sums) ch.mix_felts(&cs, 1);
+  P.tick("interaction_gen");
+  // interpolate in place: coeffs alias the evaluation buffer
+  {
+    CommittedTree& t = P.trees[2];
+    t.coeffs = std::move(it_evals);
+    for (auto& kv : by_log(t.coeffs.logs)) {
+      std::vector<uint32_t*> co;
+      for (auto i : kv.second) co.push_back(t.coeffs.ptrs[i]);
+      DevBuf dco = upload(co, st);
+      interpolate(dco.as<uint32_t*>(), (uint32_t)co.size(), kv.first, *P.tw, st);
+      CM_HIP(hipStreamSynchronize(st));
+    }
+    P.commit(t, nullptr, true);
+  }
+  tr_evals.buf.release();
+  P.tick("interaction_commit");
+  for (int t = 0; t < 3; t++) for (auto l : P.trees[t].coeffs.logs) pf.cells += 1ull << l;
+
+  // ---- stwo prove: composition polynomial ----
+  QM31 random_coeff = ch.draw_felt();
+  size_t total_constraints = 0;
+  std::vector<size_t> coff(air::N_COMPONENTS);
+  for (int c = 0; c < air::N_COMPONENTS; c++) { coff[c] = total_constraints; total_constraints += air::component_info(c).n_constraints; }
+  std::vector<QM31> powers(total_constraints);
+  {
+    QM31 cur(M31(1));
+    for (size_t g = total_constraints; g-- > 0;) { powers[g] = cur; cur = cur * random_coeff; }
+  }
+  std::vector<uint32_t> powers_w(4 * total_constraints);
+  for (size_t g = 0; g < total_constraints; g++) powers[g].to_u32(&powers_w[4 * g]);
+  DevBuf d_powers = upload(powers_w, st);
+  std::map<uint32_t, ColumnSet> accs;  // evaluation log -> 4 accumulator columns
+  for (int c = 0; c < air::N_COMPONENTS; c++) {
+    uint32_t el = clog[c] + 1;
+    if (!accs.count(el)) {
+      accs[el].alloc(std::vector<uint32_t>(4, el), st);
+      CM_HIP(hipMemsetAsync(accs[el].buf.p, 0, accs[el].buf.bytes, st));
+    }
+  }
+  CM_CHECK(cfg.log_blowup_factor == 1, "constraint evaluation reuses the committed LDE: log_blowup_factor must be 1");
+  for (int c = 0; c < air::N_COMPONENTS; c++) {
+    const air::ComponentInfo& info = air::component_info(c);
+    ConstraintArgs a;
+    a.tr = (const uint32_t* const*)P.trees[1].lde.dev(tr0[c]);
+    a.it = (const uint32_t* const*)P.trees[2].lde.dev(it0[c]);
+    a.pp = (const uint32_t* const*)P.trees[0].lde.dev();
+    a.rels = drel.as<DevRelations>();
+    a.coeff = d_powers.u32() + 4 * coff[c];
+    a.acc = accs[clog[c] + 1].dev();
+    a.log_size = clog[c];
+    a.n_base = info.n_base_constraints;
+    (pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]))).to_u32(a.cumsum_shift);
+    for (uint32_t k = 0; k < 2; k++) {
+      CPoint<M31> p = point_at_index(domain_index_at(clog[c] + 1, k));
+      a.denom_inv[k] = inv(coset_vanishing_canonic<M31>(clog[c], p)).v;
+    }
+    launch_constraints(c, a, st);
+  }
+  P.tick("constraints");
+  // DomainEvaluationAccumulator::finalize: ascending sizes, interpolate / extend / add
+  {
+    CommittedTree& t = P.trees[3];
+    ColumnSet* cur = nullptr;
+    uint32_t cur_log = 0;
+    for (auto& kv : accs) {
+      ColumnSet& vals = kv.second;
+      if (cur) {
+        ColumnSet ext;
+        ext.alloc(std::vector<uint32_t>(4, kv.first), st);
+        evaluate((const uint32_t* const*)cur->dev(), ext.dev(), 4, cur_log, kv.first, *P.tw, st);
+        add_columns(vals.dev(), (const uint32_t* const*)ext.dev(), 4, 1u << kv.first, st);
+        CM_HIP(hipStreamSynchronize(st));
+      }
+      interpolate(vals.dev(), 4, kv.first, *P.tw, st);
+      cur = &vals;
+      cur_log = kv.first;
+    }
+    CM_CHECK(cur && cur_log == comp_log, "composition polynomial log size mismatch");
+    t.coeffs = std::move(*cur);
+    P.commit(t, nullptr, true);
+  }
+  P.tick("composition_commit");
+
+  // ---- OODS sampling ----
+  CPoint<QM31> oods;
+  {
+    QM31 t = ch.draw_felt();
+    QM31 t2 = t * t;
+    QM31 iv = inv(t2 + M31(1));
+    oods.x = (QM31(M31(1)) - t2) * iv;
+    oods.y = (t + t) * iv;
+  }
+  pf.sampled_values.resize(4);
+  for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
+  // all columns at the OODS point, batched by log size
+  {
+    struct Ref { int t; uint32_t c; };
+    std::map<uint32_t, std::vector<Ref>> groups;
+    for (int t = 0; t < 4; t++)
+      for (uint32_t c = 0; c < P.trees[t].coeffs.size(); c++) groups[P.trees[t].coeffs.logs[c]].push_back({t, c});
+    for (auto& kv : groups) {
+      std::vector<const uint32_t*> cols;
+      for (auto& r : kv.second) cols.push_back(P.trees[r.t].coeffs.ptrs[r.c]);
+      DevBuf dc = upload(cols, st), scratch(eval_at_point_scratch_words((uint32_t)cols.size(), kv.first) * 4), dout(cols.size() * 16);
+      eval_at_point_batch(dc.as<const uint32_t*>(), (uint32_t)cols.size(), kv.first, oods.x, oods.y, scratch.u32(), dout.u32(), st);
+      std::vector<uint32_t> w(cols.size() * 4);
+      CM_HIP(hipMemcpyAsync(w.data(), dout.p, w.size() * 4, hipMemcpyDeviceToHost, st));
+      CM_HIP(hipStreamSynchronize(st));
+      for (size_t i = 0; i < kv.second.size(); i++) pf.sampled_values[kv.second[i].t][kv.second[i].c] = {QM31::from_u32(&w[4 * i])};
+    }
+  }
+  // previous-row mask of every component's last LogUp column group: point oods - trace_step(log)
+  std::map<uint32_t, CPoint<QM31>> prev_points;
+  {
+    std::map<uint32_t, std::vector<uint32_t>> groups;  // component log -> tree-2 column indices
+    for (int c = 0; c < air::N_COMPONENTS; c++) {
+      int ni = air::component_info(c).n_interaction;
+      for (int k = ni - 4; k < ni; k++) groups[clog[c]].push_back((uint32_t)(it0[c] + k));
+    }
+    for (auto& kv : groups) {
+      CPoint<M31> step = point_at_index(subgroup_gen_index(kv.first));
+      CPoint<QM31> neg{QM31(step.x), QM31(-step.y)};
+      CPoint<QM31> pt = cadd(oods, neg);
+      prev_points[kv.first] = pt;
+      std::vector<const uint32_t*> cols;
+      for (auto c : kv.second) cols.push_back(P.trees[2].coeffs.ptrs[c]);
+      DevBuf dc = upload(cols, st), scratch(eval_at_point_scratch_words((uint32_t)cols.size(), kv.first) * 4), dout(cols.size() * 16);
+      eval_at_point_batch(dc.as<const uint32_t*>(), (uint32_t)cols.size(), kv.first, pt.x, pt.y, scratch.u32(), dout.u32(), st);
+      std::vector<uint32_t> w(cols.size() * 4);
+      CM_HIP(hipMemcpyAsync(w.data(), dout.p, w.size() * 4, hipMemcpyDeviceToHost, st));
+      CM_HIP(hipStreamSynchronize(st));
+      for (size_t i = 0; i < kv.second.size(); i++) {
+        auto& sv = pf.sampled_values[2][kv.second[i]];
+        sv.insert(sv.begin(), QM31::from_u32(&w[4 * i]));  // mask order [-1, 0]
+      }
+    }
+  }
+  {
+    std::vector<QM31> flat;
+    for (auto& t : pf.sampled_values) for (auto& c : t) for (auto& s : c) flat.push_back(s);
+    ch.mix_felts(flat.data(), flat.size());
+  }
+  P.tick("oods_sampling");
+  // sanity check (stwo prove): composition OODS value == constraints at the sampled mask values
+  {
+    QM31 c4[4] = {pf.sampled_values[3][0][0], pf.sampled_values[3][1][0], pf.sampled_values[3][2][0], pf.sampled_values[3][3][0]};
+    QM31 comp = PointEvalH::combine_ef(c4);
+    QM31 ppv[air::N_PREPROC];
+    for (int i = 0; i < air::N_PREPROC; i++) ppv[i] = pf.sampled_values[0][i][0];
+    QM31 sum;
+    for (int c = 0; c < air::N_COMPONENTS; c++) {
+      const air::ComponentInfo& info = air::component_info(c);
+      std::vector<QM31> tr, it;
+      for (int k = 0; k < info.n_trace; k++) tr.push_back(pf.sampled_values[1][tr0[c] + k][0]);
+      for (int k = 0; k < info.n_interaction; k++) for (auto& s : pf.sampled_values[2][it0[c] + k]) it.push_back(s);
+      QM31 shift = pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]));
+      QM31 num = point_eval(c, tr.data(), it.data(), ppv, hrel, &powers[coff[c]], info.n_base_constraints, shift);
+      sum += num * inv(coset_vanishing_canonic<QM31>(clog[c], oods));
+    }
+    if (sum != comp) throw CmError(10, "ConstraintsNotSatisfied: composition polynomial does not match the constraints at the OODS point");
+  }
+
+  // ---- DEEP quotients (compute_fri_quotients) ----
+  QM31 qcoeff = ch.draw_felt();
+  struct Ref { int t; uint32_t c; };
+  std::map<uint32_t, std::vector<Ref>, std::greater<uint32_t>> qgroups;  // LDE log -> columns (tree-major order)
+  for (int t = 0; t < 4; t++)
+    for (uint32_t c = 0; c < P.trees[t].lde.size(); c++) qgroups[P.trees[t].lde.logs[c]].push_back({t, c});
+  std::vector<uint32_t> q_logs;
+  std::vector<ColumnSet> quotients;
+  for (auto& kv : qgroups) {
+    uint32_t l = kv.first;
+    std::vector<const uint32_t*> cols;
+    struct Batch { CPoint<QM31> pt; std::vector<std::pair<uint32_t, QM31>> entries; };
+    std::vector<Batch> batches;
+    for (uint32_t i = 0; i < kv.second.size(); i++) {
+      const Ref& r = kv.second[i];
+      cols.push_back(P.trees[r.t].lde.ptrs[r.c]);
+      const auto& sv = pf.sampled_values[r.t][r.c];
+      for (size_t k = 0; k < sv.size(); k++) {
+        // sample points: [oods] or [prev, oods]
+        CPoint<QM31> pt = (sv.size() == 2 && k == 0) ? prev_points[P.trees[r.t].coeffs.logs[r.c]] : oods;
+        size_t b = 0;
+        for (; b < batches.size(); b++) if (batches[b].pt.x == pt.x && batches[b].pt.y == pt.y) break;
+        if (b == batches.size()) batches.push_back(Batch{pt, {}});
+        batches[b].entries.push_back({i, sv[k]});
+      }
+    }
+    std::vector<QuotientBatch> qb(batches.size());
+    std::vector<uint32_t> col_index, coef_c;
+    for (size_t b = 0; b < batches.size(); b++) {
+      qb[b].begin = (uint32_t)col_index.size();
+      QM31 alpha(M31(1)), sum_a, sum_b;
+      QM31 cdiff = conj_u(batches[b].pt.y) - batches[b].pt.y;
+      for (auto& e : batches[b].entries) {
+        alpha = alpha * qcoeff;
+        QM31 a = conj_u(e.second) - e.second;
+        QM31 bb = e.second * cdiff - a * batches[b].pt.y;
+        sum_a += alpha * a;
+        sum_b += alpha * bb;
+        col_index.push_back(e.first);
+        uint32_t w[4];
+        (alpha * cdiff).to_u32(w);
+        coef_c.insert(coef_c.end(), w, w + 4);
+      }
+      qb[b].end = (uint32_t)col_index.size();
+      batches[b].pt.x.to_u32(qb[b].point);
+      batches[b].pt.y.to_u32(qb[b].point + 4);
+      // kernel wants (Pr.x, Pi.x, Pr.y, Pi.y) = (x.a, x.b, y.a, y.b): QM31 words already are [a.a,a.b,b.a,b.b]
+      sum_a.to_u32(qb[b].sum_a);
+      sum_b.to_u32(qb[b].sum_b);
+      qpow(qcoeff, batches[b].entries.size()).to_u32(qb[b].batch_coeff);
+    }
+    ColumnSet q;
+    q.alloc(std::vector<uint32_t>(4, l), st);
+    DevBuf dcols = upload(cols, st), dci = upload(col_index, st), dcc = upload(coef_c, st), dqb = upload(qb, st);
+    QuotientArgs a;
+    a.tw = view(*P.tw); a.log_size = l; a.cols = dcols.as<const uint32_t*>(); a.col_index = dci.u32(); a.coef_c = dcc.u32();
+    a.batches = dqb.as<QuotientBatch>(); a.n_batches = (uint32_t)qb.size(); a.out = q.dev();
+    launch_quotients(a, st);
+    CM_HIP(hipStreamSynchronize(st));
+    q_logs.push_back(l);
+    quotients.push_back(std::move(q));
+  }
+  P.tick("quotients");
+
+  // ---- FRI commit ----
+  MerkleTree first_tree;
+  {
+    std::vector<const uint32_t*> cols;
+    std::vector<uint32_t> logs;
+    for (size_t k = 0; k < quotients.size(); k++) for (int c = 0; c < 4; c++) { cols.push_back(quotients[k].ptrs[c]); logs.push_back(q_logs[k]); }
+    first_tree.commit(cols, logs, st);
+    first_tree.root(pf.fri_first.commitment.data(), st);
+    ch.mix_root(pf.fri_first.commitment);
+  }
+  QM31 circle_alpha = ch.draw_felt();
+  struct InnerLayer { ColumnSet eval; uint32_t log; MerkleTree tree; hostch::Hash32 root; };
+  std::vector<std::unique_ptr<InnerLayer>> inner;
+  uint32_t layer_log = q_logs[0] - 1;
+  const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup_factor;
+  ColumnSet layer;
+  layer.alloc(std::vector<uint32_t>(4, layer_log), st);
+  CM_HIP(hipMemsetAsync(layer.buf.p, 0, layer.buf.bytes, st));
+  size_t qi = 0;
+  while (layer_log > last_log) {
+    while (qi < quotients.size() && q_logs[qi] - 1 == layer_log) {
+      const uint32_t* src[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
+      uint32_t* dst[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
+      fold_circle_into_line(dst, src, q_logs[qi], *P.tw, circle_alpha, true, st);
+      qi++;
+    }
+    std::unique_ptr<InnerLayer> il(new InnerLayer());
+    il->log = layer_log;
+    il->eval = std::move(layer);
+    std::vector<const uint32_t*> cols(il->eval.ptrs.begin(), il->eval.ptrs.end());
+    il->tree.commit(cols, std::vector<uint32_t>(4, layer_log), st);
+    il->tree.root(il->root.data(), st);
+    ch.mix_root(il->root);
+    QM31 alpha = ch.draw_felt();
+    layer = ColumnSet();
+    layer.alloc(std::vector<uint32_t>(4, layer_log - 1), st);
+    const uint32_t* src[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
+    uint32_t* dst[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
+    fold_line(dst, src, layer_log, *P.tw, alpha, st);
+    layer_log--;
+    inner.push_back(std::move(il));
+  }
+  CM_CHECK(qi == quotients.size(), "fri: not every quotient column was folded");
+  // last layer (2^last_log values): interpolate on the host, keep 2^log_last_layer coefficients
+  {
+    uint32_t n = 1u << last_log;
+    const uint32_t* c4[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
+    std::vector<uint32_t> pos(n);
+    for (uint32_t i = 0; i < n; i++) pos[i] = i;
+    std::vector<QM31> vals = gather_q(c4, pos, st);
+    for (uint32_t l = 0; l < last_log; l++) {
+      uint32_t stride = 1u << l;
+      for (uint32_t h = 0; h < (n >> (l + 1)); h++) {
+        // LineDomain(half_odds(last_log)) doubled l times: coset half_odds(last_log - l); point bitrev(h)
+        uint32_t clog_ = last_log - l;
+        uint32_t idx = subgroup_gen_index(clog_ + 2) + subgroup_gen_index(clog_) * bit_reverse(h, clog_ - 1);
+        M31 xinv = inv(point_at_index(idx).x);
+        for (uint32_t k = 0; k < stride; k++) {
+          uint32_t i0 = (h << (l + 1)) + k, i1 = i0 + stride;
+          QM31 a = vals[i0], b = vals[i1];
+          vals[i0] = a + b;
+          vals[i1] = (a - b) * xinv;
+        }
+      }
+    }
+    M31 ninv = inv(M31::from_u32(n));
+    std::vector<QM31> ordered(n);
+    for (uint32_t i = 0; i < n; i++) ordered[bit_reverse(i, last_log)] = vals[i] * ninv;
+    uint32_t keep = 1u << cfg.log_last_layer_degree_bound;
+    for (uint32_t i = keep; i < n; i++) CM_CHECK(ordered[i].is_zero(), "fri: last layer has invalid degree");
+    pf.last_layer_poly.assign(ordered.begin(), ordered.begin() + keep);
+    pf.last_layer_log_size = cfg.log_last_layer_degree_bound;
+    ch.mix_felts(pf.last_layer_poly.data(), pf.last_layer_poly.size());
+  }
+  P.tick("fri_commit");
+  pf.proof_of_work = grind_gpu(ch.digest.data(), cfg.pow_bits, st);
+  ch.mix_u64(pf.proof_of_work);
+  P.tick("pow");
+
+  // ---- queries + decommitment ----
+  Queries queries;
+  {
+    std::set<uint32_t> s;
+    uint32_t cnt = 0, mask = (1u << q_logs[0]) - 1;
+    bool done = false;
+    while (!done) {
+      hostch::Hash32 b = ch.draw_random_bytes();
+      for (int k = 0; k < 8 && !done; k++) {
+        uint32_t w;
+        memcpy(&w, b.data() + 4 * k, 4);
+        s.insert(w & mask);
+        if (++cnt == cfg.n_queries) done = true;
+      }
+    }
+    queries.positions.assign(s.begin(), s.end());
+    queries.log_domain_size = q_logs[0];
+  }
+  std::map<uint32_t, std::vector<uint32_t>> qpos;
+  for (auto l : q_logs) qpos[l] = queries.fold(queries.log_domain_size - l).positions;
+  {
+    std::map<uint32_t, std::vector<uint32_t>> dpos;
+    for (size_t k = 0; k < quotients.size(); k++) {
+      const uint32_t* c4[4] = {quotients[k].ptrs[0], quotients[k].ptrs[1], quotients[k].ptrs[2], quotients[k].ptrs[3]};
+      std::vector<uint32_t> pos;
+      decommit_positions(c4, qpos[q_logs[k]], pos, pf.fri_first.fri_witness, st);
+      dpos[q_logs[k]] = pos;
+    }
+    std::vector<uint32_t> qv;
+    first_tree.decommit(dpos, qv, pf.fri_first.decommitment, st);
+  }
+  {
+    Queries lq = queries.fold(1);
+    for (auto& il : inner) {
+      FriLayerProofData lp;
+      const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
+      std::vector<uint32_t> pos;
+      decommit_positions(c4, lq.positions, pos, lp.fri_witness, st);
+      std::map<uint32_t, std::vector<uint32_t>> dpos;
+      dpos[il->log] = pos;
+      std::vector<uint32_t> qv;
+      il->tree.decommit(dpos, qv, lp.decommitment, st);
+      lp.commitment = il->root;
+      pf.fri_inner.push_back(std::move(lp));
+      lq = lq.fold(1);
+    }
+  }
+  pf.decommitments.resize(4);
+  pf.queried_values.resize(4);
+  for (int t = 0; t < 4; t++) {
+    P.trees[t].merkle.decommit(qpos, pf.queried_values[t], pf.decommitments[t], st);
+    pf.commitments.push_back(P.trees[t].root);
+  }
+  P.tick("decommit");
+  pf.phase_ms = P.phase_ms;
+  pf.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  pf.steps = 0;
+  for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) pf.steps += in.n_bundles[i];
+  return out.release();
+}
+
+}  // namespace cm
+
+// ================================================================= C ABI
+struct cm_proof { cm::ProofData* d; std::string json; std::vector<uint32_t> words; };
+struct cm_device_input { cm::DeviceInput* d; };
+extern "C" int32_t cm_set_last_error(const char* msg);
+
+template <class F>
+static int32_t pguard(F&& f) {
+  try { f(); return 0; }
+  catch (const cm::CmError& e) { cm_set_last_error(e.what()); return e.code ? e.code : 1; }
+  catch (const std::exception& e) { cm_set_last_error(e.what()); return 1; }
+}
+static cm_pcs_config default_cfg() { return cm_pcs_config{16, 1, 0, 80}; }
+
+extern "C" {
+int32_t cm_input_upload(const cm_prover_input* input, cm_device_input** out) {
+  return pguard([&] { cm_device_input* h = new cm_device_input(); h->d = cm::upload_input(*input); *out = h; });
+}
+int32_t cm_input_free(cm_device_input* h) { if (h) { delete h->d; delete h; } return 0; }
+int32_t cm_prove_device(const cm_device_input* input, const cm_pcs_config* config, cm_proof** out) {
+  return pguard([&] {
+    cm_pcs_config cfg = config ? *config : default_cfg();
+    cm_proof* p = new cm_proof();
+    p->d = cm::prove(*input->d, cfg);
+    *out = p;
+  });
+}
+int32_t cm_prove_segment(const cm_prover_input* input, const cm_pcs_config* config, cm_proof** out) {
+  cm_device_input* di = nullptr;
+  int32_t rc = cm_input_upload(input, &di);
+  if (rc) return rc;
+  rc = cm_prove_device(di, config, out);
+  cm_input_free(di);
+  return rc;
+}
+int32_t cm_proof_free(cm_proof* p) { if (p) { delete p->d; delete p; } return 0; }
+int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out) {
+  return pguard([&] {
+    cm_proof* q = const_cast<cm_proof*>(p);
+    if (q->json.empty()) q->json = cm::proof_to_json(*p->d);
+    *json_out = q->json.c_str();
+    *len_out = q->json.size();
+  });
+}
+int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* n_out) {
+  return pguard([&] {
+    cm_proof* q = const_cast<cm_proof*>(p);
+    if (q->words.empty()) q->words = cm::proof_to_words(*p->d);
+    *words_out = q->words.data();
+    *n_out = q->words.size();
+  });
+}
+int32_t cm_proof_commitments(const cm_proof* p, uint8_t roots[4][32]) {
+  for (int t = 0; t < 4; t++) memcpy(roots[t], p->d->commitments[t].data(), 32);
+  return 0;
+}
+int32_t cm_proof_stats(const cm_proof* p, uint64_t* cells, uint64_t* steps, double* phase_ms, uint32_t n_phases) {
+  if (cells) *cells = p->d->cells;
+  if (steps) *steps = p->d->steps;
+  for (uint32_t i = 0; i < n_phases; i++) phase_ms[i] = i < p->d->phase_ms.size() ? p->d->phase_ms[i] : 0.0;
+  return (int32_t)p->d->phase_ms.size();
+}
+}

@@ -109,3 +109,132 @@ class Backend:
         nonce = C.c_uint64(0)
         self._ck(self.L.cm_grind(d, C.c_uint32(bits), C.byref(nonce)))
         return nonce.value
+
+
+class HostInput:
+    """ProverInput built on the host by the synthetic VM + adapter (no GPU needed)."""
+
+    def __init__(self, lib, handle):
+        self.L = lib
+        self.h = handle
+        self.L.cm_host_input_view.restype = C.c_void_p
+        self.L.cm_host_input_steps.restype = C.c_uint64
+
+    @property
+    def view(self):
+        return C.c_void_p(self.L.cm_host_input_view(self.h))
+
+    @property
+    def steps(self):
+        return int(self.L.cm_host_input_steps(self.h))
+
+    def free(self):
+        if self.h:
+            self.L.cm_host_input_free(self.h)
+            self.h = None
+
+
+def _lib_error(L, rc):
+    buf = C.create_string_buffer(2048)
+    L.cm_last_error(buf, C.c_size_t(2048))
+    return CmError(f"libcairom_hip status {rc}: {buf.value.decode(errors='replace')}")
+
+
+def synth_fibonacci(n, max_steps=1 << 30, segment=0, lib=None):
+    """fibonacci_loop(n) through the synthetic VM + adapter: 10*n + 12 steps."""
+    L = lib or load_library()
+    h = C.c_void_p()
+    rc = L.cm_synth_fibonacci(C.c_uint32(n), C.c_uint64(max_steps), C.c_uint32(segment), C.byref(h))
+    if rc:
+        raise _lib_error(L, rc)
+    return HostInput(L, h)
+
+
+def vm_run(program, entry_pc=0, args=(), n_returns=0, max_steps=1 << 30, segment=0, lib=None):
+    """Run a CASM program (list of instruction word lists) and adapt one segment."""
+    L = lib or load_library()
+    words = np.array([w for ins in program for w in ins], dtype=np.uint32)
+    lens = np.array([len(ins) for ins in program], dtype=np.uint32)
+    a = np.array(list(args), dtype=np.uint32)
+    h = C.c_void_p()
+    nseg = C.c_uint32(0)
+    rc = L.cm_vm_run(_p(words), _p(lens), C.c_uint32(len(program)), C.c_uint32(entry_pc), _p(a), C.c_uint32(len(a)),
+                     C.c_uint32(n_returns), C.c_uint64(max_steps), C.c_uint32(segment), C.byref(h), C.byref(nseg))
+    if rc:
+        raise _lib_error(L, rc)
+    hi = HostInput(L, h)
+    hi.n_segments = nseg.value
+    return hi
+
+
+class Proof:
+    PHASES = ["setup", "preprocessed", "trace_gen", "trace_commit", "interaction_gen", "interaction_commit",
+              "constraints", "composition_commit", "oods_sampling", "quotients", "fri_commit", "pow", "decommit"]
+
+    def __init__(self, lib, handle):
+        self.L = lib
+        self.h = handle
+
+    def words(self):
+        p = C.POINTER(C.c_uint32)()
+        n = C.c_uint64(0)
+        rc = self.L.cm_proof_words(self.h, C.byref(p), C.byref(n))
+        if rc:
+            raise _lib_error(self.L, rc)
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def json(self):
+        p = C.c_char_p()
+        n = C.c_size_t(0)
+        rc = self.L.cm_proof_json(self.h, C.byref(p), C.byref(n))
+        if rc:
+            raise _lib_error(self.L, rc)
+        return C.string_at(p, n.value).decode()
+
+    def commitments(self):
+        roots = ((C.c_uint8 * 32) * 4)()
+        self.L.cm_proof_commitments(self.h, roots)
+        return [bytes(r) for r in roots]
+
+    def stats(self):
+        cells, steps = C.c_uint64(0), C.c_uint64(0)
+        ph = (C.c_double * 32)()
+        n = self.L.cm_proof_stats(self.h, C.byref(cells), C.byref(steps), ph, C.c_uint32(32))
+        return {"cells": cells.value, "steps": steps.value,
+                "phase_ms": dict(zip(self.PHASES, [ph[i] for i in range(min(n, 32))]))}
+
+    def free(self):
+        if self.h:
+            self.L.cm_proof_free(self.h)
+            self.h = None
+
+
+def _cfg(cfg):
+    if cfg is None:
+        return None
+    return (C.c_uint32 * 4)(*cfg)  # pow_bits, log_blowup_factor, log_last_layer_degree_bound, n_queries
+
+
+def _backend_prove(self, host_input, cfg=None):
+    """prove_cairo_m (crates/prover/src/prover.rs:23): upload + prove."""
+    h = C.c_void_p()
+    self._ck(self.L.cm_prove_segment(host_input.view, _cfg(cfg), C.byref(h)))
+    return Proof(self.L, h)
+
+
+def _backend_upload(self, host_input):
+    h = C.c_void_p()
+    self._ck(self.L.cm_input_upload(host_input.view, C.byref(h)))
+    return h
+
+
+def _backend_prove_device(self, dev_input, cfg=None):
+    h = C.c_void_p()
+    self._ck(self.L.cm_prove_device(dev_input, _cfg(cfg), C.byref(h)))
+    return Proof(self.L, h)
+
+
+Backend.prove = _backend_prove
+Backend.upload_input = _backend_upload
+Backend.prove_device = _backend_prove_device
+Backend.free_input = lambda self, h: self.L.cm_input_free(h)

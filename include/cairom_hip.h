@@ -196,6 +196,13 @@ typedef struct cm_proof cm_proof;
  * config == NULL selects REGULAR_96_BITS. */
 int32_t cm_prove_segment(const cm_prover_input* input, const cm_pcs_config* config, cm_proof** out);
 int32_t cm_proof_free(cm_proof* p);
+/* Same path with the input already resident in HBM (what bench.py times): upload once, prove many. */
+typedef struct cm_device_input cm_device_input;
+int32_t cm_input_upload(const cm_prover_input* input, cm_device_input** out);
+int32_t cm_input_free(cm_device_input* h);
+int32_t cm_prove_device(const cm_device_input* input, const cm_pcs_config* config, cm_proof** out);
+/* Flat u32 serialisation of the proof (format: cairo_m_amd/csrc/proof.hpp), used by the parity tests. */
+int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* n_out);
 /* JSON text of the proof; *len_out = length without the terminating NUL; the buffer is owned by
  * the proof object. */
 int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out);

@@ -80,3 +80,59 @@ class Oracle:
         o = np.empty_like(a)
         self.L.orc_qm31_inv(_p(a), _p(o), C.c_size_t(a.size // 4))
         return o
+
+
+def _attach_prover(cls):
+    def setup(self):
+        self.L.orc_last_error.restype = C.c_char_p
+        self.L.orc_proof_n_words.restype = C.c_uint64
+        self.L.orc_proof_cells.restype = C.c_uint64
+
+    def err(self):
+        return self.L.orc_last_error().decode(errors="replace")
+
+    def prove(self, view, cfg=(16, 1, 0, 80)):
+        """CPU restatement of prove_cairo_m; returns (words, cells)."""
+        setup(self)
+        h = C.c_void_p()
+        rc = self.L.orc_prove(view, (C.c_uint32 * 4)(*cfg), C.byref(h))
+        if rc:
+            raise RuntimeError("oracle prove failed: " + err(self))
+        n = self.L.orc_proof_n_words(h)
+        w = np.zeros(n, dtype=np.uint32)
+        self.L.orc_proof_words(h, _p(w))
+        cells = self.L.orc_proof_cells(h)
+        self.L.orc_proof_free(h)
+        return w, cells
+
+    def verify(self, words):
+        setup(self)
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        rc = self.L.orc_verify(_p(w), C.c_uint64(w.size))
+        return rc, (err(self) if rc else "")
+
+    def assert_constraints(self, view):
+        setup(self)
+        rc = self.L.orc_assert_constraints(view)
+        return rc, (err(self) if rc else "")
+
+    def component_trace(self, view, cid):
+        setup(self)
+        log, ncols = C.c_uint32(0), C.c_uint32(0)
+        self.L.orc_component_trace(view, C.c_int(cid), C.byref(log), C.byref(ncols), None, C.c_uint64(0))
+        out = np.zeros(ncols.value << log.value, dtype=np.uint32)
+        rc = self.L.orc_component_trace(view, C.c_int(cid), C.byref(log), C.byref(ncols), _p(out), C.c_uint64(out.size))
+        if rc:
+            raise RuntimeError(err(self))
+        return out.reshape(ncols.value, 1 << log.value)
+
+    def poseidon2_permute(self, state):
+        s = np.ascontiguousarray(state, dtype=np.uint32).copy()
+        self.L.orc_poseidon2_permute(_p(s))
+        return s
+
+    cls.prove, cls.verify, cls.assert_constraints = prove, verify, assert_constraints
+    cls.component_trace, cls.poseidon2_permute = component_trace, poseidon2_permute
+
+
+_attach_prover(Oracle)
