@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the hot path (prove one Cairo-M segment) on MI355X.
+
+Metric (BASELINE.json): M31 trace cells/s proved, fibonacci_loop at ~2^22 rows, end-to-end proof ms.
+A "step" = one whole proof (trace gen -> proof object) of the synthetic fibonacci_loop segment with the
+ProverInput already resident in HBM.  N > 1: one process per GPU (torch.distributed / RCCL used only for
+the barrier and the max-over-ranks reduction); every rank proves an independent segment (continuation
+segments are independent proofs — SURVEY §8e-1), so scaling is weak and there is no data-path collective.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the library on
+its launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FIB_N = 419_000          # 10*n + 12 = 4,190,012 VM steps (~2^22), one segment
+HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MODEL_BYTES_PER_CELL = 52.0  # SURVEY §8d algorithmic-bytes model for the whole path
+
+
+def cpu_baseline(sample_n):
+    """Oracle (CPU restatement, 'port') on a bounded sample of the same workload family."""
+    import subprocess
+    from tests.oracle_binding import Oracle
+    from cairo_m_amd.lib import synth_fibonacci
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    orc = Oracle(so)
+    inp = synth_fibonacci(sample_n)
+    t = time.perf_counter()
+    _, cells = orc.prove(inp.view)
+    dt = time.perf_counter() - t
+    steps = inp.steps
+    inp.free()
+    return {"value": cells / dt, "unit": "M31 trace cells/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"fibonacci_loop n={sample_n} ({steps} VM steps, {cells} cells incl. the fixed "
+                      f"2^20/2^18/2^16 preprocessed + range-check tables), oracle prove_segment, OpenMP, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--fib-n", type=int, default=FIB_N)
+    ap.add_argument("--cpu-sample-n", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cairo_m_amd import Backend
+    from cairo_m_amd.lib import synth_fibonacci
+    be = Backend(local_rank)          # fails loudly without the .so / a GPU
+    inp = synth_fibonacci(args.fib_n)  # host: synthetic VM + adapter
+    dev = be.upload_input(inp)         # ProverInput resident in HBM before the timed region
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    cells = None
+    for _ in range(args.warmup):
+        p = be.prove_device(dev)
+        cells = p.stats()["cells"]
+        p.free()
+    be.L.cm_kprof_enable(C.c_int32(1))
+    sync()
+    t0 = time.perf_counter()
+    phases = None
+    for _ in range(args.steps):
+        p = be.prove_device(dev)
+        st = p.stats()
+        cells = st["cells"]
+        phases = st["phase_ms"]
+        p.free()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+    buf = C.create_string_buffer(1 << 16)
+    be.L.cm_kprof_report(buf, C.c_size_t(1 << 16))
+    kprof = json.loads(buf.value.decode())
+    be.L.cm_kprof_enable(C.c_int32(0))
+
+    if rank == 0:
+        ms_per_step = dt * 1e3 / args.steps
+        value = world * args.steps * cells / dt
+        dom = max(kprof.items(), key=lambda kv: kv[1]["ms"]) if kprof else None
+        roofline = None
+        if dom:
+            name, k = dom
+            achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": k["ms"] / k["calls"], "launches": k["calls"],
+                        "algorithmic_bytes_per_launch": k["bytes"] / k["calls"],
+                        "whole_path_model": {"bytes_per_cell": MODEL_BYTES_PER_CELL,
+                                             "achieved_GBs": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9,
+                                             "frac": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "kernels": {n: {"ms_per_step": v["ms"] / args.steps,
+                                        "GBs": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else None}
+                                    for n, v in kprof.items()}}
+        out = {"metric": "M31 trace cells/sec proved, fibonacci_loop 2^22 rows; end-to-end proof ms",
+               "value": value, "unit": "M31 trace cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u32", "data": "synthetic",
+               "config": {"workload": f"fibonacci_loop n={args.fib_n} ({inp.steps} VM steps, one segment, "
+                                      f"{cells} committed trace cells), REGULAR_96_BITS PCS config, "
+                                      "ProverInput resident in HBM", "cells_per_proof": cells,
+                          "vm_steps": inp.steps, "parallelism": f"{world} independent segment replica(s)"},
+               "phase_ms": phases, "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    be.free_input(dev)
+    inp.free()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

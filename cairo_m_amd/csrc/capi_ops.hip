@@ -1,0 +1,122 @@
+// extern "C" wrappers for the single-op backend entry points that mirror Stwo's FieldOps / FriOps /
+// QuotientOps traits (declared in include/cairom_hip.h).  The whole-segment prover calls the same
+// engine functions directly.
+#include "../../include/cairom_hip.h"
+#include "engine.hpp"
+#include "fri_kernels.hpp"
+#include <string>
+
+using namespace cm;
+extern "C" int32_t cm_set_last_error(const char* msg);
+
+namespace {
+inline hipStream_t S(cm_stream_t s) { return (hipStream_t)(uintptr_t)s; }
+inline uint32_t* P32(cm_handle h) { return (uint32_t*)(uintptr_t)h; }
+template <class F>
+int32_t guard(F&& f) {
+  try { f(); return 0; }
+  catch (const CmError& e) { cm_set_last_error(e.what()); return e.code ? e.code : 1; }
+  catch (const std::exception& e) { cm_set_last_error(e.what()); return 1; }
+}
+__global__ void k_inverse_m31(const uint32_t* in, uint32_t* out, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = inv(M31(in[i])).v;
+}
+struct P4 { uint32_t* p[4]; };
+struct CP4 { const uint32_t* p[4]; };
+__global__ void k_inverse_qm31(CP4 in, P4 out, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  QM31 v = inv(QM31(M31(in.p[0][i]), M31(in.p[1][i]), M31(in.p[2][i]), M31(in.p[3][i])));
+  out.p[0][i] = v.a.a.v; out.p[1][i] = v.a.b.v; out.p[2][i] = v.b.a.v; out.p[3][i] = v.b.b.v;
+}
+}  // namespace
+
+extern "C" {
+
+// FieldOps::batch_inverse: element-wise inverses (the Montgomery trick of the CPU backend is a
+// latency optimisation; one Fermat chain per lane is the GPU-native form and gives the same values).
+int32_t cm_batch_inverse_m31(cm_handle in, cm_handle out, uint64_t n, cm_stream_t s) {
+  return guard([&] {
+    if (!n) return;
+    hipLaunchKernelGGL(k_inverse_m31, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(s), P32(in), P32(out), n);
+    CM_HIP(hipGetLastError());
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_batch_inverse_qm31(const cm_handle in[4], const cm_handle out[4], uint64_t n, cm_stream_t s) {
+  return guard([&] {
+    if (!n) return;
+    CP4 i4; P4 o4;
+    for (int k = 0; k < 4; k++) { i4.p[k] = P32(in[k]); o4.p[k] = P32(out[k]); }
+    hipLaunchKernelGGL(k_inverse_qm31, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(s), i4, o4, n);
+    CM_HIP(hipGetLastError());
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_fri_fold_circle_into_line(const cm_handle dst[4], const cm_handle src[4], const uint32_t alpha[4], uint32_t log_n,
+                                     cm_handle tw, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(tw, "cm_fri_fold_circle_into_line: null twiddles");
+    uint32_t* d[4]; const uint32_t* c[4];
+    for (int k = 0; k < 4; k++) { d[k] = P32(dst[k]); c[k] = P32(src[k]); }
+    fold_circle_into_line(d, c, log_n, *(Twiddles*)(uintptr_t)tw, QM31::from_u32(alpha), true, S(s));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_fri_fold_line(const cm_handle in[4], const uint32_t alpha[4], uint32_t log_n, cm_handle tw, const cm_handle out[4],
+                         cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(tw, "cm_fri_fold_line: null twiddles");
+    uint32_t* d[4]; const uint32_t* c[4];
+    for (int k = 0; k < 4; k++) { d[k] = P32(out[k]); c[k] = P32(in[k]); }
+    fold_line(d, c, log_n, *(Twiddles*)(uintptr_t)tw, QM31::from_u32(alpha), S(s));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_accumulate_quotients(uint32_t log_size, const cm_handle* cols, uint32_t n_cols, const cm_sample_batches* b,
+                                const uint32_t random_coeff[4], const cm_handle out[4], cm_handle tw, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(tw, "cm_accumulate_quotients: null twiddles");
+    QM31 rc = QM31::from_u32(random_coeff);
+    std::vector<const uint32_t*> c(n_cols);
+    for (uint32_t i = 0; i < n_cols; i++) c[i] = P32(cols[i]);
+    std::vector<QuotientBatch> qb(b->n_batches);
+    std::vector<uint32_t> col_index, coef_c;
+    for (uint32_t k = 0; k < b->n_batches; k++) {
+      CPoint<QM31> pt{QM31::from_u32(b->points + 8 * k), QM31::from_u32(b->points + 8 * k + 4)};
+      qb[k].begin = (uint32_t)col_index.size();
+      QM31 alpha(M31(1)), sum_a, sum_b;
+      QM31 cdiff = conj_u(pt.y) - pt.y;
+      for (uint32_t e = b->batch_off[k]; e < b->batch_off[k + 1]; e++) {
+        QM31 v = QM31::from_u32(b->values + 4 * e);
+        alpha = alpha * rc;
+        QM31 a = conj_u(v) - v;
+        QM31 bb = v * cdiff - a * pt.y;
+        sum_a += alpha * a;
+        sum_b += alpha * bb;
+        col_index.push_back(b->col_index[e]);
+        uint32_t w[4];
+        (alpha * cdiff).to_u32(w);
+        coef_c.insert(coef_c.end(), w, w + 4);
+      }
+      qb[k].end = (uint32_t)col_index.size();
+      pt.x.to_u32(qb[k].point);
+      pt.y.to_u32(qb[k].point + 4);
+      sum_a.to_u32(qb[k].sum_a);
+      sum_b.to_u32(qb[k].sum_b);
+      qpow(rc, b->batch_off[k + 1] - b->batch_off[k]).to_u32(qb[k].batch_coeff);
+    }
+    std::vector<uint32_t*> o(4);
+    for (int k = 0; k < 4; k++) o[k] = P32(out[k]);
+    DevBuf dcols = upload(c, S(s)), dci = upload(col_index, S(s)), dcc = upload(coef_c, S(s)), dqb = upload(qb, S(s)),
+           dout = upload(o, S(s));
+    QuotientArgs a;
+    a.tw = view(*(Twiddles*)(uintptr_t)tw); a.log_size = log_size; a.cols = dcols.as<const uint32_t*>();
+    a.col_index = dci.u32(); a.coef_c = dcc.u32(); a.batches = dqb.as<QuotientBatch>(); a.n_batches = b->n_batches;
+    a.out = dout.as<uint32_t*>();
+    launch_quotients(a, (double)n_cols, S(s));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+}

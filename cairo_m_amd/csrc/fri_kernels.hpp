@@ -27,7 +27,7 @@ struct QuotientArgs {
   uint32_t n_batches;
   uint32_t* const* out;            // 4 coordinate columns (device array)
 };
-void launch_quotients(const QuotientArgs& a, hipStream_t st);
+void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st);
 void fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw,
                            const QM31& alpha, bool accumulate, hipStream_t st);
 void fold_line(uint32_t* const out[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw, const QM31& alpha,

@@ -46,9 +46,25 @@ struct HistEval : air::LogupStream<HistEval, M31, EmptyEF> {
   __device__ void constraint(M31) {}
   __device__ EmptyEF combine(int, const M31*, int) { return {}; }
   __device__ EmptyEF ef_from(M31) { return {}; }
+  // Lookup values are heavily repeated inside a wave (e.g. clock deltas of a loop body), so plain
+  // per-lane atomics serialise on a handful of addresses.  Wave-aggregate first: up to 4 rounds of
+  // "leader value -> ballot of equal lanes -> one atomicAdd(popcount)", then per-lane atomics for the rest.
   __device__ void bump(uint32_t* t, uint32_t idx, uint32_t size) {
-    if (idx < size) atomicAdd(t + idx, 1u);
-    else atomicOr(h.error_flag, 1u);
+    if (idx >= size) { atomicOr(h.error_flag, 1u); return; }
+    bool pending = true;
+#pragma unroll 1
+    for (int round = 0; round < 4; round++) {
+      unsigned long long active = __ballot(pending);
+      if (!active) return;
+      int leader = __ffsll((long long)active) - 1;
+      uint32_t lv = (uint32_t)__shfl((int)idx, leader, 64);
+      unsigned long long same = __ballot(pending && idx == lv);
+      if (pending && idx == lv) {
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(t + idx, (uint32_t)__popcll(same));
+        pending = false;
+      }
+    }
+    if (pending) atomicAdd(t + idx, 1u);
   }
   __device__ void on_entry(int rel, M31, const M31* v, int) {
     if (rel == air::REL_RC8) bump(h.rc8, v[0].v, 1u << 8);

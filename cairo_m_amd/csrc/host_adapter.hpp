@@ -309,21 +309,12 @@ inline uint32_t build_partial_merkle_tree(const std::map<uint32_t, MemState>& me
   return cur.begin()->second.value;
 }
 
-// import_internal (adapter/mod.rs:97-193)
-inline ProverInputOwned import_segment(const Segment& seg, const uint32_t prog[2], const uint32_t inp[2],
-                                       const uint32_t outp[2]) {
-  ProverInputOwned out;
-  if (seg.trace.empty()) throw std::runtime_error("adapter: empty trace");
-  for (int i = 0; i < 2; i++) { out.program_range[i] = prog[i]; out.input_range[i] = inp[i]; out.output_range[i] = outp[i]; }
+// Memory (adapter/memory.rs:186-193) with Memory::push (adapter/memory.rs:470-535)
+struct MemArg { uint32_t address; Cell prev_val, value; uint32_t prev_clock, clock; };
+struct MemoryTracker {
   std::map<uint32_t, MemState> initial_memory, final_memory;
-  for (size_t a = 0; a < seg.initial_memory.size(); a++) {
-    MemState s{seg.initial_memory[a], 0u, 0u};
-    initial_memory[(uint32_t)a] = s;
-    final_memory[(uint32_t)a] = s;
-  }
-  struct Arg { uint32_t address; Cell prev_val, value; uint32_t prev_clock, clock; };
-  // Memory::push (adapter/memory.rs:470-535)
-  auto push = [&](uint32_t address, const Cell& value, uint32_t clock) -> Arg {
+  std::vector<cm_clock_update> clock_updates;
+  MemArg push(uint32_t address, const Cell& value, uint32_t clock) {
     MemState prev;
     auto it = final_memory.find(address);
     if (it == final_memory.end()) {
@@ -339,19 +330,39 @@ inline ProverInputOwned import_segment(const Segment& seg, const uint32_t prog[2
       if (ii != initial_memory.end()) ii->second.mult = 1;
       else initial_memory[address] = MemState{value, 0u, 1u};
     }
-    const MemState& init = initial_memory.find(address)->second;
+    auto init_it = initial_memory.find(address);
     if (clock > prev_clk) {
       uint32_t delta = clock - prev_clk;
       if (delta > air::RC20_LIMIT) {
+        if (init_it == initial_memory.end()) throw std::runtime_error("adapter: clock update on a cell without initial entry");
+        const MemState& init = init_it->second;
         uint32_t num_steps = delta / air::RC20_LIMIT;
         for (uint32_t k = 0; k < num_steps; k++) {
-          out.clock_updates.push_back(cm_clock_update{address, prev_clk, {init.value[0], init.value[1], init.value[2], init.value[3]}});
+          clock_updates.push_back(cm_clock_update{address, prev_clk, {init.value[0], init.value[1], init.value[2], init.value[3]}});
           prev_clk += air::RC20_LIMIT;
         }
       }
     }
-    return Arg{address, prev.value, value, prev_clk, clock};
-  };
+    return MemArg{address, prev.value, value, prev_clk, clock};
+  }
+};
+
+// import_internal (adapter/mod.rs:97-193)
+inline ProverInputOwned import_segment(const Segment& seg, const uint32_t prog[2], const uint32_t inp[2],
+                                       const uint32_t outp[2]) {
+  ProverInputOwned out;
+  if (seg.trace.empty()) throw std::runtime_error("adapter: empty trace");
+  for (int i = 0; i < 2; i++) { out.program_range[i] = prog[i]; out.input_range[i] = inp[i]; out.output_range[i] = outp[i]; }
+  MemoryTracker mt;
+  std::map<uint32_t, MemState>& initial_memory = mt.initial_memory;
+  std::map<uint32_t, MemState>& final_memory = mt.final_memory;
+  for (size_t a = 0; a < seg.initial_memory.size(); a++) {
+    MemState s{seg.initial_memory[a], 0u, 0u};
+    initial_memory[(uint32_t)a] = s;
+    final_memory[(uint32_t)a] = s;
+  }
+  using Arg = MemArg;
+  auto push = [&](uint32_t address, const Cell& value, uint32_t clock) -> Arg { return mt.push(address, value, clock); };
   out.initial_pc = seg.trace[0][0];
   out.initial_fp = seg.trace[0][1];
   size_t mi = 0;
@@ -388,6 +399,7 @@ inline ProverInputOwned import_segment(const Segment& seg, const uint32_t prog[2
     out.bundles[comp].push_back(b);
     clock++;
   }
+  out.clock_updates = mt.clock_updates;
   out.n_steps = seg.trace.size() - 1;
   out.final_pc = seg.trace.back()[0];
   out.final_fp = seg.trace.back()[1];

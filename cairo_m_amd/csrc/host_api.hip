@@ -47,6 +47,46 @@ int32_t cm_synth_fibonacci(uint32_t n, uint64_t max_steps, uint32_t segment_inde
 const cm_prover_input* cm_host_input_view(const cm_host_input* h) { return &h->view; }
 uint64_t cm_host_input_steps(const cm_host_input* h) { return h->owned.n_steps; }
 int32_t cm_host_input_free(cm_host_input* h) { delete h; return 0; }
+// Test hook for the reference's Memory::push known-answer tests (adapter/memory.rs:545-858).
+// preload: n_preload cells (addr, v0..v3); script: n entries (addr, v0..v3, clock).
+// results: per entry (prev_clock, prev_v0..3); state_out per address asked: see tests/test_adapter.py.
+int32_t cm_adapter_memory_script(const uint32_t* preload, uint32_t n_preload, const uint32_t* script, uint32_t n,
+                                 uint32_t* results, uint32_t* n_clock_updates, uint32_t* clock_updates_out, uint32_t cu_cap,
+                                 const uint32_t* query_addrs, uint32_t n_query, uint32_t* state_out) {
+  try {
+    cm::host::MemoryTracker mt;
+    for (uint32_t i = 0; i < n_preload; i++) {
+      cm::host::MemState s{{preload[5 * i + 1], preload[5 * i + 2], preload[5 * i + 3], preload[5 * i + 4]}, 0u, 0u};
+      mt.initial_memory[preload[5 * i]] = s;
+      mt.final_memory[preload[5 * i]] = s;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t* e = script + 6 * i;
+      cm::host::MemArg a = mt.push(e[0], cm::host::Cell{e[1], e[2], e[3], e[4]}, e[5]);
+      results[5 * i] = a.prev_clock;
+      for (int k = 0; k < 4; k++) results[5 * i + 1 + k] = a.prev_val[k];
+    }
+    *n_clock_updates = (uint32_t)mt.clock_updates.size();
+    for (uint32_t i = 0; i < mt.clock_updates.size() && i < cu_cap; i++) {
+      clock_updates_out[6 * i] = mt.clock_updates[i].address;
+      clock_updates_out[6 * i + 1] = mt.clock_updates[i].prev_clock;
+      for (int k = 0; k < 4; k++) clock_updates_out[6 * i + 2 + k] = mt.clock_updates[i].value[k];
+    }
+    // per queried address: present_i, v0..3, clock, mult (initial) then the same for final  (14 words)
+    for (uint32_t i = 0; i < n_query; i++) {
+      uint32_t* o = state_out + 14 * i;
+      for (int half = 0; half < 2; half++) {
+        auto& m = half ? mt.final_memory : mt.initial_memory;
+        auto it = m.find(query_addrs[i]);
+        uint32_t* q = o + 7 * half;
+        q[0] = it != m.end();
+        if (it != m.end()) { for (int k = 0; k < 4; k++) q[1 + k] = it->second.value[k]; q[5] = it->second.clock; q[6] = it->second.mult; }
+        else for (int k = 1; k < 7; k++) q[k] = 0;
+      }
+    }
+    return 0;
+  } catch (const std::exception& e) { return cm_set_last_error(e.what()); }
+}
 int32_t cm_poseidon2_permute(uint32_t state[16]) {
   cm::M31 s[16];
   for (int i = 0; i < 16; i++) s[i] = cm::M31::from_u32(state[i]);

@@ -1,0 +1,3 @@
+// part 1 of the per-component AIR kernels (split only to parallelise compilation)
+#define CM_AIR_PART 1
+#include "kernels_air.inc"

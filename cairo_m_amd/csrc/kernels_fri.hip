@@ -7,6 +7,7 @@
 #include "device_common.hpp"
 #include "engine.hpp"
 #include "fri_kernels.hpp"
+#include "kprof.hpp"
 
 namespace cm {
 
@@ -79,8 +80,9 @@ __global__ void __launch_bounds__(256) k_fold_line(Ptr4 out, CPtr4 src, uint32_t
 }
 
 // ================================================================= host wrappers
-void launch_quotients(const QuotientArgs& a, hipStream_t st) {
+void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st) {
   uint32_t n = 1u << a.log_size;
+  KProfScope kp("k_quotients", (4.0 * n_cols + 16.0) * (double)n, st);
   hipLaunchKernelGGL(k_quotients, dim3((n + 255) / 256), dim3(256), 0, st, a);
   CM_HIP(hipGetLastError());
 }

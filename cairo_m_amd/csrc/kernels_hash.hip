@@ -11,6 +11,7 @@
 #include "field.hpp"
 #include "device_common.hpp"
 #include "engine.hpp"
+#include "kprof.hpp"
 
 namespace cm {
 
@@ -123,6 +124,8 @@ __global__ void k_gather_values(const uint32_t* const* cols, const uint32_t* col
 void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
                   uint32_t* d_out, hipStream_t st) {
   uint32_t n = 1u << log_size;
+  // algorithmic bytes: column values once + 64 B of child hashes in, 32 B out per node
+  KProfScope kp("k_merkle_layer", (4.0 * ncols + (d_prev ? 64.0 : 0.0) + 32.0) * (double)n, st);
   hipLaunchKernelGGL(k_merkle_layer, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
   CM_HIP(hipGetLastError());
 }

@@ -11,6 +11,7 @@
 #include "field.hpp"
 #include "device_common.hpp"
 #include "engine.hpp"
+#include "kprof.hpp"
 
 namespace cm {
 
@@ -245,6 +246,9 @@ static void launch_pass(const uint32_t* const* d_src, uint32_t* const* d_dst, ui
   uint32_t tile_log = W + M;
   uint32_t ntiles = 1u << (n - tile_log);
   size_t lds = (size_t)4 << tile_log;
+  // algorithmic bytes of one pass: every element written once; read once unless it is implicit zero padding
+  KProfScope kp(INV ? "k_fft_pass<ifft>" : "k_fft_pass<fft>",
+                4.0 * ncols * ((double)(1u << n) + (double)(in_len < (1u << n) ? in_len : (1u << n))), st);
   hipLaunchKernelGGL(k_fft_pass<INV>, dim3(ntiles, ncols), dim3(256), lds, st, a);
 }
 void interpolate_oop(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n, const Twiddles& tw,
@@ -307,6 +311,7 @@ void eval_at_point_batch(const uint32_t* const* d_coeffs, uint32_t ncols, uint32
   hipLaunchKernelGGL(k_point_table, dim3(((1u << low) + 255) / 256), dim3(256), 0, st, d_maps, 0u, low, d_low);
   hipLaunchKernelGGL(k_point_table, dim3(((1u << high) + 255) / 256), dim3(256), 0, st, d_maps, low, high, d_high);
   uint32_t nchunks = 1u << high;
+  KProfScope kp("k_eval_at_point", 4.0 * ncols * (double)(1u << n), st);
   hipLaunchKernelGGL(k_eval_at_point_partial, dim3(nchunks, ncols), dim3(256), 0, st, d_coeffs, n, d_low, d_high,
                      d_partial);
   hipLaunchKernelGGL(k_reduce_partials, dim3(ncols), dim3(256), 0, st, d_partial, nchunks, d_out);

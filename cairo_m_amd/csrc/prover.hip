@@ -11,6 +11,7 @@
 #include "gpu_air.hpp"
 #include "host_channel.hpp"
 #include "proof.hpp"
+#include "kprof.hpp"
 #include <chrono>
 #include <memory>
 #include <map>
@@ -629,7 +630,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     QuotientArgs a;
     a.tw = view(*P.tw); a.log_size = l; a.cols = dcols.as<const uint32_t*>(); a.col_index = dci.u32(); a.coef_c = dcc.u32();
     a.batches = dqb.as<QuotientBatch>(); a.n_batches = (uint32_t)qb.size(); a.out = q.dev();
-    launch_quotients(a, st);
+    launch_quotients(a, (double)cols.size(), st);
     CM_HIP(hipStreamSynchronize(st));
     q_logs.push_back(l);
     quotients.push_back(std::move(q));
@@ -832,6 +833,28 @@ int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* 
 int32_t cm_proof_commitments(const cm_proof* p, uint8_t roots[4][32]) {
   for (int t = 0; t < 4; t++) memcpy(roots[t], p->d->commitments[t].data(), 32);
   return 0;
+}
+int32_t cm_kprof_enable(int32_t on) {
+  cm::KProf::get().reset();
+  cm::KProf::get().on = on != 0;
+  return 0;
+}
+// JSON: {"kernel": {"calls": n, "ms": total, "bytes": algorithmic bytes}, ...}
+int32_t cm_kprof_report(char* buf, size_t buf_len) {
+  (void)hipDeviceSynchronize();
+  cm::KProf& k = cm::KProf::get();
+  k.flush();
+  std::string s = "{";
+  bool first = true;
+  for (auto& kv : k.agg) {
+    if (!first) s += ",";
+    first = false;
+    s += "\"" + kv.first + "\":{\"calls\":" + std::to_string(kv.second.calls) + ",\"ms\":" + std::to_string(kv.second.ms) +
+         ",\"bytes\":" + std::to_string(kv.second.bytes) + "}";
+  }
+  s += "}";
+  if (buf && buf_len) { size_t n = s.size() < buf_len - 1 ? s.size() : buf_len - 1; memcpy(buf, s.data(), n); buf[n] = 0; }
+  return (int32_t)s.size();
 }
 int32_t cm_proof_stats(const cm_proof* p, uint64_t* cells, uint64_t* steps, double* phase_ms, uint32_t n_phases) {
   if (cells) *cells = p->d->cells;

@@ -104,7 +104,7 @@ typedef struct {
 } cm_sample_batches;
 int32_t cm_accumulate_quotients(uint32_t log_size, const cm_handle* cols, uint32_t n_cols,
                                 const cm_sample_batches* batches, const uint32_t random_coeff[4],
-                                const cm_handle out[4], cm_stream_t s);
+                                const cm_handle out[4], cm_handle tw, cm_stream_t s);
 
 /* ---- Cairo-M prover input (mirror of crates/prover/src/adapter/mod.rs:27-83 ProverInput) ----- */
 #define CM_N_OPCODE_COMPONENTS 26
@@ -177,6 +177,10 @@ int32_t cm_synth_fibonacci(uint32_t n, uint64_t max_steps, uint32_t segment_inde
 const cm_prover_input* cm_host_input_view(const cm_host_input* h);
 uint64_t cm_host_input_steps(const cm_host_input* h);
 int32_t cm_host_input_free(cm_host_input* h);
+/* Test hook: replay `Memory::push` (crates/prover/src/adapter/memory.rs:470-535) over a script of accesses. */
+int32_t cm_adapter_memory_script(const uint32_t* preload, uint32_t n_preload, const uint32_t* script, uint32_t n,
+                                 uint32_t* results, uint32_t* n_clock_updates, uint32_t* clock_updates_out, uint32_t cu_cap,
+                                 const uint32_t* query_addrs, uint32_t n_query, uint32_t* state_out);
 /* Poseidon2-M31 t=16 permutation in place (reference KAT: crates/prover/tests/poseidon2.rs:14-34). */
 int32_t cm_poseidon2_permute(uint32_t state[16]);
 
@@ -208,6 +212,9 @@ int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* 
 int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out);
 /* The four commitment roots (trees 0..3), 32 bytes each. */
 int32_t cm_proof_commitments(const cm_proof* p, uint8_t roots[4][32]);
+/* Optional HIP-event kernel timing on the launch stream (bench.py `roofline`). */
+int32_t cm_kprof_enable(int32_t on);
+int32_t cm_kprof_report(char* buf, size_t buf_len);
 /* cells = sum over committed columns of trees 0,1,2 of 2^log_size. */
 int32_t cm_proof_stats(const cm_proof* p, uint64_t* cells, uint64_t* steps, double* phase_ms, uint32_t n_phases);
 

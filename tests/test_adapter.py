@@ -1,0 +1,83 @@
+"""Adapter known answers restated from the reference's own unit tests
+(/root/reference/crates/prover/src/adapter/memory.rs:545-858: Memory::push) through the C-ABI test hook.
+CPU only (host code of the library)."""
+import ctypes as C
+
+import numpy as np
+
+from cairo_m_amd.lib import load_library
+
+P = 2**31 - 1
+RC20_LIMIT = (1 << 20) - 1
+
+
+def run(script, preload=(), queries=()):
+    L = load_library()
+    pre = np.array([w for e in preload for w in e], dtype=np.uint32)
+    scr = np.array([w for e in script for w in e], dtype=np.uint32)
+    res = np.zeros(5 * len(script), dtype=np.uint32)
+    ncu = C.c_uint32(0)
+    cu = np.zeros(6 * 64, dtype=np.uint32)
+    q = np.array(list(queries), dtype=np.uint32)
+    st = np.zeros(14 * max(1, len(queries)), dtype=np.uint32)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+    rc = L.cm_adapter_memory_script(p(pre), C.c_uint32(len(preload)), p(scr), C.c_uint32(len(script)), p(res), C.byref(ncu),
+                                    p(cu), C.c_uint32(64), p(q), C.c_uint32(len(queries)), p(st))
+    assert rc == 0
+    return res.reshape(-1, 5), cu[: 6 * ncu.value].reshape(-1, 6), st.reshape(-1, 2, 7)
+
+
+def test_memory_push_first_entry():  # memory.rs:545-584
+    res, cu, st = run([(100, 1, 2, 3, 4, 10)], queries=[100])
+    assert list(res[0]) == [0, 1, 2, 3, 4]           # prev_clock 0, prev_val = value
+    assert list(st[0][1]) == [1, 1, 2, 3, 4, 10, P - 1]   # final: (value, clock 10, -1)
+    assert list(st[0][0]) == [1, 1, 2, 3, 4, 0, 1]        # initial: (value, 0, 1)
+    assert len(cu) == 0
+
+
+def test_memory_push_same_address():  # memory.rs:586-634
+    res, _, st = run([(100, 1, 2, 3, 4, 10), (100, 5, 6, 7, 8, 20)], queries=[100])
+    assert list(res[1]) == [10, 1, 2, 3, 4]
+    assert list(st[0][1]) == [1, 5, 6, 7, 8, 20, P - 1]
+    assert list(st[0][0]) == [1, 1, 2, 3, 4, 0, 1]
+
+
+def test_memory_push_different_addresses():  # memory.rs:636-698
+    res, _, st = run([(100, 1, 2, 3, 4, 10), (200, 9, 10, 11, 12, 30)], queries=[100, 200])
+    assert list(res[1]) == [0, 9, 10, 11, 12]
+    assert list(st[0][1]) == [1, 1, 2, 3, 4, 10, P - 1] and list(st[1][1]) == [1, 9, 10, 11, 12, 30, P - 1]
+    assert list(st[0][0]) == [1, 1, 2, 3, 4, 0, 1] and list(st[1][0]) == [1, 9, 10, 11, 12, 0, 1]
+
+
+def test_memory_push_multiple_large_clock_deltas():  # memory.rs:700-737
+    delta = 3 * RC20_LIMIT + 500
+    res, cu, _ = run([(100, 1, 2, 3, 4, 10), (100, 5, 6, 7, 8, 10 + delta)])
+    assert len(cu) == 3
+    assert [int(r[1]) for r in cu] == [10, 10 + RC20_LIMIT, 10 + 2 * RC20_LIMIT]
+    assert int(res[1][0]) == 10 + 3 * RC20_LIMIT  # prev_clock = last inserted step
+
+
+def test_memory_push_no_clock_update_for_small_delta():  # memory.rs:739-760
+    _, cu, _ = run([(100, 1, 2, 3, 4, 10), (100, 5, 6, 7, 8, 10 + RC20_LIMIT - 1)])
+    assert len(cu) == 0
+
+
+def test_memory_push_with_preloaded_memory():  # memory.rs:762-858
+    pre = [(0, 10, 20, 30, 40), (1, 50, 60, 70, 80)]
+    res, _, st = run([(0, 10, 20, 30, 40, 5)], preload=pre, queries=[0, 1])
+    assert list(res[0]) == [0, 10, 20, 30, 40]
+    assert list(st[0][0]) == [1, 10, 20, 30, 40, 0, 1]          # initial multiplicity flips to 1
+    assert list(st[0][1]) == [1, 10, 20, 30, 40, 5, P - 1]
+    assert list(st[1][0]) == [1, 50, 60, 70, 80, 0, 0]
+    res, _, st = run([(0, 10, 20, 30, 40, 5), (0, 100, 200, 300, 400, 10)], preload=pre, queries=[0])
+    assert list(res[1]) == [5, 10, 20, 30, 40]
+    assert list(st[0][1]) == [1, 100, 200, 300, 400, 10, P - 1]
+
+
+def test_poseidon2_host_matches_reference_kat():
+    import json, os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon2_kat.json")))
+    L = load_library()
+    s = np.array(kat["input"], dtype=np.uint32)
+    L.cm_poseidon2_permute(s.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert [f"{int(x):08x}" for x in s] == kat["output_hex"]

@@ -33,3 +33,35 @@ def test_fibonacci_proof_bit_exact(backend, oracle, n):
     assert len(j["stark_proof"]["commitments"]) == 4 and len(j["claim"]["opcodes"]) == 26
     proof.free()
     inp.free()
+
+
+def test_felt_and_u32_programs_bit_exact(backend, oracle):
+    """All-felt-opcode and all-u32-opcode programs (tests/test_oracle_air.py): HIP proof == oracle proof."""
+    from cairo_m_amd.lib import vm_run
+    from tests.test_oracle_air import felt_program, u32_program
+    for prog, nret in ((felt_program(), 1), (u32_program(), 0)):
+        inp = vm_run(prog, entry_pc=0, args=(), n_returns=nret)
+        proof = backend.prove(inp)
+        got = proof.words()
+        want, _ = oracle.prove(inp.view)
+        assert got.size == want.size and np.array_equal(got, want)
+        assert oracle.verify(got)[0] == 0
+        proof.free()
+        inp.free()
+
+
+def test_full_size_proof_properties(backend):
+    """fibonacci_loop at 2^20 steps (BASELINE configs[1]): too big for the oracle prover in a test, so check
+    size-independent properties: determinism (two runs give identical words) and the cell count formula."""
+    inp = synth_fibonacci(100_000)
+    assert inp.steps == 1_000_012
+    dev = backend.upload_input(inp)
+    p1 = backend.prove_device(dev)
+    p2 = backend.prove_device(dev)
+    w1, w2 = p1.words(), p2.words()
+    assert np.array_equal(w1, w2)
+    st = p1.stats()
+    assert st["steps"] == 1_000_012 and st["cells"] > 4e7
+    p1.free(); p2.free()
+    backend.free_input(dev)
+    inp.free()

@@ -1,0 +1,142 @@
+"""AIR / trace consistency on the CPU oracle — the check the reference runs in
+crates/prover/tests/prover.rs:351-370 (`assert_constraints`): every constraint of every component
+vanishes on every trace row (incl. padding) and the LogUp sums + public data cancel.  Programs exercise
+the opcode components through the synthetic VM.  Also: oracle prove -> oracle verify round trip."""
+import numpy as np
+import pytest
+
+from cairo_m_amd.lib import synth_fibonacci, vm_run
+
+P = 2**31 - 1
+
+
+def neg(k):
+    return P - k
+
+
+def test_fibonacci_constraints(oracle):
+    inp = synth_fibonacci(40)
+    assert inp.steps == 10 * 40 + 12
+    rc, err = oracle.assert_constraints(inp.view)
+    assert rc == 0, err
+    inp.free()
+
+
+def felt_program():
+    """call/ret, store_fp_fp (add/sub/mul/div), store_fp_imm (add/mul), double derefs, jnz both ways,
+    jmp abs/rel, assert_eq, store_frame_pointer, store_le.  Entry frame: 0 args, 1 return."""
+    return [
+        [9, 7, 0],            # 0: [fp+0] = 7
+        [9, 3, 1],            # 1: [fp+1] = 3
+        [0, 0, 1, 2],         # 2: [fp+2] = 10
+        [1, 0, 1, 3],         # 3: [fp+3] = 4
+        [2, 0, 1, 4],         # 4: [fp+4] = 21
+        [3, 4, 1, 5],         # 5: [fp+5] = 7
+        [4, 5, 100, 6],       # 6: [fp+6] = 107
+        [6, 6, 2, 7],         # 7: [fp+7] = 214
+        [50, 7, 214],         # 8: assert [fp+7] == 214
+        [43, 0, 8],           # 9: [fp+8] = fp
+        [8, 8, 2, 9],         # 10: [fp+9] = [[fp+8]+2] = 10
+        [44, 8, 10, 9],       # 11: [[fp+8]+10] = [fp+9]  -> [fp+10] = 10
+        [9, 1, 11],           # 12: [fp+11] = 1
+        [42, 8, 11, 12],      # 13: [fp+12] = [[fp+8]+[fp+11]] = [fp+1] = 3
+        [45, 8, 11, 12],      # 14: [[fp+8]+[fp+11]] = [fp+12]  (rewrites [fp+1] = 3)
+        [48, 0, 7, 13],       # 15: [fp+13] = (7 <= 7) = 1
+        [48, 2, 5, 14],       # 16: [fp+14] = (10 <= 5) = 0
+        [14, 14, 5],          # 17: jnz [fp+14]=0 -> not taken
+        [14, 13, 2],          # 18: jnz [fp+13]=1 -> +2 (to 20)
+        [9, 99, 15],          # 19: skipped
+        [13, 2],              # 20: jmp rel +2 -> 22
+        [9, 98, 15],          # 21: skipped
+        [12, 23],             # 22: jmp abs 23
+        [10, 20, 26],         # 23: call abs: frame_off 20, target 26
+        [4, 2, 0, neg(3)],    # 24: return slot = [fp+2] + 0
+        [11],                 # 25: ret (top level)
+        [9, 5, 0],            # 26: callee: [fp+0] = 5
+        [11],                 # 27: ret
+    ]
+
+
+def test_felt_opcodes_constraints(oracle):
+    inp = vm_run(felt_program(), entry_pc=0, args=(), n_returns=1)
+    rc, err = oracle.assert_constraints(inp.view)
+    assert rc == 0, err
+    inp.free()
+
+
+def u32_program():
+    """u32 immediates, add/sub/mul/div (fp and imm), lt (fp and imm), and/or/xor (fp and imm).
+    U32StoreEqFpFp / U32StoreEqFpImm are left out on purpose: the reference AIR looks their instruction words up
+    at the wrong place (u32_store_eq_fp_fp.rs:210 reads dst_off from inst_value_4; u32_store_eq_fp_imm.rs:250-251
+    looks the second word up at pc), so their LogUp cannot balance in the reference either; the restated
+    components keep that behaviour and are covered through their padding rows."""
+    A, B = 0x89ABCDEF, 0x00012345
+    lo = lambda v: v & 0xFFFF
+    hi = lambda v: v >> 16
+    return [
+        [23, lo(A), hi(A), 0],          # 0: u32 [0..1] = A
+        [23, lo(B), hi(B), 2],          # 1: u32 [2..3] = B
+        [15, 0, 2, 4],                  # 2: [4..5] = A + B
+        [16, 0, 2, 6],                  # 3: [6..7] = A - B
+        [16, 2, 0, 8],                  # 4: [8..9] = B - A (wraps)
+        [17, 0, 2, 10],                 # 5: [10..11] = A * B
+        [18, 0, 2, 12, 14],             # 6: [12..13] = A / B ; [14..15] = A % B      (2 cells)
+        [19, 0, 0xFFFF, 0xFFFF, 16],    # 8: [16..17] = A + 0xFFFFFFFF               (2 cells)
+        [21, 2, 0x0101, 0x0001, 18],    # 10: [18..19] = B * 0x00010101
+        [22, 0, 1000, 0, 20, 22],       # 12: [20..21] = A / 1000 ; [22..23] = A % 1000
+        [28, 2, 0, 25],                 # 14: [25] = B < A = 1
+        [28, 0, 2, 26],                 # 15: [26] = A < B = 0
+        [34, 2, lo(A), hi(A), 27],      # 16: [27] = B < A (imm)
+        [36, 0, 2, 30],                 # 22: and
+        [37, 0, 2, 32],                 # 23: or
+        [38, 0, 2, 34],                 # 24: xor
+        [39, 0, 0x00FF, 0xFF00, 36],    # 25: and imm
+        [40, 0, 0x00FF, 0xFF00, 38],    # 27: or imm
+        [41, 0, 0x00FF, 0xFF00, 40],    # 29: xor imm
+        [11],                           # 31: ret (division by zero is not provable: q*d + r = n cannot hold)
+    ]
+
+
+def test_u32_opcodes_constraints(oracle):
+    inp = vm_run(u32_program(), entry_pc=0, args=(), n_returns=0)
+    rc, err = oracle.assert_constraints(inp.view)
+    assert rc == 0, err
+    inp.free()
+
+
+CHAIN_PROG = [[9, 1, 0], [4, 0, 1, 1], [4, 1, 1, 0], [4, 0, 1, 1], [4, 1, 1, 0], [4, 0, 1, 1], [11]]
+
+
+def test_segments_chain(oracle):
+    """Continuation: segments cut every max_steps; final root of segment i == initial root of i+1
+    (reference: crates/prover/tests/prover.rs:203-243)."""
+    import ctypes as C
+    roots = []
+    first = vm_run(CHAIN_PROG, max_steps=2, segment=0)
+    nseg = first.n_segments
+    first.free()
+    assert nseg == 4
+    for s in range(nseg):
+        inp = vm_run(CHAIN_PROG, max_steps=2, segment=s)
+        rc, err = oracle.assert_constraints(inp.view)
+        assert rc == 0, err
+        # initial_root / final_root are words 3 and 4 after (initial_pc, initial_fp, final_pc, final_fp)? read via prove-free path:
+        words = np.ctypeslib.as_array(C.cast(inp.view, C.POINTER(C.c_uint32)), shape=(4,))
+        roots.append(tuple(int(w) for w in words))
+        inp.free()
+    # registers chain: final (pc, fp) of segment i = initial (pc, fp) of segment i+1
+    for a, b in zip(roots, roots[1:]):
+        assert a[2:] == b[:2]
+
+
+@pytest.mark.parametrize("n", [3])
+def test_oracle_prove_verify_roundtrip(oracle, n):
+    inp = synth_fibonacci(n)
+    words, cells = oracle.prove(inp.view)
+    assert cells > 0
+    rc, err = oracle.verify(words)
+    assert rc == 0, err
+    bad = words.copy()
+    bad[100] ^= 1
+    assert oracle.verify(bad)[0] != 0
+    inp.free()
