@@ -34,7 +34,7 @@ void launch_logup(int cid, const uint32_t* const* d_cols, const uint32_t* const*
                   const DevRelations* d_rels, uint32_t* const* d_out, hipStream_t st);
 void launch_constraints(int cid, const ConstraintArgs& a, hipStream_t st);
 size_t logup_finalize_scratch_words(uint32_t log_size);
-void logup_finalize_last(uint32_t* const* d_cols4, uint32_t log_size, uint32_t* d_scratch, uint32_t* h_claimed_sum,
+void logup_finalize_last(uint32_t* const* d_cols4, uint32_t log_size, uint32_t* d_scratch, uint32_t* d_claimed_sum,
                          hipStream_t st);
 void launch_preproc(int pp_id, uint32_t log_size, uint32_t* d_col, hipStream_t st);
 void add_columns(uint32_t* const* d_dst, const uint32_t* const* d_src, uint32_t ncols, uint32_t n, hipStream_t st);

@@ -71,7 +71,10 @@ int32_t cm_init(int32_t device) {
 int32_t cm_shutdown(void) {
   return guard([&] {
     std::lock_guard<std::mutex> lk(g_init_mu);
-    if (g_inited) CM_HIP(hipDeviceSynchronize());
+    if (g_inited) {
+      CM_HIP(hipDeviceSynchronize());
+      pool_trim();
+    }
     g_inited = false;
   });
 }

@@ -35,11 +35,28 @@ void eval_at_point_batch(const uint32_t* const* d_coeffs, uint32_t ncols, uint32
 // Merkle
 void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
                   uint32_t* d_out, hipStream_t st);
+// layers 2^top_log .. 2^0 in one launch (top_log <= 10)
+constexpr uint32_t MERKLE_TAIL_LOG = 7;
+struct MerkleTailArgs {
+  uint32_t top_log;
+  const uint32_t* prev;                       // hashes of layer top_log + 1, or null
+  const uint32_t* const* cols;                // device array of all (sorted) column pointers of the tree
+  uint32_t col_begin[MERKLE_TAIL_LOG + 1];    // column range of layer l in `cols`
+  uint32_t col_end[MERKLE_TAIL_LOG + 1];
+  uint32_t* layers[MERKLE_TAIL_LOG + 1];      // output buffer of layer l
+};
+void merkle_tail(const MerkleTailArgs& a, hipStream_t st);
 uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st);
 void gather_hashes(const uint32_t* const* d_layers, const uint32_t* d_layer_idx, const uint32_t* d_node_idx, uint32_t n,
                    uint32_t* d_out, hipStream_t st);
 void gather_values(const uint32_t* const* d_cols, const uint32_t* d_col_idx, const uint32_t* d_row_idx, uint32_t n,
                    uint32_t* d_out, hipStream_t st);
+
+// pool.cpp-style services implemented in pool.hip
+void* pool_get(size_t bytes);
+void pool_put(void* p);
+void pool_trim();
+void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st);
 
 // simple RAII device buffer
 struct DevBuf {
@@ -55,25 +72,29 @@ struct DevBuf {
     return *this;
   }
   ~DevBuf() { release(); }
+  // Buffers come from a caching pool (pool.hpp): after the first proof no hipMalloc/hipFree (and none of
+  // hipFree's implicit device syncs) happen on the hot path.  Reuse is stream-ordered: the prover runs on
+  // one stream, and the per-op C-ABI wrappers synchronise before their temporaries are released.
   void alloc(size_t b) {
     release();
     if (b == 0) b = 4;
-    CM_HIP(hipMalloc(&p, b));
+    p = pool_get(b);
     bytes = b;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) pool_put(p);
     p = nullptr;
     bytes = 0;
   }
   uint32_t* u32() const { return (uint32_t*)p; }
   template <class T> T* as() const { return (T*)p; }
 };
+// Small host->device uploads (pointer arrays, coefficients, positions) go through a pinned staging ring
+// and hipMemcpyAsync on the launch stream: no host sync, no pageable-copy stall.
 template <class T>
 inline DevBuf upload(const std::vector<T>& v, hipStream_t st) {
   DevBuf b(v.size() * sizeof(T));
-  (void)st;
-  if (!v.empty()) CM_HIP(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (!v.empty()) stage_upload(b.p, v.data(), v.size() * sizeof(T), st);
   return b;
 }
 

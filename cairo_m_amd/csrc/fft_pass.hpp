@@ -1,0 +1,28 @@
+// Shared argument block of the circle-FFT butterfly passes.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+namespace cm {
+
+// One launch applies butterfly layers [lo, hi) of a size-2^n transform to every column of a batch.
+// Tile = 2^W values of index bits [lo,hi)  x  2^M consecutive low indices (M = 0 when lo == 0), W + M <= 11.
+// INVERSE: ibutterfly (a+b, (a-b)*itw), layers ascending.  Forward: (a+b*tw, a-b*tw), descending.
+// in_len: logical input length; reads at index >= in_len return 0 (zero-extension => LDE).
+struct FftPassArgs {
+  const uint32_t* const* src;
+  uint32_t* const* dst;
+  const uint32_t* xtw;  // (i)xtw table
+  const uint32_t* ytw;  // (i)ytw table
+  uint32_t R;           // root log of the twiddle tables
+  uint32_t n;           // transform log size
+  uint32_t lo, hi;      // layer range
+  uint32_t M;           // log of contiguous low run per tile
+  uint32_t in_len;      // logical input length per column
+  uint32_t scale;       // multiply outputs by this (1 = none); used for 1/N on the last inverse pass
+};
+
+// register-blocked radix-8 pass (kernels_fft.hip); requires W + M == 11 exactly
+void launch_fft_pass_r8(bool inverse, const FftPassArgs& a, uint32_t ntiles, uint32_t ncols, hipStream_t st);
+
+}  // namespace cm

@@ -34,12 +34,14 @@ __device__ __forceinline__ EmptyEF operator*(EmptyEF, M31) { return {}; }
 __device__ __forceinline__ EmptyEF operator+(EmptyEF, EmptyEF) { return {}; }
 
 struct HistPtrs { uint32_t *rc8, *rc16, *rc20, *bitwise; uint32_t* error_flag; };
+constexpr uint32_t HIST_SMALL = 2048;  // per-block LDS bins for the small range-check values
 
 struct HistEval : air::LogupStream<HistEval, M31, EmptyEF> {
   const uint32_t* const* cols;
   uint32_t row;
   int ci = 0;
   HistPtrs h;
+  uint32_t* lds;  // [rc20: HIST_SMALL][rc16: HIST_SMALL][rc8: 256] block-private bins
   __device__ M31 next() { return M31(cols[ci++][row]); }
   __device__ M31 preproc(int) { return M31(); }
   __device__ M31 c(uint32_t v) { return M31(v); }
@@ -67,9 +69,11 @@ struct HistEval : air::LogupStream<HistEval, M31, EmptyEF> {
     if (pending) atomicAdd(t + idx, 1u);
   }
   __device__ void on_entry(int rel, M31, const M31* v, int) {
-    if (rel == air::REL_RC8) bump(h.rc8, v[0].v, 1u << 8);
-    else if (rel == air::REL_RC16) bump(h.rc16, v[0].v, 1u << 16);
-    else if (rel == air::REL_RC20) bump(h.rc20, v[0].v, 1u << 20);
+    // small values (clock deltas, limbs of small numbers) are counted in block-private LDS bins and
+    // flushed once per block; the rest goes to HBM with wave-aggregated atomics
+    if (rel == air::REL_RC8) { if (v[0].v < 256u) atomicAdd(lds + 2 * HIST_SMALL + v[0].v, 1u); else atomicOr(h.error_flag, 1u); }
+    else if (rel == air::REL_RC16) { if (v[0].v < HIST_SMALL) atomicAdd(lds + HIST_SMALL + v[0].v, 1u); else bump(h.rc16, v[0].v, 1u << 16); }
+    else if (rel == air::REL_RC20) { if (v[0].v < HIST_SMALL) atomicAdd(lds + v[0].v, 1u); else bump(h.rc20, v[0].v, 1u << 20); }
     else if (rel == air::REL_BITWISE) {
       uint32_t ok = (v[0].v < 3u) & (v[1].v < 256u) & (v[2].v < 256u);
       bump(h.bitwise, ok ? v[0].v * 65536u + (v[1].v << 8) + v[2].v : 0xffffffffu, 1u << 18);

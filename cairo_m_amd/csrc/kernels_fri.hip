@@ -21,28 +21,48 @@ __device__ __forceinline__ void domain_point_at_row(const TwiddleView& tw, uint3
   x = (h & 1u) ? -xx : xx;
 }
 
+// Threads are arranged as (rows_per_block = 256 / S) x S column slices: every slice sums its share of the
+// per-column terms, slices are reduced through LDS, slice 0 finishes the row.  S = 1 for large domains; small
+// domains (idle components: 2^5 rows but ~10^3 columns) use S up to 64 so the launch is not one serial loop.
+template <int S>
 __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
-  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= (1u << a.log_size)) return;
+  constexpr int ROWS = 256 / S;
+  __shared__ uint32_t red[S > 1 ? 256 * 4 : 4];
+  const uint32_t slice = threadIdx.x / ROWS, rl = threadIdx.x % ROWS;
+  const uint32_t row = blockIdx.x * ROWS + rl;
+  const bool live = row < (1u << a.log_size);
   M31 px, py;
-  domain_point_at_row(a.tw, a.log_size, row, px, py);
+  if (live) domain_point_at_row(a.tw, a.log_size, row, px, py);
   QM31 acc;
   for (uint32_t b = 0; b < a.n_batches; b++) {
     const QuotientBatch& qb = a.batches[b];
     QM31 num;
-    for (uint32_t k = qb.begin; k < qb.end; k++) {
-      M31 v(a.cols[a.col_index[k]][row]);
-      num += QM31::from_u32(a.coef_c + 4 * k) * v;
+    if (live)
+      for (uint32_t k = qb.begin + slice; k < qb.end; k += S) {
+        M31 v(a.cols[a.col_index[k]][row]);
+        num += QM31::from_u32(a.coef_c + 4 * k) * v;
+      }
+    if (S > 1) {
+      __syncthreads();
+      num.to_u32(red + 4 * threadIdx.x);
+      __syncthreads();
+      if (slice == 0) {
+        for (int s2 = 1; s2 < S; s2++) num += QM31::from_u32(red + 4 * (s2 * ROWS + rl));
+      }
     }
-    // sum_k (a_k * y + b_k) = A*y + B (A, B summed on the host; field arithmetic is exact)
-    num = num - (QM31::from_u32(qb.sum_a) * py + QM31::from_u32(qb.sum_b));
-    // denominator (Pr.x - p.x) * Pi.y - (Pr.y - p.y) * Pi.x in CM31
-    CM31 prx(M31(qb.point[0]), M31(qb.point[1])), pix(M31(qb.point[2]), M31(qb.point[3]));
-    CM31 pry(M31(qb.point[4]), M31(qb.point[5])), piy(M31(qb.point[6]), M31(qb.point[7]));
-    CM31 den = (prx - CM31(px)) * piy - (pry - CM31(py)) * pix;
-    acc = acc * QM31::from_u32(qb.batch_coeff) + mul_cm31(num, inv(den));
+    if (slice == 0 && live) {
+      // sum_k (a_k * y + b_k) = A*y + B (A, B summed on the host; field arithmetic is exact)
+      num = num - (QM31::from_u32(qb.sum_a) * py + QM31::from_u32(qb.sum_b));
+      // denominator (Pr.x - p.x) * Pi.y - (Pr.y - p.y) * Pi.x in CM31
+      CM31 prx(M31(qb.point[0]), M31(qb.point[1])), pix(M31(qb.point[2]), M31(qb.point[3]));
+      CM31 pry(M31(qb.point[4]), M31(qb.point[5])), piy(M31(qb.point[6]), M31(qb.point[7]));
+      CM31 den = (prx - CM31(px)) * piy - (pry - CM31(py)) * pix;
+      acc = acc * QM31::from_u32(qb.batch_coeff) + mul_cm31(num, inv(den));
+    }
   }
-  a.out[0][row] = acc.a.a.v; a.out[1][row] = acc.a.b.v; a.out[2][row] = acc.b.a.v; a.out[3][row] = acc.b.b.v;
+  if (slice == 0 && live) {
+    a.out[0][row] = acc.a.a.v; a.out[1][row] = acc.a.b.v; a.out[2][row] = acc.b.a.v; a.out[3][row] = acc.b.b.v;
+  }
 }
 
 __device__ __forceinline__ QM31 ld4(const uint32_t* const* c, uint32_t i) {
@@ -83,7 +103,9 @@ __global__ void __launch_bounds__(256) k_fold_line(Ptr4 out, CPtr4 src, uint32_t
 void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st) {
   uint32_t n = 1u << a.log_size;
   KProfScope kp("k_quotients", (4.0 * n_cols + 16.0) * (double)n, st);
-  hipLaunchKernelGGL(k_quotients, dim3((n + 255) / 256), dim3(256), 0, st, a);
+  if (a.log_size >= 14) hipLaunchKernelGGL(k_quotients<1>, dim3((n + 255) / 256), dim3(256), 0, st, a);
+  else if (a.log_size >= 10) hipLaunchKernelGGL(k_quotients<8>, dim3((n + 31) / 32), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_quotients<64>, dim3((n + 3) / 4), dim3(256), 0, st, a);
   CM_HIP(hipGetLastError());
 }
 void fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw,

@@ -82,6 +82,44 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
   o[1] = make_uint4(h[4], h[5], h[6], h[7]);
 }
 
+// All layers 2^top_log .. 2^0 of a tree in ONE launch (one 1024-thread block): the small layers are pure
+// launch/dependency latency as separate kernels (26 trees x 10 layers per proof).  Hashes of the layer being
+// consumed stay in LDS; every layer is still written to HBM for the decommitment gathers.
+__global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
+  __shared__ uint32_t bufA[1024 * 8];
+  __shared__ uint32_t bufB[512 * 8];
+  uint32_t* buf[2];  // layer top -> A (<= 1024 nodes), top-1 -> B (<= 512), top-2 -> A, ...
+  buf[0] = bufA;
+  buf[1] = bufB;
+  const uint32_t tid = threadIdx.x;
+  int cur = 0;
+  for (int l = (int)a.top_log; l >= 0; l--) {
+    const uint32_t n = 1u << l;
+    if (tid < n) {
+      uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t m[16];
+      const bool from_global = (l == (int)a.top_log);
+      if (!from_global || a.prev) {
+        const uint32_t* p = from_global ? a.prev + (size_t)tid * 16 : buf[cur ^ 1] + tid * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = p[k];
+        b2s_compress(h, m);
+      }
+      const uint32_t c_begin = a.col_begin[l], c_end = a.col_end[l];
+      for (uint32_t c0 = c_begin; c0 < c_end; c0 += 16) {
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? a.cols[c0 + k][tid] : 0u;
+        b2s_compress(h, m);
+      }
+      uint32_t* o = a.layers[l] + (size_t)tid * 8;
+#pragma unroll
+      for (int k = 0; k < 8; k++) { o[k] = h[k]; buf[cur][tid * 8 + k] = h[k]; }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 // Proof of work: smallest nonce in [base, base + n) with trailing_zeros(F(digest, [lo,hi,0..])[0..16B]) >= bits.
 // result initialised to ~0ull; atomicMin keeps the smallest hit.
 __global__ void __launch_bounds__(256) k_grind(const uint32_t* __restrict__ digest, uint32_t bits, uint64_t base,
@@ -127,6 +165,11 @@ void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* con
   // algorithmic bytes: column values once + 64 B of child hashes in, 32 B out per node
   KProfScope kp("k_merkle_layer", (4.0 * ncols + (d_prev ? 64.0 : 0.0) + 32.0) * (double)n, st);
   hipLaunchKernelGGL(k_merkle_layer, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
+  CM_HIP(hipGetLastError());
+}
+void merkle_tail(const MerkleTailArgs& a, hipStream_t st) {
+  KProfScope kp("k_merkle_tail", 0.0, st);
+  hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(1024), 0, st, a);
   CM_HIP(hipGetLastError());
 }
 uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st) {

@@ -12,6 +12,7 @@
 #include "device_common.hpp"
 #include "engine.hpp"
 #include "kprof.hpp"
+#include "fft_pass.hpp"
 
 namespace cm {
 
@@ -58,19 +59,8 @@ __global__ void k_twiddles_y(uint32_t* ytw, uint32_t* iytw, uint32_t R) {
 // Tile = 2^W values of index bits [lo,hi)  x  2^M consecutive low indices (M = 0 when lo == 0).
 // INVERSE: ibutterfly (a+b, (a-b)*itw), layers ascending.  Forward: (a+b*tw, a-b*tw), descending.
 // in_len: logical input length; reads at index >= in_len return 0 (zero-extension => LDE).
-struct FftPassArgs {
-  const uint32_t* const* src;
-  uint32_t* const* dst;
-  const uint32_t* xtw;  // (i)xtw table
-  const uint32_t* ytw;  // (i)ytw table
-  uint32_t R;           // root log of the twiddle tables
-  uint32_t n;           // transform log size
-  uint32_t lo, hi;      // layer range
-  uint32_t M;           // log of contiguous low run per tile
-  uint32_t in_len;      // logical input length per column
-  uint32_t scale;       // multiply outputs by this (1 = none); used for 1/N on the last inverse pass
-};
-
+// (FftPassArgs lives in fft_pass.hpp; this generic LDS-sweep kernel serves tiles smaller than 2^11,
+// the register-blocked radix-8 kernel in kernels_fft.hip serves full 2^11 tiles.)
 template <bool INVERSE>
 __global__ void __launch_bounds__(256) k_fft_pass(FftPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
@@ -249,7 +239,8 @@ static void launch_pass(const uint32_t* const* d_src, uint32_t* const* d_dst, ui
   // algorithmic bytes of one pass: every element written once; read once unless it is implicit zero padding
   KProfScope kp(INV ? "k_fft_pass<ifft>" : "k_fft_pass<fft>",
                 4.0 * ncols * ((double)(1u << n) + (double)(in_len < (1u << n) ? in_len : (1u << n))), st);
-  hipLaunchKernelGGL(k_fft_pass<INV>, dim3(ntiles, ncols), dim3(256), lds, st, a);
+  if (tile_log == FFT_TILE_LOG) launch_fft_pass_r8(INV, a, ntiles, ncols, st);
+  else hipLaunchKernelGGL(k_fft_pass<INV>, dim3(ntiles, ncols), dim3(256), lds, st, a);
 }
 void interpolate_oop(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n, const Twiddles& tw,
                      hipStream_t st) {

@@ -40,12 +40,28 @@ struct MerkleTree {
     layers.resize(max_log + 1);
     d_cols = upload(cols, st);
     size_t ci = 0;
-    for (int log = (int)max_log; log >= 0; log--) {
+    const int tail_top = (int)std::min<uint32_t>(max_log, MERKLE_TAIL_LOG);
+    for (int log = (int)max_log; log > tail_top; log--) {
       size_t c0 = ci;
       while (ci < cols.size() && col_logs[ci] == (uint32_t)log) ci++;
       layers[log].alloc((size_t)32 << log);
       const uint32_t* prev = (log < (int)max_log) ? layers[log + 1].u32() : nullptr;
       merkle_layer((uint32_t)log, prev, d_cols.as<const uint32_t*>() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
+    }
+    {
+      // layers 2^tail_top .. 2^0: one fused launch
+      MerkleTailArgs a;
+      a.top_log = (uint32_t)tail_top;
+      a.prev = (tail_top < (int)max_log) ? layers[tail_top + 1].u32() : nullptr;
+      a.cols = d_cols.as<const uint32_t*>();
+      for (int log = tail_top; log >= 0; log--) {
+        a.col_begin[log] = (uint32_t)ci;
+        while (ci < cols.size() && col_logs[ci] == (uint32_t)log) ci++;
+        a.col_end[log] = (uint32_t)ci;
+        layers[log].alloc((size_t)32 << log);
+        a.layers[log] = layers[log].u32();
+      }
+      merkle_tail(a, st);
     }
     std::vector<const uint32_t*> lp(layers.size());
     for (size_t i = 0; i < layers.size(); i++) lp[i] = layers[i].u32();

@@ -14,6 +14,7 @@
 #include "kprof.hpp"
 #include <chrono>
 #include <memory>
+#include <mutex>
 #include <map>
 #include <set>
 #include <algorithm>
@@ -145,10 +146,8 @@ struct Prover {
         DevBuf dsrc = upload(src, st);
         interpolate_oop(dsrc.as<const uint32_t*>(), dco.as<uint32_t*>(), (uint32_t)co.size(), kv.first, *tw, st);
         evaluate(dco.as<const uint32_t*>(), dld.as<uint32_t*>(), (uint32_t)co.size(), kv.first, kv.first + cfg.log_blowup_factor, *tw, st);
-        CM_HIP(hipStreamSynchronize(st));  // pointer arrays are freed at scope exit
       } else {
         evaluate(dco.as<const uint32_t*>(), dld.as<uint32_t*>(), (uint32_t)co.size(), kv.first, kv.first + cfg.log_blowup_factor, *tw, st);
-        CM_HIP(hipStreamSynchronize(st));
       }
     }
     std::vector<const uint32_t*> cols(t.lde.ptrs.begin(), t.lde.ptrs.end());
@@ -157,6 +156,18 @@ struct Prover {
     ch.mix_root(t.root);
   }
 };
+
+// Twiddle tables depend only on the domain size: built once per size and kept (like the code objects).
+static Twiddles* cached_twiddles(uint32_t R, hipStream_t st) {
+  static std::mutex mu;
+  static std::map<uint32_t, Twiddles*> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(R);
+  if (it != cache.end()) return it->second;
+  Twiddles* t = twiddles_create(R, st);
+  cache[R] = t;
+  return t;
+}
 
 // ---- host point evaluator (stwo FrameworkComponent::evaluate_constraint_quotients_at_point) ------------
 struct HostRelations {
@@ -294,8 +305,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   for (int c = 0; c < air::N_COMPONENTS; c++) max_log = std::max(max_log, clog[c]);
   for (int c = 0; c < air::N_COMPONENTS; c++) CM_CHECK(clog[c] <= 26, "component too large");
   const uint32_t comp_log = max_log + 1;
-  P.tw = twiddles_create(comp_log + cfg.log_blowup_factor, st);
-  std::unique_ptr<Twiddles, void (*)(Twiddles*)> tw_guard(P.tw, twiddles_destroy);
+  P.tw = cached_twiddles(comp_log + cfg.log_blowup_factor, st);
 
   // ---- transcript setup (prover.rs:33-36, 62-66) ----
   ch.mix_u64(cfg.pow_bits);
@@ -401,14 +411,17 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   }
   {
     DevBuf scratch(logup_finalize_scratch_words(max_log) * 4);
+    DevBuf d_sums(air::N_COMPONENTS * 16);
     for (int c = 0; c < air::N_COMPONENTS; c++) {
       const air::ComponentInfo& info = air::component_info(c);
       launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
                    drel.as<DevRelations>(), it_evals.dev(it0[c]), st);
-      uint32_t cs[4];
-      logup_finalize_last(it_evals.dev(it0[c] + info.n_interaction - 4), clog[c], scratch.u32(), cs, st);
-      pf.claimed_sums.push_back(QM31::from_u32(cs));
+      logup_finalize_last(it_evals.dev(it0[c] + info.n_interaction - 4), clog[c], scratch.u32(), d_sums.u32() + 4 * c, st);
     }
+    uint32_t sums[air::N_COMPONENTS * 4];
+    CM_HIP(hipMemcpyAsync(sums, d_sums.p, sizeof(sums), hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    for (int c = 0; c < air::N_COMPONENTS; c++) pf.claimed_sums.push_back(QM31::from_u32(sums + 4 * c));
   }
   for (auto& cs : pf.claimed_sums) ch.mix_felts(&cs, 1);
   P.tick("interaction_gen");
@@ -421,7 +434,6 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       for (auto i : kv.second) co.push_back(t.coeffs.ptrs[i]);
       DevBuf dco = upload(co, st);
       interpolate(dco.as<uint32_t*>(), (uint32_t)co.size(), kv.first, *P.tw, st);
-      CM_HIP(hipStreamSynchronize(st));
     }
     P.commit(t, nullptr, true);
   }
@@ -482,7 +494,6 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
         ext.alloc(std::vector<uint32_t>(4, kv.first), st);
         evaluate((const uint32_t* const*)cur->dev(), ext.dev(), 4, cur_log, kv.first, *P.tw, st);
         add_columns(vals.dev(), (const uint32_t* const*)ext.dev(), 4, 1u << kv.first, st);
-        CM_HIP(hipStreamSynchronize(st));
       }
       interpolate(vals.dev(), 4, kv.first, *P.tw, st);
       cur = &vals;
@@ -631,7 +642,6 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     a.tw = view(*P.tw); a.log_size = l; a.cols = dcols.as<const uint32_t*>(); a.col_index = dci.u32(); a.coef_c = dcc.u32();
     a.batches = dqb.as<QuotientBatch>(); a.n_batches = (uint32_t)qb.size(); a.out = q.dev();
     launch_quotients(a, (double)cols.size(), st);
-    CM_HIP(hipStreamSynchronize(st));
     q_logs.push_back(l);
     quotients.push_back(std::move(q));
   }
