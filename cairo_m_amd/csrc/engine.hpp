@@ -47,10 +47,8 @@ struct MerkleTailArgs {
 };
 void merkle_tail(const MerkleTailArgs& a, hipStream_t st);
 uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st);
-void gather_hashes(const uint32_t* const* d_layers, const uint32_t* d_layer_idx, const uint32_t* d_node_idx, uint32_t n,
-                   uint32_t* d_out, hipStream_t st);
-void gather_values(const uint32_t* const* d_cols, const uint32_t* d_col_idx, const uint32_t* d_row_idx, uint32_t n,
-                   uint32_t* d_out, hipStream_t st);
+// out[q * width + w] = addrs[q][w]  (decommitment gathers: width 1 = values, 8 = hashes)
+void gather_words(const uint32_t* const* d_addrs, uint32_t n, uint32_t width, uint32_t* d_out, hipStream_t st);
 
 // pool.cpp-style services implemented in pool.hip
 void* pool_get(size_t bytes);

@@ -23,6 +23,7 @@ struct FftPassArgs {
 };
 
 // register-blocked radix-8 pass (kernels_fft.hip); requires W + M == 11 exactly
+bool fft_pass_r8_supported(uint32_t W, uint32_t M, uint32_t lo);
 void launch_fft_pass_r8(bool inverse, const FftPassArgs& a, uint32_t ntiles, uint32_t ncols, hipStream_t st);
 
 }  // namespace cm

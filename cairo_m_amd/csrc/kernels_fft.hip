@@ -2,9 +2,12 @@
 //
 // A block of 256 threads owns a 2^11-element tile; every thread keeps 8 elements in registers and applies
 // up to 3 butterfly layers (radix-8) before the tile is re-distributed through LDS, so an 11-layer pass
-// costs 3 LDS exchanges instead of 11 read-modify-write sweeps (the first and last rounds go straight
-// from/to HBM).  Global accesses: contiguous pass = 32 B per lane (8 consecutive words) on one side and
-// coalesced dwords on the other; strided passes move 2^M-word runs (M >= 4 => full 64-B segments).
+// costs 3 LDS exchanges instead of 11 read-modify-write sweeps.  The kernel is specialised on the number of
+// layers W of the pass (tile = 2^W strided values x 2^M contiguous words, M = 11 - W; W = 11 is the
+// contiguous pass) so that every index computation constant-folds and the round loop is fully unrolled —
+// the pass is ALU-bound on M31 butterflies, not HBM-bound, so instruction count is what matters.
+// Global accesses: the contiguous pass stages its HBM side through LDS with 16-byte-per-lane accesses;
+// strided passes move 2^M-word runs (M >= 4 => full 64-B segments) with coalesced dwords.
 // Replaces the butterfly loops of Stwo's SimdBackend `ifft`/`rfft` (reached from
 // tree_builder.extend_evals / commit, crates/prover/src/prover.rs:71-73, 80-82, 100-102).
 #include "field.hpp"
@@ -15,40 +18,22 @@ namespace cm {
 
 constexpr uint32_t TILE_LOG = 11;
 // LDS padding: one extra word every 32 to break the power-of-two strides of the exchanges
-__device__ __forceinline__ uint32_t phys(uint32_t i) { return i + (i >> 5); }
+__device__ __forceinline__ constexpr uint32_t phys(uint32_t i) { return i + (i >> 5); }
 
+template <int W>
+struct PassGeom {
+  static constexpr uint32_t M = (W == 11) ? 0u : (uint32_t)(TILE_LOG - W);
+  static constexpr uint32_t NR = (W + 2) / 3;
+  // round r works on local bits [b, b + k)
+  static __device__ __forceinline__ constexpr uint32_t b(uint32_t r) { return M + 3 * r; }
+  static __device__ __forceinline__ constexpr uint32_t k(uint32_t r) { return (W - 3 * r) < 3 ? (W - 3 * r) : 3; }
+};
 
-__device__ __forceinline__ uint32_t tile_gidx(const FftPassArgs& a, uint32_t base, uint32_t li) {
-  return base | ((li >> a.M) << a.lo) | (li & ((1u << a.M) - 1));
-}
-template <bool INVERSE, int K>
-__device__ __forceinline__ void butterflies(M31 (&v)[8], const uint32_t (&li)[8], const FftPassArgs& a, uint32_t b, uint32_t base) {
-#pragma unroll
-  for (int ss = 0; ss < K; ss++) {
-    const int s = INVERSE ? ss : (K - 1 - ss);
-    const uint32_t layer = a.lo + (b - a.M) + s;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      if ((e >> s) & 1) continue;
-      const int e1 = e | (1 << s);
-      uint32_t h = tile_gidx(a, base, li[e]) >> (layer + 1);
-      uint32_t tw;
-      if (layer == 0) tw = a.ytw[(1u << (a.n - 1)) + h];
-      else {
-        uint32_t L = a.R - a.n + layer - 1;
-        tw = a.xtw[(1u << (a.R - 1)) - (1u << (a.R - 1 - L)) + h];
-      }
-      M31 x = v[e], y = v[e1], w(tw);
-      if (INVERSE) { v[e] = x + y; v[e1] = (x - y) * w; }
-      else { M31 yt = y * w; v[e] = x + yt; v[e1] = x - yt; }
-    }
-  }
-}
-
-template <bool INVERSE>
+template <bool INVERSE, int W>
 __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
+  using G = PassGeom<W>;
+  constexpr uint32_t M = G::M;
   __shared__ uint32_t tile[(1u << TILE_LOG) + (1u << (TILE_LOG - 5))];
-  const uint32_t W = a.hi - a.lo, M = a.M;
   const uint32_t* __restrict__ src = a.src[blockIdx.y];
   uint32_t* __restrict__ dst = a.dst[blockIdx.y];
   const uint32_t low_fixed_bits = a.lo - M;
@@ -56,33 +41,31 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
   const uint32_t high = blockIdx.x >> low_fixed_bits;
   const uint32_t base = (high << a.hi) | (lowf << M);
   const uint32_t t = threadIdx.x;
-  // local index (11 bits) -> global index
-  auto gidx = [&](uint32_t li) { return base | ((li >> M) << a.lo) | (li & ((1u << M) - 1)); };
-  // rounds over the active local bits [M, 11): chunks of 3 (last chunk may be 1 or 2)
-  const uint32_t nrounds = (W + 2) / 3;
+  const uint32_t lo = a.lo;
+  auto gidx = [&](uint32_t li) -> uint32_t { return base | ((li >> M) << lo) | (li & ((1u << M) - 1)); };
   M31 v[8];
-  for (uint32_t rr = 0; rr < nrounds; rr++) {
-    const uint32_t r = INVERSE ? rr : (nrounds - 1 - rr);
-    const uint32_t b = M + 3 * r;                       // first local bit of the round
-    const uint32_t k = (W - 3 * r) < 3 ? (W - 3 * r) : 3;  // layers in this round
+#pragma unroll
+  for (uint32_t rr = 0; rr < G::NR; rr++) {
+    const uint32_t r = INVERSE ? rr : (G::NR - 1 - rr);
+    const uint32_t b = G::b(r), k = G::k(r);
     // element e of thread t: j = e & (2^k-1) inside the butterfly group, g = e >> k selects the group
     uint32_t li[8];
 #pragma unroll
     for (uint32_t e = 0; e < 8; e++) {
-      uint32_t j = e & ((1u << k) - 1), g = e >> k;
-      uint32_t rho = (t << (3 - k)) | g;               // the 11-k remaining bits
+      const uint32_t j = e & ((1u << k) - 1), g = e >> k;
+      const uint32_t rho = (t << (3 - k)) | g;  // the 11-k remaining bits
       li[e] = ((rho >> b) << (b + k)) | (j << b) | (rho & ((1u << b) - 1));
     }
-    if (rr == 0 && !(INVERSE && M == 0)) {
+    const bool staged_in = (rr == 0) && INVERSE && M == 0;
+    if (rr == 0 && !staged_in) {
 #pragma unroll
       for (uint32_t e = 0; e < 8; e++) {
         uint32_t gi = gidx(li[e]);
         v[e] = M31(gi < a.in_len ? src[gi] : 0u);
       }
     } else {
-      if (rr == 0) {
-        // contiguous tile, first round works on index bits 0..2: a direct load would be 8 dwords per lane at a
-        // 32-byte lane stride.  Stage the tile through LDS with fully coalesced 16-byte loads instead.
+      if (staged_in) {
+        // contiguous tile, first round works on index bits 0..2: stage through LDS with coalesced 16-byte loads
 #pragma unroll
         for (uint32_t it = 0; it < 2; it++) {
           uint32_t w0 = (it * 256 + t) * 4;
@@ -95,42 +78,80 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
 #pragma unroll
       for (uint32_t e = 0; e < 8; e++) v[e] = M31(tile[phys(li[e])]);
     }
-    // butterflies (compile-time layer count so that v[] stays in registers)
-    if (k == 3) butterflies<INVERSE, 3>(v, li, a, b, base);
-    else if (k == 2) butterflies<INVERSE, 2>(v, li, a, b, base);
-    else butterflies<INVERSE, 1>(v, li, a, b, base);
-    if (rr + 1 == nrounds && !(!INVERSE && M == 0)) {
+    // butterflies: k layers on bits [b, b+k).  h(e) = h0 + (j >> (s+1)) with h0 from the j = 0 element of the group
+#pragma unroll
+    for (uint32_t ss = 0; ss < k; ss++) {
+      const uint32_t s = INVERSE ? ss : (k - 1 - ss);
+      const uint32_t layer = lo + (b - M) + s;
+      const uint32_t* __restrict__ twp;
+      if (W == 11 && b + s == 0) twp = a.ytw + (1u << (a.n - 1));
+      else {
+        const uint32_t L = a.R - a.n + layer - 1;
+        twp = a.xtw + ((1u << (a.R - 1)) - (1u << (a.R - 1 - L)));
+      }
+#pragma unroll
+      for (uint32_t e = 0; e < 8; e++) {
+        if ((e >> s) & 1u) continue;
+        const uint32_t e1 = e | (1u << s);
+        const uint32_t g0 = e & ~((1u << k) - 1);  // j = 0 element of this group
+        const uint32_t j = e & ((1u << k) - 1);
+        const uint32_t h = (gidx(li[g0]) >> (layer + 1)) + (j >> (s + 1));
+        M31 w(twp[h]);
+        M31 x = v[e], y = v[e1];
+        if (INVERSE) { v[e] = x + y; v[e1] = (x - y) * w; }
+        else { M31 yt = y * w; v[e] = x + yt; v[e1] = x - yt; }
+      }
+    }
+    const bool staged_out = (rr + 1 == G::NR) && !INVERSE && M == 0;
+    if (rr + 1 == G::NR && !staged_out) {
       const M31 sc(a.scale);
 #pragma unroll
       for (uint32_t e = 0; e < 8; e++) {
         M31 o = v[e];
-        if (a.scale != 1u) o = o * sc;
+        if (INVERSE && a.scale != 1u) o = o * sc;
         dst[gidx(li[e])] = o.v;
-      }
-    } else if (rr + 1 == nrounds) {
-      // forward transform, last round holds 8 consecutive words per lane: stage through LDS, store 16 B per lane
-      __syncthreads();
-#pragma unroll
-      for (uint32_t e = 0; e < 8; e++) tile[phys(li[e])] = v[e].v;
-      __syncthreads();
-#pragma unroll
-      for (uint32_t it = 0; it < 2; it++) {
-        uint32_t w0 = (it * 256 + t) * 4;
-        uint4 q = make_uint4(tile[phys(w0)], tile[phys(w0 + 1)], tile[phys(w0 + 2)], tile[phys(w0 + 3)]);
-        *reinterpret_cast<uint4*>(dst + base + w0) = q;
       }
     } else {
       __syncthreads();  // previous round's readers are done with the tile
 #pragma unroll
       for (uint32_t e = 0; e < 8; e++) tile[phys(li[e])] = v[e].v;
       __syncthreads();
+      if (staged_out) {
+        // forward transform, last round holds 8 consecutive words per lane: store 16 B per lane from LDS
+#pragma unroll
+        for (uint32_t it = 0; it < 2; it++) {
+          uint32_t w0 = (it * 256 + t) * 4;
+          uint4 q = make_uint4(tile[phys(w0)], tile[phys(w0 + 1)], tile[phys(w0 + 2)], tile[phys(w0 + 3)]);
+          *reinterpret_cast<uint4*>(dst + base + w0) = q;
+        }
+      }
     }
   }
 }
 
+template <bool INV>
+static void launch_w(const FftPassArgs& a, uint32_t ntiles, uint32_t ncols, hipStream_t st) {
+  const uint32_t W = a.hi - a.lo;
+  dim3 grid(ntiles, ncols), block(256);
+  switch (W) {
+    case 1: hipLaunchKernelGGL((k_fft_pass_r8<INV, 1>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_fft_pass_r8<INV, 2>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_fft_pass_r8<INV, 3>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_fft_pass_r8<INV, 4>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((k_fft_pass_r8<INV, 5>), grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((k_fft_pass_r8<INV, 6>), grid, block, 0, st, a); break;
+    case 7: hipLaunchKernelGGL((k_fft_pass_r8<INV, 7>), grid, block, 0, st, a); break;
+    case 11: hipLaunchKernelGGL((k_fft_pass_r8<INV, 11>), grid, block, 0, st, a); break;
+    default: break;
+  }
+}
+bool fft_pass_r8_supported(uint32_t W, uint32_t M, uint32_t lo) {
+  if (W == 11) return lo == 0 && M == 0;
+  return W >= 1 && W <= 7 && M == TILE_LOG - W && lo >= M;
+}
 void launch_fft_pass_r8(bool inverse, const FftPassArgs& a, uint32_t ntiles, uint32_t ncols, hipStream_t st) {
-  if (inverse) hipLaunchKernelGGL(k_fft_pass_r8<true>, dim3(ntiles, ncols), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_fft_pass_r8<false>, dim3(ntiles, ncols), dim3(256), 0, st, a);
+  if (inverse) launch_w<true>(a, ntiles, ncols, st);
+  else launch_w<false>(a, ntiles, ncols, st);
 }
 
 }  // namespace cm

@@ -142,19 +142,12 @@ __global__ void __launch_bounds__(256) k_grind(const uint32_t* __restrict__ dige
   if (tz >= bits) atomicMin(result, (unsigned long long)nonce);
 }
 
-// Gather 32-byte hashes / single u32 values at arbitrary positions (decommitment).
-__global__ void k_gather_hashes(const uint32_t* const* layers, const uint32_t* layer_idx, const uint32_t* node_idx,
-                                uint32_t n, uint32_t* out) {
+// Decommitment gather: out[q * width + w] = addrs[q][w]  (width 1 = column values, 8 = 32-byte hashes).
+__global__ void k_gather_words(const uint32_t* const* addrs, uint32_t n, uint32_t width, uint32_t* out) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * 8) return;
-  uint32_t q = t >> 3, w = t & 7;
-  out[t] = layers[layer_idx[q]][(size_t)node_idx[q] * 8 + w];
-}
-__global__ void k_gather_values(const uint32_t* const* cols, const uint32_t* col_idx, const uint32_t* row_idx,
-                                uint32_t n, uint32_t* out) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  out[t] = cols[col_idx[t]][row_idx[t]];
+  if (t >= n * width) return;
+  uint32_t q = t / width, w = t - q * width;
+  out[t] = addrs[q][w];
 }
 
 
@@ -189,17 +182,9 @@ uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st) {
     CM_CHECK(base < (1ull << 40), "grind: no nonce found");
   }
 }
-void gather_hashes(const uint32_t* const* d_layers, const uint32_t* d_layer_idx, const uint32_t* d_node_idx, uint32_t n,
-                   uint32_t* d_out, hipStream_t st) {
+void gather_words(const uint32_t* const* d_addrs, uint32_t n, uint32_t width, uint32_t* d_out, hipStream_t st) {
   if (!n) return;
-  hipLaunchKernelGGL(k_gather_hashes, dim3((n * 8 + 255) / 256), dim3(256), 0, st, d_layers, d_layer_idx, d_node_idx, n,
-                     d_out);
-  CM_HIP(hipGetLastError());
-}
-void gather_values(const uint32_t* const* d_cols, const uint32_t* d_col_idx, const uint32_t* d_row_idx, uint32_t n,
-                   uint32_t* d_out, hipStream_t st) {
-  if (!n) return;
-  hipLaunchKernelGGL(k_gather_values, dim3((n + 255) / 256), dim3(256), 0, st, d_cols, d_col_idx, d_row_idx, n, d_out);
+  hipLaunchKernelGGL(k_gather_words, dim3((n * width + 255) / 256), dim3(256), 0, st, d_addrs, n, width, d_out);
   CM_HIP(hipGetLastError());
 }
 

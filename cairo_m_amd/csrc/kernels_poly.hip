@@ -143,13 +143,15 @@ __global__ void k_bit_reverse(uint32_t* const* cols, uint32_t log_n) {
 // and multiplies by hightab[hi].  partial[col][chunk] -> k_reduce_partials sums chunks.
 constexpr uint32_t EAP_LOW_BITS = 10;
 
-// tab[i] = prod_{bits k of i} maps[first_bit + k], i < 2^nbits   (maps given as 4 u32 each)
-__global__ void k_point_table(const uint32_t* maps, uint32_t first_bit, uint32_t nbits, uint32_t* tab) {
+// tab[i] = prod_{bits k of i} maps[first_bit + k], i < 2^nbits.  The <= 32 QM31 factors travel in the
+// kernel arguments (512 B), so sampling needs no host->device copy.
+struct PointMaps { uint32_t w[32 * 4]; };
+__global__ void k_point_table(PointMaps maps, uint32_t first_bit, uint32_t nbits, uint32_t* tab) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << nbits)) return;
   QM31 r(M31(1));
   for (uint32_t k = 0; k < nbits; k++)
-    if ((i >> k) & 1u) r = r * QM31::from_u32(maps + 4 * (first_bit + k));
+    if ((i >> k) & 1u) r = r * QM31::from_u32(maps.w + 4 * (first_bit + k));
   r.to_u32(tab + 4 * i);
 }
 
@@ -239,7 +241,7 @@ static void launch_pass(const uint32_t* const* d_src, uint32_t* const* d_dst, ui
   // algorithmic bytes of one pass: every element written once; read once unless it is implicit zero padding
   KProfScope kp(INV ? "k_fft_pass<ifft>" : "k_fft_pass<fft>",
                 4.0 * ncols * ((double)(1u << n) + (double)(in_len < (1u << n) ? in_len : (1u << n))), st);
-  if (tile_log == FFT_TILE_LOG) launch_fft_pass_r8(INV, a, ntiles, ncols, st);
+  if (tile_log == FFT_TILE_LOG && fft_pass_r8_supported(W, M, lo)) launch_fft_pass_r8(INV, a, ntiles, ncols, st);
   else hipLaunchKernelGGL(k_fft_pass<INV>, dim3(ntiles, ncols), dim3(256), lds, st, a);
 }
 void interpolate_oop(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n, const Twiddles& tw,
@@ -290,17 +292,16 @@ void eval_at_point_batch(const uint32_t* const* d_coeffs, uint32_t ncols, uint32
   uint32_t low = n < EAP_LOW_BITS ? n : EAP_LOW_BITS;
   uint32_t high = n - low;
   // maps[k]: factor of index bit k
-  uint32_t maps[32 * 4] = {0};
-  py.to_u32(maps);
+  PointMaps maps;
+  for (uint32_t k = 0; k < 32 * 4; k++) maps.w[k] = 0;
+  py.to_u32(maps.w);
   QM31 x = px;
-  for (uint32_t k = 1; k < n; k++) { x.to_u32(maps + 4 * k); x = double_x(x); }
-  uint32_t* d_maps = d_scratch;
-  uint32_t* d_low = d_maps + 32 * 4;
+  for (uint32_t k = 1; k < n; k++) { x.to_u32(maps.w + 4 * k); x = double_x(x); }
+  uint32_t* d_low = d_scratch + 32 * 4;
   uint32_t* d_high = d_low + 4 * ((size_t)1 << low);
   uint32_t* d_partial = d_high + 4 * ((size_t)1 << high);
-  CM_HIP(hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_point_table, dim3(((1u << low) + 255) / 256), dim3(256), 0, st, d_maps, 0u, low, d_low);
-  hipLaunchKernelGGL(k_point_table, dim3(((1u << high) + 255) / 256), dim3(256), 0, st, d_maps, low, high, d_high);
+  hipLaunchKernelGGL(k_point_table, dim3(((1u << low) + 255) / 256), dim3(256), 0, st, maps, 0u, low, d_low);
+  hipLaunchKernelGGL(k_point_table, dim3(((1u << high) + 255) / 256), dim3(256), 0, st, maps, low, high, d_high);
   uint32_t nchunks = 1u << high;
   KProfScope kp("k_eval_at_point", 4.0 * ncols * (double)(1u << n), st);
   hipLaunchKernelGGL(k_eval_at_point_partial, dim3(nchunks, ncols), dim3(256), 0, st, d_coeffs, n, d_low, d_high,

@@ -1,7 +1,9 @@
 // Device-resident mixed-degree Merkle tree (Stwo MerkleProver over Blake2sMerkleHasher):
-// layers live in HBM (8 u32 per node); commit() drives k_merkle_layer from the largest layer down;
-// decommit() replays Stwo's decommitment walk on the host and fetches only the needed hashes /
-// column values with two gather kernels.
+// layers live in HBM (8 u32 per node); commit() drives k_merkle_layer from the largest layer down and
+// finishes the small layers in one fused launch; decommitment is split in two so that ALL trees of a proof
+// share one gather launch: plan_decommit() replays Stwo's decommitment walk on the host and appends the
+// device addresses it needs to a GatherBatch; after GatherBatch::run() finish_decommit() distributes the
+// fetched words.
 // Reference call sites: tree_builder.commit (crates/prover/src/prover.rs:73, 82, 102) and
 // commitment_scheme.prove_values -> tree.decommit inside stwo `prove` (prover.rs:131).
 #pragma once
@@ -20,14 +22,43 @@ struct MerkleDecommitment {
   std::vector<uint32_t> column_witness;
 };
 
+// One batched device->host gather of single words and 32-byte hashes at arbitrary device addresses.
+struct GatherBatch {
+  std::vector<const uint32_t*> word_addrs, hash_addrs;
+  std::vector<uint32_t> words, hashes;  // results (hashes: 8 words each)
+  size_t add_word(const uint32_t* p) { word_addrs.push_back(p); return word_addrs.size() - 1; }
+  size_t add_hash(const uint32_t* p) { hash_addrs.push_back(p); return hash_addrs.size() - 1; }
+  void run(hipStream_t st) {
+    words.resize(word_addrs.size());
+    hashes.resize(hash_addrs.size() * 8);
+    DevBuf dw, dh, ow, oh;
+    if (!word_addrs.empty()) {
+      dw = upload(word_addrs, st);
+      ow.alloc(words.size() * 4);
+      gather_words(dw.as<const uint32_t*>(), (uint32_t)word_addrs.size(), 1, ow.u32(), st);
+      CM_HIP(hipMemcpyAsync(words.data(), ow.p, words.size() * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (!hash_addrs.empty()) {
+      dh = upload(hash_addrs, st);
+      oh.alloc(hashes.size() * 4);
+      gather_words(dh.as<const uint32_t*>(), (uint32_t)hash_addrs.size(), 8, oh.u32(), st);
+      CM_HIP(hipMemcpyAsync(hashes.data(), oh.p, hashes.size() * 4, hipMemcpyDeviceToHost, st));
+    }
+    CM_HIP(hipStreamSynchronize(st));
+  }
+};
+
+struct DecommitPlan {
+  size_t hash0 = 0, n_hash = 0;    // range in GatherBatch::hash_addrs
+  size_t word0 = 0;                // first index in GatherBatch::word_addrs
+  std::vector<uint8_t> is_query;   // per requested word: 1 -> queried_values, 0 -> column_witness
+};
+
 struct MerkleTree {
   std::vector<DevBuf> layers;            // layers[k]: 2^k nodes
   std::vector<const uint32_t*> cols;     // columns sorted by size desc (stable)
   std::vector<uint32_t> col_logs;        // same order
   DevBuf d_cols;                         // device copy of `cols`
-  DevBuf d_layers;                       // device array of layer pointers
-
-  static uint32_t ilog2(uint64_t n) { uint32_t l = 0; while ((1ull << (l + 1)) <= n) l++; return l; }
 
   void commit(const std::vector<const uint32_t*>& columns, const std::vector<uint32_t>& logs, hipStream_t st) {
     std::vector<uint32_t> order(columns.size());
@@ -63,22 +94,17 @@ struct MerkleTree {
       }
       merkle_tail(a, st);
     }
-    std::vector<const uint32_t*> lp(layers.size());
-    for (size_t i = 0; i < layers.size(); i++) lp[i] = layers[i].u32();
-    d_layers = upload(lp, st);
   }
   void root(uint8_t out[32], hipStream_t st) const {
     CM_HIP(hipMemcpyAsync(out, layers[0].p, 32, hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
   }
 
-  // queries_per_log_size: log -> sorted unique positions.
-  void decommit(const std::map<uint32_t, std::vector<uint32_t>>& queries_per_log_size, std::vector<uint32_t>& queried_values,
-                MerkleDecommitment& d, hipStream_t st) const {
-    // pass 1: symbolic walk, record what to fetch
-    std::vector<uint32_t> h_layer, h_node;          // hash witness requests
-    std::vector<uint32_t> v_col, v_row;             // value requests, in walk order
-    std::vector<uint8_t> v_is_query;                // 1 = goes to queried_values, 0 = column_witness
+  // Symbolic decommitment walk (Stwo MerkleProver::decommit).  queries_per_log_size: log -> sorted unique positions.
+  DecommitPlan plan_decommit(const std::map<uint32_t, std::vector<uint32_t>>& queries_per_log_size, GatherBatch& gb) const {
+    DecommitPlan plan;
+    plan.hash0 = gb.hash_addrs.size();
+    plan.word0 = gb.word_addrs.size();
     size_t ci = 0;
     std::vector<uint32_t> last;
     for (int layer_log = (int)layers.size() - 1; layer_log >= 0; layer_log--) {
@@ -96,38 +122,39 @@ struct MerkleTree {
         else if (pi < last.size()) node = last[pi] / 2;
         else node = colq[qi];
         if (has_prev) {
+          const uint32_t* child = layers[layer_log + 1].u32();
           if (pi < last.size() && last[pi] == 2 * node) pi++;
-          else { h_layer.push_back(layer_log + 1); h_node.push_back(2 * node); }
+          else gb.add_hash(child + (size_t)(2 * node) * 8);
           if (pi < last.size() && last[pi] == 2 * node + 1) pi++;
-          else { h_layer.push_back(layer_log + 1); h_node.push_back(2 * node + 1); }
+          else gb.add_hash(child + (size_t)(2 * node + 1) * 8);
         }
         bool isq = qi < colq.size() && colq[qi] == node;
         if (isq) qi++;
-        for (size_t c = c0; c < ci; c++) { v_col.push_back((uint32_t)c); v_row.push_back(node); v_is_query.push_back(isq); }
+        for (size_t c = c0; c < ci; c++) { gb.add_word(cols[c] + node); plan.is_query.push_back(isq); }
         total.push_back(node);
       }
       last.swap(total);
     }
-    // pass 2: fetch
-    std::vector<uint32_t> hashes(h_layer.size() * 8), vals(v_col.size());
-    if (!h_layer.empty()) {
-      DevBuf dl = upload(h_layer, st), dn = upload(h_node, st), dout(hashes.size() * 4);
-      gather_hashes(d_layers.as<const uint32_t*>(), dl.u32(), dn.u32(), (uint32_t)h_layer.size(), dout.u32(), st);
-      CM_HIP(hipMemcpyAsync(hashes.data(), dout.p, hashes.size() * 4, hipMemcpyDeviceToHost, st));
-      CM_HIP(hipStreamSynchronize(st));
+    plan.n_hash = gb.hash_addrs.size() - plan.hash0;
+    return plan;
+  }
+  static void finish_decommit(const DecommitPlan& plan, const GatherBatch& gb, std::vector<uint32_t>& queried_values,
+                              MerkleDecommitment& d) {
+    d.hash_witness.resize(plan.n_hash);
+    for (size_t i = 0; i < plan.n_hash; i++) memcpy(d.hash_witness[i].data(), &gb.hashes[8 * (plan.hash0 + i)], 32);
+    for (size_t i = 0; i < plan.is_query.size(); i++) {
+      uint32_t v = gb.words[plan.word0 + i];
+      if (plan.is_query[i]) queried_values.push_back(v);
+      else d.column_witness.push_back(v);
     }
-    if (!v_col.empty()) {
-      DevBuf dc = upload(v_col, st), dr = upload(v_row, st), dout(vals.size() * 4);
-      gather_values(d_cols.as<const uint32_t*>(), dc.u32(), dr.u32(), (uint32_t)v_col.size(), dout.u32(), st);
-      CM_HIP(hipMemcpyAsync(vals.data(), dout.p, vals.size() * 4, hipMemcpyDeviceToHost, st));
-      CM_HIP(hipStreamSynchronize(st));
-    }
-    d.hash_witness.resize(h_layer.size());
-    for (size_t i = 0; i < h_layer.size(); i++) memcpy(d.hash_witness[i].data(), &hashes[8 * i], 32);
-    for (size_t i = 0; i < vals.size(); i++) {
-      if (v_is_query[i]) queried_values.push_back(vals[i]);
-      else d.column_witness.push_back(vals[i]);
-    }
+  }
+  // single-tree convenience (per-op C ABI)
+  void decommit(const std::map<uint32_t, std::vector<uint32_t>>& queries_per_log_size, std::vector<uint32_t>& queried_values,
+                MerkleDecommitment& d, hipStream_t st) const {
+    GatherBatch gb;
+    DecommitPlan plan = plan_decommit(queries_per_log_size, gb);
+    gb.run(st);
+    finish_decommit(plan, gb, queried_values, d);
   }
 };
 

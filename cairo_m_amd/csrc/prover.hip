@@ -86,7 +86,7 @@ struct ColumnSet {
   std::vector<uint32_t> logs;
   std::vector<uint32_t*> ptrs;
   DevBuf buf, d_ptrs;
-  void alloc(const std::vector<uint32_t>& logs_, hipStream_t st) {
+  void alloc(const std::vector<uint32_t>& logs_, hipStream_t st, bool upload_ptrs = true) {
     logs = logs_;
     size_t total = 0;
     for (auto l : logs) total += (size_t)1 << l;
@@ -94,9 +94,12 @@ struct ColumnSet {
     ptrs.resize(logs.size());
     size_t off = 0;
     for (size_t i = 0; i < logs.size(); i++) { ptrs[i] = buf.u32() + off; off += (size_t)1 << logs[i]; }
-    d_ptrs = upload(ptrs, st);
+    if (upload_ptrs) d_ptrs = upload(ptrs, st);
   }
-  uint32_t* const* dev(size_t first = 0) const { return d_ptrs.as<uint32_t*>() + first; }
+  uint32_t* const* dev(size_t first = 0) const {
+    CM_CHECK(d_ptrs.p, "ColumnSet::dev(): pointer table was not uploaded");
+    return d_ptrs.as<uint32_t*>() + first;
+  }
   size_t size() const { return logs.size(); }
 };
 
@@ -137,18 +140,24 @@ struct Prover {
     std::vector<uint32_t> lde_logs(logs);
     for (auto& l : lde_logs) l += cfg.log_blowup_factor;
     t.lde.alloc(lde_logs, st);
+    // one pointer-table upload for all size groups of the tree: [src | coeffs | lde] per group
+    struct Grp { uint32_t log, n; size_t off; };
+    std::vector<Grp> grps;
+    std::vector<const uint32_t*> table;
     for (auto& kv : by_log(logs)) {
-      std::vector<const uint32_t*> src;
-      std::vector<uint32_t*> co, ld;
-      for (auto i : kv.second) { if (!from_coeffs) src.push_back(evals->ptrs[i]); co.push_back(t.coeffs.ptrs[i]); ld.push_back(t.lde.ptrs[i]); }
-      DevBuf dco = upload(co, st), dld = upload(ld, st);
-      if (!from_coeffs) {
-        DevBuf dsrc = upload(src, st);
-        interpolate_oop(dsrc.as<const uint32_t*>(), dco.as<uint32_t*>(), (uint32_t)co.size(), kv.first, *tw, st);
-        evaluate(dco.as<const uint32_t*>(), dld.as<uint32_t*>(), (uint32_t)co.size(), kv.first, kv.first + cfg.log_blowup_factor, *tw, st);
-      } else {
-        evaluate(dco.as<const uint32_t*>(), dld.as<uint32_t*>(), (uint32_t)co.size(), kv.first, kv.first + cfg.log_blowup_factor, *tw, st);
-      }
+      Grp g{kv.first, (uint32_t)kv.second.size(), table.size()};
+      for (auto i : kv.second) table.push_back(from_coeffs ? nullptr : evals->ptrs[i]);
+      for (auto i : kv.second) table.push_back(t.coeffs.ptrs[i]);
+      for (auto i : kv.second) table.push_back(t.lde.ptrs[i]);
+      grps.push_back(g);
+    }
+    DevBuf d_table = upload(table, st);
+    for (auto& g : grps) {
+      const uint32_t* const* dsrc = d_table.as<const uint32_t*>() + g.off;
+      uint32_t* const* dco = (uint32_t* const*)(d_table.as<uint32_t*>() + g.off + g.n);
+      uint32_t* const* dld = (uint32_t* const*)(d_table.as<uint32_t*>() + g.off + 2 * g.n);
+      if (!from_coeffs) interpolate_oop(dsrc, dco, g.n, g.log, *tw, st);
+      evaluate((const uint32_t* const*)dco, dld, g.n, g.log, g.log + cfg.log_blowup_factor, *tw, st);
     }
     std::vector<const uint32_t*> cols(t.lde.ptrs.begin(), t.lde.ptrs.end());
     t.merkle.commit(cols, t.lde.logs, st);
@@ -243,23 +252,21 @@ struct Queries {
   }
 };
 
-// gather 4-coordinate values at positions from device columns
-static std::vector<QM31> gather_q(const uint32_t* const col4[4], const std::vector<uint32_t>& pos, hipStream_t st) {
-  std::vector<QM31> out(pos.size());
-  if (pos.empty()) return out;
-  std::vector<const uint32_t*> cols(col4, col4 + 4);
-  std::vector<uint32_t> ci, ri;
-  for (auto p : pos) for (uint32_t k = 0; k < 4; k++) { ci.push_back(k); ri.push_back(p); }
-  DevBuf dc = upload(cols, st), dci = upload(ci, st), dri = upload(ri, st), dout(ci.size() * 4);
-  gather_values(dc.as<const uint32_t*>(), dci.u32(), dri.u32(), (uint32_t)ci.size(), dout.u32(), st);
-  std::vector<uint32_t> w(ci.size());
-  CM_HIP(hipMemcpyAsync(w.data(), dout.p, w.size() * 4, hipMemcpyDeviceToHost, st));
-  CM_HIP(hipStreamSynchronize(st));
-  for (size_t i = 0; i < pos.size(); i++) out[i] = QM31::from_u32(&w[4 * i]);
-  return out;
+// 4-coordinate values at `pos` of a SecureColumnByCoords, through a GatherBatch
+struct QGather { size_t w0 = 0, n = 0; };
+static QGather plan_gather_q(const uint32_t* const col4[4], const std::vector<uint32_t>& pos, GatherBatch& gb) {
+  QGather g;
+  g.w0 = gb.word_addrs.size();
+  g.n = pos.size();
+  for (auto p : pos) for (int k = 0; k < 4; k++) gb.add_word(col4[k] + p);
+  return g;
 }
-static void decommit_positions(const uint32_t* const col4[4], const std::vector<uint32_t>& queries, std::vector<uint32_t>& positions,
-                               std::vector<QM31>& witness, hipStream_t st) {
+static void finish_gather_q(const QGather& g, const GatherBatch& gb, std::vector<QM31>& out) {
+  for (size_t i = 0; i < g.n; i++) out.push_back(QM31::from_u32(&gb.words[g.w0 + 4 * i]));
+}
+// compute_decommitment_positions_and_witness_evals (fold step 1): decommitment positions + witness requests
+static QGather plan_fri_positions(const uint32_t* const col4[4], const std::vector<uint32_t>& queries, std::vector<uint32_t>& positions,
+                                  GatherBatch& gb) {
   std::vector<uint32_t> wpos;
   size_t i = 0;
   while (i < queries.size()) {
@@ -274,8 +281,7 @@ static void decommit_positions(const uint32_t* const col4[4], const std::vector<
     }
     i = j;
   }
-  std::vector<QM31> w = gather_q(col4, wpos, st);
-  witness.insert(witness.end(), w.begin(), w.end());
+  return plan_gather_q(col4, wpos, gb);
 }
 
 // =========================================================================================================
@@ -429,11 +435,16 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   {
     CommittedTree& t = P.trees[2];
     t.coeffs = std::move(it_evals);
-    for (auto& kv : by_log(t.coeffs.logs)) {
-      std::vector<uint32_t*> co;
-      for (auto i : kv.second) co.push_back(t.coeffs.ptrs[i]);
-      DevBuf dco = upload(co, st);
-      interpolate(dco.as<uint32_t*>(), (uint32_t)co.size(), kv.first, *P.tw, st);
+    {
+      std::vector<uint32_t*> table;
+      struct Grp { uint32_t log, n; size_t off; };
+      std::vector<Grp> grps;
+      for (auto& kv : by_log(t.coeffs.logs)) {
+        grps.push_back(Grp{kv.first, (uint32_t)kv.second.size(), table.size()});
+        for (auto i : kv.second) table.push_back(t.coeffs.ptrs[i]);
+      }
+      DevBuf d_table = upload(table, st);
+      for (auto& g : grps) interpolate(d_table.as<uint32_t*>() + g.off, g.n, g.log, *P.tw, st);
     }
     P.commit(t, nullptr, true);
   }
@@ -516,48 +527,58 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   }
   pf.sampled_values.resize(4);
   for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
-  // all columns at the OODS point, batched by log size
-  {
-    struct Ref { int t; uint32_t c; };
-    std::map<uint32_t, std::vector<Ref>> groups;
-    for (int t = 0; t < 4; t++)
-      for (uint32_t c = 0; c < P.trees[t].coeffs.size(); c++) groups[P.trees[t].coeffs.logs[c]].push_back({t, c});
-    for (auto& kv : groups) {
-      std::vector<const uint32_t*> cols;
-      for (auto& r : kv.second) cols.push_back(P.trees[r.t].coeffs.ptrs[r.c]);
-      DevBuf dc = upload(cols, st), scratch(eval_at_point_scratch_words((uint32_t)cols.size(), kv.first) * 4), dout(cols.size() * 16);
-      eval_at_point_batch(dc.as<const uint32_t*>(), (uint32_t)cols.size(), kv.first, oods.x, oods.y, scratch.u32(), dout.u32(), st);
-      std::vector<uint32_t> w(cols.size() * 4);
-      CM_HIP(hipMemcpyAsync(w.data(), dout.p, w.size() * 4, hipMemcpyDeviceToHost, st));
-      CM_HIP(hipStreamSynchronize(st));
-      for (size_t i = 0; i < kv.second.size(); i++) pf.sampled_values[kv.second[i].t][kv.second[i].c] = {QM31::from_u32(&w[4 * i])};
-    }
-  }
-  // previous-row mask of every component's last LogUp column group: point oods - trace_step(log)
+  // Sampling jobs = (log size, point): every column at the OODS point, plus the previous-row mask
+  // (oods - trace_step(log)) of each component's last LogUp column group.  All jobs share one pointer-table
+  // upload, one scratch buffer and ONE device->host copy of the results.
   std::map<uint32_t, CPoint<QM31>> prev_points;
   {
-    std::map<uint32_t, std::vector<uint32_t>> groups;  // component log -> tree-2 column indices
-    for (int c = 0; c < air::N_COMPONENTS; c++) {
-      int ni = air::component_info(c).n_interaction;
-      for (int k = ni - 4; k < ni; k++) groups[clog[c]].push_back((uint32_t)(it0[c] + k));
-    }
-    for (auto& kv : groups) {
-      CPoint<M31> step = point_at_index(subgroup_gen_index(kv.first));
-      CPoint<QM31> neg{QM31(step.x), QM31(-step.y)};
-      CPoint<QM31> pt = cadd(oods, neg);
-      prev_points[kv.first] = pt;
-      std::vector<const uint32_t*> cols;
-      for (auto c : kv.second) cols.push_back(P.trees[2].coeffs.ptrs[c]);
-      DevBuf dc = upload(cols, st), scratch(eval_at_point_scratch_words((uint32_t)cols.size(), kv.first) * 4), dout(cols.size() * 16);
-      eval_at_point_batch(dc.as<const uint32_t*>(), (uint32_t)cols.size(), kv.first, pt.x, pt.y, scratch.u32(), dout.u32(), st);
-      std::vector<uint32_t> w(cols.size() * 4);
-      CM_HIP(hipMemcpyAsync(w.data(), dout.p, w.size() * 4, hipMemcpyDeviceToHost, st));
-      CM_HIP(hipStreamSynchronize(st));
-      for (size_t i = 0; i < kv.second.size(); i++) {
-        auto& sv = pf.sampled_values[2][kv.second[i]];
-        sv.insert(sv.begin(), QM31::from_u32(&w[4 * i]));  // mask order [-1, 0]
+    struct Ref { int t; uint32_t c; bool prev; };
+    struct Job { uint32_t log; CPoint<QM31> pt; std::vector<Ref> refs; size_t off = 0, out_off = 0; };
+    std::vector<Job> jobs;
+    {
+      std::map<uint32_t, std::vector<Ref>> groups;
+      for (int t = 0; t < 4; t++)
+        for (uint32_t c = 0; c < P.trees[t].coeffs.size(); c++) groups[P.trees[t].coeffs.logs[c]].push_back({t, c, false});
+      for (auto& kv : groups) jobs.push_back(Job{kv.first, oods, kv.second});
+      std::map<uint32_t, std::vector<Ref>> pgroups;
+      for (int c = 0; c < air::N_COMPONENTS; c++) {
+        int ni = air::component_info(c).n_interaction;
+        for (int k = ni - 4; k < ni; k++) pgroups[clog[c]].push_back({2, (uint32_t)(it0[c] + k), true});
+      }
+      for (auto& kv : pgroups) {
+        CPoint<M31> step = point_at_index(subgroup_gen_index(kv.first));
+        CPoint<QM31> neg{QM31(step.x), QM31(-step.y)};
+        CPoint<QM31> pt = cadd(oods, neg);
+        prev_points[kv.first] = pt;
+        jobs.push_back(Job{kv.first, pt, kv.second});
       }
     }
+    std::vector<const uint32_t*> table;
+    size_t n_out = 0, scratch_words = 0;
+    for (auto& j : jobs) {
+      j.off = table.size();
+      j.out_off = n_out;
+      for (auto& r : j.refs) table.push_back(P.trees[r.t].coeffs.ptrs[r.c]);
+      n_out += j.refs.size();
+      scratch_words += eval_at_point_scratch_words((uint32_t)j.refs.size(), j.log);
+    }
+    DevBuf d_table = upload(table, st), scratch(scratch_words * 4), dout(n_out * 16);
+    size_t soff = 0;
+    for (auto& j : jobs) {
+      eval_at_point_batch(d_table.as<const uint32_t*>() + j.off, (uint32_t)j.refs.size(), j.log, j.pt.x, j.pt.y,
+                          scratch.u32() + soff, dout.u32() + 4 * j.out_off, st);
+      soff += eval_at_point_scratch_words((uint32_t)j.refs.size(), j.log);
+    }
+    std::vector<uint32_t> w(n_out * 4);
+    CM_HIP(hipMemcpyAsync(w.data(), dout.p, w.size() * 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    for (auto& j : jobs)
+      for (size_t i = 0; i < j.refs.size(); i++) {
+        auto& sv = pf.sampled_values[j.refs[i].t][j.refs[i].c];
+        QM31 v = QM31::from_u32(&w[4 * (j.out_off + i)]);
+        if (j.refs[i].prev) sv.insert(sv.begin(), v);  // mask order [-1, 0]
+        else sv.push_back(v);
+      }
   }
   {
     std::vector<QM31> flat;
@@ -592,58 +613,87 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     for (uint32_t c = 0; c < P.trees[t].lde.size(); c++) qgroups[P.trees[t].lde.logs[c]].push_back({t, c});
   std::vector<uint32_t> q_logs;
   std::vector<ColumnSet> quotients;
-  for (auto& kv : qgroups) {
-    uint32_t l = kv.first;
-    std::vector<const uint32_t*> cols;
-    struct Batch { CPoint<QM31> pt; std::vector<std::pair<uint32_t, QM31>> entries; };
-    std::vector<Batch> batches;
-    for (uint32_t i = 0; i < kv.second.size(); i++) {
-      const Ref& r = kv.second[i];
-      cols.push_back(P.trees[r.t].lde.ptrs[r.c]);
-      const auto& sv = pf.sampled_values[r.t][r.c];
-      for (size_t k = 0; k < sv.size(); k++) {
-        // sample points: [oods] or [prev, oods]
-        CPoint<QM31> pt = (sv.size() == 2 && k == 0) ? prev_points[P.trees[r.t].coeffs.logs[r.c]] : oods;
-        size_t b = 0;
-        for (; b < batches.size(); b++) if (batches[b].pt.x == pt.x && batches[b].pt.y == pt.y) break;
-        if (b == batches.size()) batches.push_back(Batch{pt, {}});
-        batches[b].entries.push_back({i, sv[k]});
+  {
+    // host side of compute_fri_quotients for every size group, packed into ONE upload:
+    // [column pointers | out pointers | col_index | coef_c | batches] per group, 16-byte aligned
+    struct GroupOff { size_t cols, out, ci, cc, qb; uint32_t n_batches, n_cols; };
+    std::vector<GroupOff> offs;
+    std::vector<uint8_t> blob;
+    auto put = [&](const void* p, size_t bytes) {
+      size_t o = (blob.size() + 15) & ~(size_t)15;
+      blob.resize(o + bytes);
+      if (bytes) memcpy(blob.data() + o, p, bytes);
+      return o;
+    };
+    for (auto& kv : qgroups) {
+      uint32_t l = kv.first;
+      std::vector<const uint32_t*> cols;
+      struct Batch { CPoint<QM31> pt; std::vector<std::pair<uint32_t, QM31>> entries; };
+      std::vector<Batch> batches;
+      for (uint32_t i = 0; i < kv.second.size(); i++) {
+        const Ref& r = kv.second[i];
+        cols.push_back(P.trees[r.t].lde.ptrs[r.c]);
+        const auto& sv = pf.sampled_values[r.t][r.c];
+        for (size_t k = 0; k < sv.size(); k++) {
+          // sample points: [oods] or [prev, oods]
+          CPoint<QM31> pt = (sv.size() == 2 && k == 0) ? prev_points[P.trees[r.t].coeffs.logs[r.c]] : oods;
+          size_t b = 0;
+          for (; b < batches.size(); b++) if (batches[b].pt.x == pt.x && batches[b].pt.y == pt.y) break;
+          if (b == batches.size()) batches.push_back(Batch{pt, {}});
+          batches[b].entries.push_back({i, sv[k]});
+        }
       }
-    }
-    std::vector<QuotientBatch> qb(batches.size());
-    std::vector<uint32_t> col_index, coef_c;
-    for (size_t b = 0; b < batches.size(); b++) {
-      qb[b].begin = (uint32_t)col_index.size();
-      QM31 alpha(M31(1)), sum_a, sum_b;
-      QM31 cdiff = conj_u(batches[b].pt.y) - batches[b].pt.y;
-      for (auto& e : batches[b].entries) {
-        alpha = alpha * qcoeff;
-        QM31 a = conj_u(e.second) - e.second;
-        QM31 bb = e.second * cdiff - a * batches[b].pt.y;
-        sum_a += alpha * a;
-        sum_b += alpha * bb;
-        col_index.push_back(e.first);
-        uint32_t w[4];
-        (alpha * cdiff).to_u32(w);
-        coef_c.insert(coef_c.end(), w, w + 4);
+      std::vector<QuotientBatch> qb(batches.size());
+      std::vector<uint32_t> col_index, coef_c;
+      for (size_t b = 0; b < batches.size(); b++) {
+        qb[b].begin = (uint32_t)col_index.size();
+        QM31 alpha(M31(1)), sum_a, sum_b;
+        QM31 cdiff = conj_u(batches[b].pt.y) - batches[b].pt.y;
+        for (auto& e : batches[b].entries) {
+          alpha = alpha * qcoeff;
+          QM31 a = conj_u(e.second) - e.second;
+          QM31 bb = e.second * cdiff - a * batches[b].pt.y;
+          sum_a += alpha * a;
+          sum_b += alpha * bb;
+          col_index.push_back(e.first);
+          uint32_t w[4];
+          (alpha * cdiff).to_u32(w);
+          coef_c.insert(coef_c.end(), w, w + 4);
+        }
+        qb[b].end = (uint32_t)col_index.size();
+        batches[b].pt.x.to_u32(qb[b].point);   // words = (Pr.x, Pi.x): QM31 = (a.a, a.b, b.a, b.b)
+        batches[b].pt.y.to_u32(qb[b].point + 4);
+        sum_a.to_u32(qb[b].sum_a);
+        sum_b.to_u32(qb[b].sum_b);
+        qpow(qcoeff, batches[b].entries.size()).to_u32(qb[b].batch_coeff);
       }
-      qb[b].end = (uint32_t)col_index.size();
-      batches[b].pt.x.to_u32(qb[b].point);
-      batches[b].pt.y.to_u32(qb[b].point + 4);
-      // kernel wants (Pr.x, Pi.x, Pr.y, Pi.y) = (x.a, x.b, y.a, y.b): QM31 words already are [a.a,a.b,b.a,b.b]
-      sum_a.to_u32(qb[b].sum_a);
-      sum_b.to_u32(qb[b].sum_b);
-      qpow(qcoeff, batches[b].entries.size()).to_u32(qb[b].batch_coeff);
+      ColumnSet q;
+      q.alloc(std::vector<uint32_t>(4, l), st, false);
+      GroupOff g;
+      g.cols = put(cols.data(), cols.size() * sizeof(void*));
+      g.out = put(q.ptrs.data(), 4 * sizeof(void*));
+      g.ci = put(col_index.data(), col_index.size() * 4);
+      g.cc = put(coef_c.data(), coef_c.size() * 4);
+      g.qb = put(qb.data(), qb.size() * sizeof(QuotientBatch));
+      g.n_batches = (uint32_t)qb.size();
+      g.n_cols = (uint32_t)cols.size();
+      offs.push_back(g);
+      q_logs.push_back(l);
+      quotients.push_back(std::move(q));
     }
-    ColumnSet q;
-    q.alloc(std::vector<uint32_t>(4, l), st);
-    DevBuf dcols = upload(cols, st), dci = upload(col_index, st), dcc = upload(coef_c, st), dqb = upload(qb, st);
-    QuotientArgs a;
-    a.tw = view(*P.tw); a.log_size = l; a.cols = dcols.as<const uint32_t*>(); a.col_index = dci.u32(); a.coef_c = dcc.u32();
-    a.batches = dqb.as<QuotientBatch>(); a.n_batches = (uint32_t)qb.size(); a.out = q.dev();
-    launch_quotients(a, (double)cols.size(), st);
-    q_logs.push_back(l);
-    quotients.push_back(std::move(q));
+    DevBuf d_blob = upload(blob, st);
+    const uint8_t* base = d_blob.as<uint8_t>();
+    for (size_t k = 0; k < offs.size(); k++) {
+      QuotientArgs a;
+      a.tw = view(*P.tw); a.log_size = q_logs[k];
+      a.cols = (const uint32_t* const*)(base + offs[k].cols);
+      a.out = (uint32_t* const*)(base + offs[k].out);
+      a.col_index = (const uint32_t*)(base + offs[k].ci);
+      a.coef_c = (const uint32_t*)(base + offs[k].cc);
+      a.batches = (const QuotientBatch*)(base + offs[k].qb);
+      a.n_batches = offs[k].n_batches;
+      launch_quotients(a, (double)offs[k].n_cols, st);
+    }
   }
   P.tick("quotients");
 
@@ -663,7 +713,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   uint32_t layer_log = q_logs[0] - 1;
   const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup_factor;
   ColumnSet layer;
-  layer.alloc(std::vector<uint32_t>(4, layer_log), st);
+  layer.alloc(std::vector<uint32_t>(4, layer_log), st, false);
   CM_HIP(hipMemsetAsync(layer.buf.p, 0, layer.buf.bytes, st));
   size_t qi = 0;
   while (layer_log > last_log) {
@@ -682,7 +732,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     ch.mix_root(il->root);
     QM31 alpha = ch.draw_felt();
     layer = ColumnSet();
-    layer.alloc(std::vector<uint32_t>(4, layer_log - 1), st);
+    layer.alloc(std::vector<uint32_t>(4, layer_log - 1), st, false);
     const uint32_t* src[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
     uint32_t* dst[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
     fold_line(dst, src, layer_log, *P.tw, alpha, st);
@@ -696,7 +746,13 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     const uint32_t* c4[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
     std::vector<uint32_t> pos(n);
     for (uint32_t i = 0; i < n; i++) pos[i] = i;
-    std::vector<QM31> vals = gather_q(c4, pos, st);
+    std::vector<QM31> vals;
+    {
+      GatherBatch gb;
+      QGather g = plan_gather_q(c4, pos, gb);
+      gb.run(st);
+      finish_gather_q(g, gb, vals);
+    }
     for (uint32_t l = 0; l < last_log; l++) {
       uint32_t stride = 1u << l;
       for (uint32_t h = 0; h < (n >> (l + 1)); h++) {
@@ -747,37 +803,53 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   std::map<uint32_t, std::vector<uint32_t>> qpos;
   for (auto l : q_logs) qpos[l] = queries.fold(queries.log_domain_size - l).positions;
   {
-    std::map<uint32_t, std::vector<uint32_t>> dpos;
+    // One batched gather for every tree of the proof: FRI first layer, inner layers, the 4 commitment trees.
+    GatherBatch gb;
+    std::vector<QGather> first_w;
+    std::map<uint32_t, std::vector<uint32_t>> first_dpos;
     for (size_t k = 0; k < quotients.size(); k++) {
       const uint32_t* c4[4] = {quotients[k].ptrs[0], quotients[k].ptrs[1], quotients[k].ptrs[2], quotients[k].ptrs[3]};
       std::vector<uint32_t> pos;
-      decommit_positions(c4, qpos[q_logs[k]], pos, pf.fri_first.fri_witness, st);
-      dpos[q_logs[k]] = pos;
+      first_w.push_back(plan_fri_positions(c4, qpos[q_logs[k]], pos, gb));
+      first_dpos[q_logs[k]] = pos;
     }
-    std::vector<uint32_t> qv;
-    first_tree.decommit(dpos, qv, pf.fri_first.decommitment, st);
-  }
-  {
-    Queries lq = queries.fold(1);
-    for (auto& il : inner) {
-      FriLayerProofData lp;
-      const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
-      std::vector<uint32_t> pos;
-      decommit_positions(c4, lq.positions, pos, lp.fri_witness, st);
-      std::map<uint32_t, std::vector<uint32_t>> dpos;
-      dpos[il->log] = pos;
+    DecommitPlan first_plan = first_tree.plan_decommit(first_dpos, gb);
+    std::vector<QGather> inner_w;
+    std::vector<DecommitPlan> inner_plan;
+    {
+      Queries lq = queries.fold(1);
+      for (auto& il : inner) {
+        const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
+        std::vector<uint32_t> pos;
+        inner_w.push_back(plan_fri_positions(c4, lq.positions, pos, gb));
+        std::map<uint32_t, std::vector<uint32_t>> dpos;
+        dpos[il->log] = pos;
+        inner_plan.push_back(il->tree.plan_decommit(dpos, gb));
+        lq = lq.fold(1);
+      }
+    }
+    DecommitPlan tree_plan[4];
+    for (int t = 0; t < 4; t++) tree_plan[t] = P.trees[t].merkle.plan_decommit(qpos, gb);
+    gb.run(st);
+    for (auto& g : first_w) finish_gather_q(g, gb, pf.fri_first.fri_witness);
+    {
       std::vector<uint32_t> qv;
-      il->tree.decommit(dpos, qv, lp.decommitment, st);
-      lp.commitment = il->root;
-      pf.fri_inner.push_back(std::move(lp));
-      lq = lq.fold(1);
+      MerkleTree::finish_decommit(first_plan, gb, qv, pf.fri_first.decommitment);
     }
-  }
-  pf.decommitments.resize(4);
-  pf.queried_values.resize(4);
-  for (int t = 0; t < 4; t++) {
-    P.trees[t].merkle.decommit(qpos, pf.queried_values[t], pf.decommitments[t], st);
-    pf.commitments.push_back(P.trees[t].root);
+    for (size_t i = 0; i < inner.size(); i++) {
+      FriLayerProofData lp;
+      finish_gather_q(inner_w[i], gb, lp.fri_witness);
+      std::vector<uint32_t> qv;
+      MerkleTree::finish_decommit(inner_plan[i], gb, qv, lp.decommitment);
+      lp.commitment = inner[i]->root;
+      pf.fri_inner.push_back(std::move(lp));
+    }
+    pf.decommitments.resize(4);
+    pf.queried_values.resize(4);
+    for (int t = 0; t < 4; t++) {
+      MerkleTree::finish_decommit(tree_plan[t], gb, pf.queried_values[t], pf.decommitments[t]);
+      pf.commitments.push_back(P.trees[t].root);
+    }
   }
   P.tick("decommit");
   pf.phase_ms = P.phase_ms;
