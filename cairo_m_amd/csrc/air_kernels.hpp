@@ -33,9 +33,13 @@ void launch_hist(int cid, const uint32_t* const* d_cols, uint32_t log_size, cons
 void launch_logup(int cid, const uint32_t* const* d_cols, const uint32_t* const* d_pp, uint32_t log_size,
                   const DevRelations* d_rels, uint32_t* const* d_out, hipStream_t st);
 void launch_constraints(int cid, const ConstraintArgs& a, hipStream_t st);
-size_t logup_finalize_scratch_words(uint32_t log_size);
-void logup_finalize_last(uint32_t* const* d_cols4, uint32_t log_size, uint32_t* d_scratch, uint32_t* d_claimed_sum,
-                         hipStream_t st);
+// LogupTraceGenerator::finalize_last for every component at once
+struct LogupTailJob {
+  uint32_t* col[4];     // last 4 interaction columns (trace domain, bit-reversed circle order)
+  uint32_t log_size;
+  uint32_t tmp_off, btot_off;  // filled by logup_finalize_all
+};
+void logup_finalize_all(const std::vector<LogupTailJob>& jobs, uint32_t* d_sums, hipStream_t st);
 void launch_preproc(int pp_id, uint32_t log_size, uint32_t* d_col, hipStream_t st);
 void add_columns(uint32_t* const* d_dst, const uint32_t* const* d_src, uint32_t ncols, uint32_t n, hipStream_t st);
 

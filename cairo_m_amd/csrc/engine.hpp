@@ -46,6 +46,17 @@ struct MerkleTailArgs {
   uint32_t* layers[MERKLE_TAIL_LOG + 1];      // output buffer of layer l
 };
 void merkle_tail(const MerkleTailArgs& a, hipStream_t st);
+// up to MERKLE_MULTI_LEVELS consecutive layers per launch (top layer must have >= 256 nodes)
+constexpr uint32_t MERKLE_MULTI_LEVELS = 4;
+struct MerkleMultiArgs {
+  uint32_t top_log, n_levels;
+  const uint32_t* prev;                        // hashes of layer top_log + 1, or null
+  const uint32_t* const* cols;                 // device array of all (sorted) column pointers of the tree
+  uint32_t col_begin[MERKLE_MULTI_LEVELS];     // column range of level lv (layer top_log - lv) in `cols`
+  uint32_t col_end[MERKLE_MULTI_LEVELS];
+  uint32_t* layers[MERKLE_MULTI_LEVELS];       // output buffer of level lv
+};
+void merkle_multi(const MerkleMultiArgs& a, double alg_bytes, hipStream_t st);
 uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st);
 // out[q * width + w] = addrs[q][w]  (decommitment gathers: width 1 = values, 8 = hashes)
 void gather_words(const uint32_t* const* d_addrs, uint32_t n, uint32_t width, uint32_t* d_out, hipStream_t st);

@@ -72,12 +72,36 @@ struct MerkleTree {
     d_cols = upload(cols, st);
     size_t ci = 0;
     const int tail_top = (int)std::min<uint32_t>(max_log, MERKLE_TAIL_LOG);
-    for (int log = (int)max_log; log > tail_top; log--) {
-      size_t c0 = ci;
-      while (ci < cols.size() && col_logs[ci] == (uint32_t)log) ci++;
-      layers[log].alloc((size_t)32 << log);
-      const uint32_t* prev = (log < (int)max_log) ? layers[log + 1].u32() : nullptr;
-      merkle_layer((uint32_t)log, prev, d_cols.as<const uint32_t*>() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
+    for (int log = (int)max_log; log > tail_top;) {
+      // group of up to MERKLE_MULTI_LEVELS layers per launch (the top layer of a group needs >= 256 nodes)
+      int levels = std::min<int>((int)MERKLE_MULTI_LEVELS, log - tail_top);
+      if (log < 8) levels = 1;
+      if (levels == 1) {
+        size_t c0 = ci;
+        while (ci < cols.size() && col_logs[ci] == (uint32_t)log) ci++;
+        layers[log].alloc((size_t)32 << log);
+        const uint32_t* prev = (log < (int)max_log) ? layers[log + 1].u32() : nullptr;
+        merkle_layer((uint32_t)log, prev, d_cols.as<const uint32_t*>() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
+        log--;
+        continue;
+      }
+      MerkleMultiArgs a;
+      a.top_log = (uint32_t)log;
+      a.n_levels = (uint32_t)levels;
+      a.prev = (log < (int)max_log) ? layers[log + 1].u32() : nullptr;
+      a.cols = d_cols.as<const uint32_t*>();
+      double bytes = 0;
+      for (int lv = 0; lv < levels; lv++) {
+        int l = log - lv;
+        a.col_begin[lv] = (uint32_t)ci;
+        while (ci < cols.size() && col_logs[ci] == (uint32_t)l) ci++;
+        a.col_end[lv] = (uint32_t)ci;
+        layers[l].alloc((size_t)32 << l);
+        a.layers[lv] = layers[l].u32();
+        bytes += (4.0 * (a.col_end[lv] - a.col_begin[lv]) + 32.0 + ((lv == 0 && a.prev) ? 64.0 : 0.0)) * (double)((size_t)1 << l);
+      }
+      merkle_multi(a, bytes, st);
+      log -= levels;
     }
     {
       // layers 2^tail_top .. 2^0: one fused launch

@@ -416,14 +416,16 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     it_evals.alloc(logs, st);
   }
   {
-    DevBuf scratch(logup_finalize_scratch_words(max_log) * 4);
     DevBuf d_sums(air::N_COMPONENTS * 16);
+    std::vector<LogupTailJob> jobs(air::N_COMPONENTS);
     for (int c = 0; c < air::N_COMPONENTS; c++) {
       const air::ComponentInfo& info = air::component_info(c);
       launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
                    drel.as<DevRelations>(), it_evals.dev(it0[c]), st);
-      logup_finalize_last(it_evals.dev(it0[c] + info.n_interaction - 4), clog[c], scratch.u32(), d_sums.u32() + 4 * c, st);
+      for (int k = 0; k < 4; k++) jobs[c].col[k] = it_evals.ptrs[it0[c] + info.n_interaction - 4 + k];
+      jobs[c].log_size = clog[c];
     }
+    logup_finalize_all(jobs, d_sums.u32(), st);
     uint32_t sums[air::N_COMPONENTS * 4];
     CM_HIP(hipMemcpyAsync(sums, d_sums.p, sizeof(sums), hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));

@@ -110,6 +110,37 @@ class Backend:
         self._ck(self.L.cm_grind(d, C.c_uint32(bits), C.byref(nonce)))
         return nonce.value
 
+    # -- FieldOps / FriOps / QuotientOps ----------------------------------------------------
+    def batch_inverse_m31(self, src, dst, n):
+        self._ck(self.L.cm_batch_inverse_m31(C.c_uint64(src), C.c_uint64(dst), C.c_uint64(n), C.c_uint64(0)))
+
+    def batch_inverse_qm31(self, src4, dst4, n):
+        self._ck(self.L.cm_batch_inverse_qm31(self._harr(src4), self._harr(dst4), C.c_uint64(n), C.c_uint64(0)))
+
+    def fri_fold_circle_into_line(self, dst4, src4, alpha, log_n, tw):
+        a = np.ascontiguousarray(alpha, dtype=np.uint32)
+        self._ck(self.L.cm_fri_fold_circle_into_line(self._harr(dst4), self._harr(src4), _p(a), C.c_uint32(log_n),
+                                                     C.c_uint64(tw), C.c_uint64(0)))
+
+    def fri_fold_line(self, src4, alpha, log_n, tw, out4):
+        a = np.ascontiguousarray(alpha, dtype=np.uint32)
+        self._ck(self.L.cm_fri_fold_line(self._harr(src4), _p(a), C.c_uint32(log_n), C.c_uint64(tw),
+                                         self._harr(out4), C.c_uint64(0)))
+
+    def accumulate_quotients(self, log_size, cols, points, batch_off, col_index, values, coeff, out4, tw):
+        """points: (n_batches, 8) u32; batch_off: n_batches+1; col_index: entries; values: (entries, 4)."""
+        class Batches(C.Structure):
+            _fields_ = [("n_batches", C.c_uint32), ("points", C.c_void_p), ("batch_off", C.c_void_p),
+                        ("col_index", C.c_void_p), ("values", C.c_void_p)]
+        pts = np.ascontiguousarray(points, dtype=np.uint32)
+        off = np.ascontiguousarray(batch_off, dtype=np.uint32)
+        ci = np.ascontiguousarray(col_index, dtype=np.uint32)
+        vals = np.ascontiguousarray(values, dtype=np.uint32)
+        co = np.ascontiguousarray(coeff, dtype=np.uint32)
+        b = Batches(len(off) - 1, pts.ctypes.data, off.ctypes.data, ci.ctypes.data, vals.ctypes.data)
+        self._ck(self.L.cm_accumulate_quotients(C.c_uint32(log_size), self._harr(cols), C.c_uint32(len(cols)), C.byref(b),
+                                                _p(co), self._harr(out4), C.c_uint64(tw), C.c_uint64(0)))
+
 
 class HostInput:
     """ProverInput built on the host by the synthetic VM + adapter (no GPU needed)."""

@@ -86,4 +86,46 @@ void orc_poseidon2_permute(uint32_t* state) {
   air::Poseidon2C::witness<OrcOps>(in, 1, o);
   for (int i = 0; i < 16; i++) state[i] = o[air::Poseidon2C::N_TRACE - 16 + i].v;
 }
+// ---- per-op exports (parity tests of the FriOps / QuotientOps C-ABI entry points) ----
+// cols: 4 coordinate columns, each 2^log (src) / 2^(log-1) (dst), contiguous
+void orc_fold_circle_into_line(uint32_t* dst, const uint32_t* src, uint32_t log, const uint32_t* alpha) {
+  size_t N = (size_t)1 << log, H = N / 2;
+  std::vector<Col> d(4, Col(H)), s(4, Col(N));
+  for (int k = 0; k < 4; k++) {
+    for (size_t i = 0; i < H; i++) d[k][i] = M31(dst[k * H + i]);
+    for (size_t i = 0; i < N; i++) s[k][i] = M31(src[k * N + i]);
+  }
+  fold_circle_into_line(d, s, log, QM31::from_m31s(M31(alpha[0]), M31(alpha[1]), M31(alpha[2]), M31(alpha[3])));
+  for (int k = 0; k < 4; k++) for (size_t i = 0; i < H; i++) dst[k * H + i] = d[k][i].v;
+}
+void orc_fold_line(const uint32_t* src, uint32_t log, const uint32_t* alpha, uint32_t* out) {
+  size_t N = (size_t)1 << log, H = N / 2;
+  std::vector<Col> s(4, Col(N));
+  for (int k = 0; k < 4; k++) for (size_t i = 0; i < N; i++) s[k][i] = M31(src[k * N + i]);
+  std::vector<Col> o = fold_line(s, log, QM31::from_m31s(M31(alpha[0]), M31(alpha[1]), M31(alpha[2]), M31(alpha[3])));
+  for (int k = 0; k < 4; k++) for (size_t i = 0; i < H; i++) out[k * H + i] = o[k][i].v;
+}
+// cols: n_cols columns of 2^log contiguous; samples given as batches in the same layout as cm_sample_batches
+void orc_accumulate_quotients(uint32_t log, const uint32_t* cols, uint32_t n_cols, uint32_t n_batches, const uint32_t* points,
+                              const uint32_t* batch_off, const uint32_t* col_index, const uint32_t* values,
+                              const uint32_t* coeff, uint32_t* out) {
+  size_t N = (size_t)1 << log;
+  std::vector<Col> c(n_cols, Col(N));
+  std::vector<const Col*> cp(n_cols);
+  for (uint32_t j = 0; j < n_cols; j++) {
+    for (size_t i = 0; i < N; i++) c[j][i] = M31(cols[j * N + i]);
+    cp[j] = &c[j];
+  }
+  auto q = [](const uint32_t* w) { return QM31::from_m31s(M31(w[0]), M31(w[1]), M31(w[2]), M31(w[3])); };
+  // the oracle groups samples by point in insertion order; feed them column-major so that the grouping
+  // reproduces the given batches (the caller passes batches with increasing first-appearance order)
+  std::vector<std::vector<std::pair<PointQ, QM31>>> samples(n_cols);
+  for (uint32_t b = 0; b < n_batches; b++)
+    for (uint32_t e = batch_off[b]; e < batch_off[b + 1]; e++) {
+      PointQ pt; pt.x = q(points + 8 * b); pt.y = q(points + 8 * b + 4);
+      samples[col_index[e]].push_back({pt, q(values + 4 * e)});
+    }
+  std::vector<Col> o = accumulate_quotients(log, cp, samples, q(coeff));
+  for (int k = 0; k < 4; k++) for (size_t i = 0; i < N; i++) out[k * N + i] = o[k][i].v;
+}
 }

@@ -126,6 +126,32 @@ def _attach_prover(cls):
             raise RuntimeError(err(self))
         return out.reshape(ncols.value, 1 << log.value)
 
+    def fold_circle_into_line(self, dst4, src4, log, alpha):
+        d = np.ascontiguousarray(np.concatenate(dst4), dtype=np.uint32).copy()
+        s = np.ascontiguousarray(np.concatenate(src4), dtype=np.uint32)
+        a = np.ascontiguousarray(alpha, dtype=np.uint32)
+        self.L.orc_fold_circle_into_line(_p(d), _p(s), C.c_uint32(log), _p(a))
+        return d.reshape(4, -1)
+
+    def fold_line(self, src4, log, alpha):
+        s = np.ascontiguousarray(np.concatenate(src4), dtype=np.uint32)
+        a = np.ascontiguousarray(alpha, dtype=np.uint32)
+        out = np.empty(4 << (log - 1), dtype=np.uint32)
+        self.L.orc_fold_line(_p(s), C.c_uint32(log), _p(a), _p(out))
+        return out.reshape(4, -1)
+
+    def accumulate_quotients(self, log, cols, points, batch_off, col_index, values, coeff):
+        c = np.ascontiguousarray(np.concatenate(cols), dtype=np.uint32)
+        pts = np.ascontiguousarray(points, dtype=np.uint32)
+        off = np.ascontiguousarray(batch_off, dtype=np.uint32)
+        ci = np.ascontiguousarray(col_index, dtype=np.uint32)
+        vals = np.ascontiguousarray(values, dtype=np.uint32)
+        co = np.ascontiguousarray(coeff, dtype=np.uint32)
+        out = np.empty(4 << log, dtype=np.uint32)
+        self.L.orc_accumulate_quotients(C.c_uint32(log), _p(c), C.c_uint32(len(cols)), C.c_uint32(len(off) - 1), _p(pts),
+                                        _p(off), _p(ci), _p(vals), _p(co), _p(out))
+        return out.reshape(4, -1)
+
     def poseidon2_permute(self, state):
         s = np.ascontiguousarray(state, dtype=np.uint32).copy()
         self.L.orc_poseidon2_permute(_p(s))
@@ -133,6 +159,7 @@ def _attach_prover(cls):
 
     cls.prove, cls.verify, cls.assert_constraints = prove, verify, assert_constraints
     cls.component_trace, cls.poseidon2_permute = component_trace, poseidon2_permute
+    cls.fold_circle_into_line, cls.fold_line, cls.accumulate_quotients = fold_circle_into_line, fold_line, accumulate_quotients
 
 
 _attach_prover(Oracle)
