@@ -28,7 +28,7 @@ MODEL_BYTES_PER_CELL = 52.0  # SURVEY §8d algorithmic-bytes model for the whole
 def cpu_baseline(sample_n):
     """Oracle (CPU restatement, 'port') on a bounded sample of the same workload family."""
     import subprocess
-    from tests.oracle_binding import Oracle
+    from tests.oracle_binding import Oracle, oracle_threads
     from cairo_m_amd.lib import synth_fibonacci
     so = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(so):
@@ -40,9 +40,9 @@ def cpu_baseline(sample_n):
     dt = time.perf_counter() - t
     steps = inp.steps
     inp.free()
-    return {"value": cells / dt, "unit": "M31 trace cells/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": cells / dt, "unit": "M31 trace cells/s", "cores": oracle_threads(), "kind": "port",
             "sample": f"fibonacci_loop n={sample_n} ({steps} VM steps, {cells} cells incl. the fixed "
-                      f"2^20/2^18/2^16 preprocessed + range-check tables), oracle prove_segment, OpenMP, {dt:.1f} s"}
+                      f"2^20/2^18/2^16 preprocessed + range-check tables), oracle prove_segment, OpenMP x{oracle_threads()} of {os.cpu_count()} host cores, {dt:.1f} s"}
 
 
 def main():
@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--fib-n", type=int, default=FIB_N)
     ap.add_argument("--cpu-sample-n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kprof", action="store_true", help="debug: no in-library HIP-event kernel timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -77,12 +78,32 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def kprof_report():
+        buf = C.create_string_buffer(1 << 16)
+        be.L.cm_kprof_report(buf, C.c_size_t(1 << 16))
+        return json.loads(buf.value.decode())
+
+    # Warmup: every kernel class is HIP-event timed (per-class table + which class dominates).  Events cost
+    # a few microseconds per launch (~2 ms per proof over ~500 launches), so in the timed region only the
+    # dominant class keeps its events: `value` is not taxed by the instrumentation, and `roofline.achieved`
+    # still comes from launches inside the timed region.
     cells = None
+    kprof_all = {}
     for _ in range(args.warmup):
         p = be.prove_device(dev)
         cells = p.stats()["cells"]
         p.free()
-    be.L.cm_kprof_enable(C.c_int32(1))
+    n_prof = 1
+    if not args.no_kprof:  # one extra untimed, fully instrumented pass (after the cold-start warmup)
+        be.L.cm_kprof_enable(C.c_int32(1))
+        p = be.prove_device(dev)
+        cells = p.stats()["cells"]
+        p.free()
+        kprof_all = kprof_report()
+    dom_name = max(kprof_all.items(), key=lambda kv: kv[1]["ms"])[0] if kprof_all else None
+    be.L.cm_kprof_enable(C.c_int32(0 if args.no_kprof else 1))
+    if dom_name:
+        be.L.cm_kprof_filter(dom_name.encode())
     sync()
     t0 = time.perf_counter()
     phases = None
@@ -99,9 +120,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         dist.barrier()
-    buf = C.create_string_buffer(1 << 16)
-    be.L.cm_kprof_report(buf, C.c_size_t(1 << 16))
-    kprof = json.loads(buf.value.decode())
+    kprof = kprof_report() if not args.no_kprof else {}
     be.L.cm_kprof_enable(C.c_int32(0))
 
     if rank == 0:
@@ -119,9 +138,11 @@ def main():
                         "whole_path_model": {"bytes_per_cell": MODEL_BYTES_PER_CELL,
                                              "achieved_GBs": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9,
                                              "frac": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                        "kernels": {n: {"ms_per_step": v["ms"] / args.steps,
+                        "kernels_note": "per-class HIP-event totals from the instrumented (untimed) pass after the warmup; '(region)' = "
+                                        "one interval around a fork/join of per-component launches on side streams",
+                        "kernels": {n: {"ms_per_step": v["ms"] / n_prof, "launches_per_step": v["calls"] / n_prof,
                                         "GBs": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else None}
-                                    for n, v in kprof.items()}}
+                                    for n, v in kprof_all.items()}}
         out = {"metric": "M31 trace cells/sec proved, fibonacci_loop 2^22 rows; end-to-end proof ms",
                "value": value, "unit": "M31 trace cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

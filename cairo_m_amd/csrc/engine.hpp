@@ -48,6 +48,7 @@ struct MerkleTailArgs {
 void merkle_tail(const MerkleTailArgs& a, hipStream_t st);
 // up to MERKLE_MULTI_LEVELS consecutive layers per launch (top layer must have >= 256 nodes)
 constexpr uint32_t MERKLE_MULTI_LEVELS = 4;
+constexpr uint32_t MERKLE_MULTI_MAX_TOP = 19;  // layers of 2^19 nodes and more get their own launch
 struct MerkleMultiArgs {
   uint32_t top_log, n_levels;
   const uint32_t* prev;                        // hashes of layer top_log + 1, or null
@@ -57,6 +58,9 @@ struct MerkleMultiArgs {
   uint32_t* layers[MERKLE_MULTI_LEVELS];       // output buffer of level lv
 };
 void merkle_multi(const MerkleMultiArgs& a, double alg_bytes, hipStream_t st);
+// device-side transcript step of the FRI commit phase: chan = {digest[8], n_sent} (9 u32);
+// chan <- mix_root(root); felt_out[4] <- draw_felt(); root_log[8] <- root (read back once at the end)
+void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log, hipStream_t st);
 uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st);
 // out[q * width + w] = addrs[q][w]  (decommitment gathers: width 1 = values, 8 = hashes)
 void gather_words(const uint32_t* const* d_addrs, uint32_t n, uint32_t width, uint32_t* d_out, hipStream_t st);
@@ -66,6 +70,21 @@ void* pool_get(size_t bytes);
 void pool_put(void* p);
 void pool_trim();
 void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st);
+
+// Fork/join over a small set of side streams (thread-local, created once): independent per-component
+// launches of one phase run concurrently instead of serialising 34 tiny kernels on one stream.
+// Fork f(main); launch on f.stream(i) ...; f.join();  — every side stream first waits for everything
+// enqueued on `main` before the fork, and `main` waits for all side work at join().
+struct Fork {
+  static constexpr int N = 8;
+  hipStream_t main;
+  uint32_t used = 0;
+  bool joined = false;
+  explicit Fork(hipStream_t main_stream);
+  hipStream_t stream(int i);
+  void join();
+  ~Fork();
+};
 
 // simple RAII device buffer
 struct DevBuf {

@@ -29,8 +29,28 @@ struct QuotientArgs {
 };
 void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st);
 void fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw,
-                           const QM31& alpha, bool accumulate, hipStream_t st);
+                           const QM31& alpha, bool accumulate, hipStream_t st, const uint32_t* d_alpha = nullptr);
+// d_alpha != null: the folding challenge is read from device memory (4 u32) instead of `alpha`
 void fold_line(uint32_t* const out[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw, const QM31& alpha,
-               hipStream_t st);
+               hipStream_t st, const uint32_t* d_alpha = nullptr);
+
+// Tail of the FRI commit phase in ONE launch (one 1024-thread block): for every remaining layer
+// (2^top_log ... 2^(last_log+1) values) fold the pending circle quotients in, build the layer's Merkle
+// tree, do the transcript step (mix_root, draw the folding challenge) and fold to the next layer.  These
+// layers are pure launch/dependency latency as separate kernels (~6 launches each).
+constexpr uint32_t FRI_TAIL_MAX_LOG = 13;
+struct FriTailLayer {
+  uint32_t* cols[4];                        // line evaluation of the layer (4 coordinates x 2^log)
+  const uint32_t* circle[4];                // quotient columns of log + 1 to fold in first, or null
+  uint32_t* merkle[FRI_TAIL_MAX_LOG + 1];   // Merkle layers of the layer's tree: merkle[k] has 2^k nodes
+};
+struct FriTailArgs {
+  TwiddleView tw;
+  uint32_t top_log, last_log;               // layers top_log .. last_log+1 are committed; layers[last_log].cols is the output
+  uint32_t first_index;                     // index of layer top_log in alphas (4 u32 each) / roots (8 u32 each)
+  uint32_t *chan, *alphas, *roots;          // device transcript state, challenges (alphas[0..4) = circle alpha), root log
+  FriTailLayer layers[FRI_TAIL_MAX_LOG + 1];  // indexed by log
+};
+void fri_tail(const FriTailArgs& a, hipStream_t st);
 
 }  // namespace cm

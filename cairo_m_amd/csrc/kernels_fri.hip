@@ -8,6 +8,7 @@
 #include "engine.hpp"
 #include "fri_kernels.hpp"
 #include "kprof.hpp"
+#include "blake2s_dev.hpp"
 
 namespace cm {
 
@@ -77,10 +78,10 @@ struct CPtr4 { const uint32_t* p[4]; };
 // dst[i] = dst[i] * alpha^2 + (f0 + f1) + alpha * (f0 - f1) / y_i,  (f0, f1) = src[2i], src[2i+1]
 __global__ void __launch_bounds__(256) k_fold_circle(Ptr4 dst, CPtr4 src, uint32_t log_n, TwiddleView tw, const uint32_t alpha4_0,
                                                      const uint32_t alpha4_1, const uint32_t alpha4_2, const uint32_t alpha4_3,
-                                                     int accumulate) {
+                                                     int accumulate, const uint32_t* __restrict__ alpha_dev) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << (log_n - 1))) return;
-  QM31 alpha = QM31(M31(alpha4_0), M31(alpha4_1), M31(alpha4_2), M31(alpha4_3));
+  QM31 alpha = alpha_dev ? QM31::from_u32(alpha_dev) : QM31(M31(alpha4_0), M31(alpha4_1), M31(alpha4_2), M31(alpha4_3));
   M31 yinv(tw.iytw[(1u << (log_n - 1)) + i]);
   QM31 f0 = ld4(src.p, 2 * i), f1 = ld4(src.p, 2 * i + 1);
   QM31 v = (f0 + f1) + alpha * ((f0 - f1) * yinv);
@@ -89,14 +90,71 @@ __global__ void __launch_bounds__(256) k_fold_circle(Ptr4 dst, CPtr4 src, uint32
 }
 // out[i] = (f0 + f1) + alpha * (f0 - f1) / x_i on LineDomain(half_odds(log_n))
 __global__ void __launch_bounds__(256) k_fold_line(Ptr4 out, CPtr4 src, uint32_t log_n, TwiddleView tw, const uint32_t alpha4_0,
-                                                   const uint32_t alpha4_1, const uint32_t alpha4_2, const uint32_t alpha4_3) {
+                                                   const uint32_t alpha4_1, const uint32_t alpha4_2, const uint32_t alpha4_3,
+                                                   const uint32_t* __restrict__ alpha_dev) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << (log_n - 1))) return;
-  QM31 alpha = QM31(M31(alpha4_0), M31(alpha4_1), M31(alpha4_2), M31(alpha4_3));
+  QM31 alpha = alpha_dev ? QM31::from_u32(alpha_dev) : QM31(M31(alpha4_0), M31(alpha4_1), M31(alpha4_2), M31(alpha4_3));
   uint32_t L = tw.R - (log_n + 1);
   M31 xinv(tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + i]);
   QM31 f0 = ld4(src.p, 2 * i), f1 = ld4(src.p, 2 * i + 1);
   st4(out.p, i, (f0 + f1) + alpha * ((f0 - f1) * xinv));
+}
+
+__global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
+  const uint32_t tid = threadIdx.x;
+  uint32_t ai = a.first_index;
+  for (uint32_t l = a.top_log; l > a.last_log; l--, ai++) {
+    const FriTailLayer& L = a.layers[l];
+    const uint32_t n = 1u << l;
+    if (L.circle[0]) {  // fold_circle_into_line of the quotient columns of log l + 1 (k_fold_circle)
+      const QM31 alpha = QM31::from_u32(a.alphas);
+      const QM31 alpha2 = alpha * alpha;
+      for (uint32_t i = tid; i < n; i += 1024) {
+        M31 yinv(a.tw.iytw[n + i]);
+        QM31 f0 = ld4(L.circle, 2 * i), f1 = ld4(L.circle, 2 * i + 1);
+        st4(L.cols, i, ld4(L.cols, i) * alpha2 + ((f0 + f1) + alpha * ((f0 - f1) * yinv)));
+      }
+      __syncthreads();
+    }
+    // Merkle tree of the 4 coordinate columns (k_merkle_layer framing: one compression per node)
+    for (uint32_t i = tid; i < n; i += 1024) {
+      uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t m[16] = {L.cols[0][i], L.cols[1][i], L.cols[2][i], L.cols[3][i], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      b2s_compress(h, m);
+      uint4* o = reinterpret_cast<uint4*>(L.merkle[l] + (size_t)i * 8);
+      o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+      o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+    }
+    __syncthreads();
+    for (int k = (int)l - 1; k >= 0; k--) {
+      for (uint32_t i = tid; i < (1u << k); i += 1024) {
+        const uint4* p = reinterpret_cast<const uint4*>(L.merkle[k + 1] + (size_t)i * 16);
+        uint4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+        uint32_t m[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+        uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        b2s_compress(h, m);
+        uint4* o = reinterpret_cast<uint4*>(L.merkle[k] + (size_t)i * 8);
+        o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) chan_mix_root_draw_dev(a.chan, L.merkle[0], a.alphas + 4 * ai, a.roots + 8 * ai);
+    __syncthreads();
+    {  // fold_line into the next layer (k_fold_line)
+      const QM31 alpha = QM31::from_u32(a.alphas + 4 * ai);
+      uint32_t* const* dst = a.layers[l - 1].cols;
+      const uint32_t Lx = a.tw.R - (l + 1);
+      const uint32_t* xt = a.tw.ixtw + (1u << (a.tw.R - 1)) - (1u << (a.tw.R - 1 - Lx));
+      for (uint32_t i = tid; i < n / 2; i += 1024) {
+        M31 xinv(xt[i]);
+        QM31 f0 = ld4(L.cols, 2 * i), f1 = ld4(L.cols, 2 * i + 1);
+        st4(dst, i, (f0 + f1) + alpha * ((f0 - f1) * xinv));
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // ================================================================= host wrappers
@@ -109,23 +167,29 @@ void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st) {
   CM_HIP(hipGetLastError());
 }
 void fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw,
-                           const QM31& alpha, bool accumulate, hipStream_t st) {
+                           const QM31& alpha, bool accumulate, hipStream_t st, const uint32_t* d_alpha) {
   CM_CHECK(log_n >= 2 && log_n <= tw.R, "fold_circle: bad log size");
   Ptr4 d; CPtr4 s;
   for (int i = 0; i < 4; i++) { d.p[i] = dst[i]; s.p[i] = src[i]; }
   uint32_t n = 1u << (log_n - 1);
   hipLaunchKernelGGL(k_fold_circle, dim3((n + 255) / 256), dim3(256), 0, st, d, s, log_n, view(tw), alpha.a.a.v, alpha.a.b.v,
-                     alpha.b.a.v, alpha.b.b.v, accumulate ? 1 : 0);
+                     alpha.b.a.v, alpha.b.b.v, accumulate ? 1 : 0, d_alpha);
   CM_HIP(hipGetLastError());
 }
 void fold_line(uint32_t* const out[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw, const QM31& alpha,
-               hipStream_t st) {
+               hipStream_t st, const uint32_t* d_alpha) {
   CM_CHECK(log_n >= 1 && log_n + 1 <= tw.R, "fold_line: bad log size");
   Ptr4 d; CPtr4 s;
   for (int i = 0; i < 4; i++) { d.p[i] = out[i]; s.p[i] = src[i]; }
   uint32_t n = 1u << (log_n - 1);
   hipLaunchKernelGGL(k_fold_line, dim3((n + 255) / 256), dim3(256), 0, st, d, s, log_n, view(tw), alpha.a.a.v, alpha.a.b.v,
-                     alpha.b.a.v, alpha.b.b.v);
+                     alpha.b.a.v, alpha.b.b.v, d_alpha);
+  CM_HIP(hipGetLastError());
+}
+void fri_tail(const FriTailArgs& a, hipStream_t st) {
+  CM_CHECK(a.top_log <= FRI_TAIL_MAX_LOG && a.last_log < a.top_log, "fri_tail: bad layer range");
+  KProfScope kp("k_fri_tail", 0.0, st);
+  hipLaunchKernelGGL(k_fri_tail, dim3(1), dim3(1024), 0, st, a);
   CM_HIP(hipGetLastError());
 }
 

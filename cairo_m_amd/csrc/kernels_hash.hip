@@ -12,48 +12,9 @@
 #include "device_common.hpp"
 #include "engine.hpp"
 #include "kprof.hpp"
+#include "blake2s_dev.hpp"
 
 namespace cm {
-
-__device__ __constant__ uint32_t B2S_IV_D[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
-                                                0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
-
-__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __funnelshift_r(x, x, n); }
-
-#define CM_G(a, b, c, d, x, y)                 \
-  a = a + b + (x); d = rotr(d ^ a, 16);        \
-  c = c + d;       b = rotr(b ^ c, 12);        \
-  a = a + b + (y); d = rotr(d ^ a, 8);         \
-  c = c + d;       b = rotr(b ^ c, 7);
-
-#define CM_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
-  CM_G(v0, v4, v8, v12, m[s0], m[s1])                                                  \
-  CM_G(v1, v5, v9, v13, m[s2], m[s3])                                                  \
-  CM_G(v2, v6, v10, v14, m[s4], m[s5])                                                 \
-  CM_G(v3, v7, v11, v15, m[s6], m[s7])                                                 \
-  CM_G(v0, v5, v10, v15, m[s8], m[s9])                                                 \
-  CM_G(v1, v6, v11, v12, m[s10], m[s11])                                               \
-  CM_G(v2, v7, v8, v13, m[s12], m[s13])                                                \
-  CM_G(v3, v4, v9, v14, m[s14], m[s15])
-
-// h <- F(h, m, t0=0, t1=0, f0=0, f1=0)
-__device__ __forceinline__ void b2s_compress(uint32_t (&h)[8], const uint32_t (&m)[16]) {
-  uint32_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
-  uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
-  uint32_t v12 = 0x510E527Fu, v13 = 0x9B05688Cu, v14 = 0x1F83D9ABu, v15 = 0x5BE0CD19u;
-  CM_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
-  CM_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
-  CM_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
-  CM_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
-  CM_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
-  CM_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
-  CM_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
-  CM_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
-  CM_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
-  CM_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
-  h[0] ^= v0 ^ v8;  h[1] ^= v1 ^ v9;  h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11;
-  h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
-}
 
 // hashes[i] = hash_node(children (prev[2i], prev[2i+1]) if prev != null, cols[*][i])
 __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const uint32_t* __restrict__ prev,
@@ -223,6 +184,12 @@ __global__ void __launch_bounds__(256) k_grind(const uint32_t* __restrict__ dige
   if (tz >= bits) atomicMin(result, (unsigned long long)nonce);
 }
 
+// chan = {digest[8], n_sent}.  Blake2sChannel::mix_root then draw_felt (host twin: host_channel.hpp).
+__global__ void k_chan_mix_root_draw(uint32_t* chan, const uint32_t* root, uint32_t* felt_out, uint32_t* root_log) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  chan_mix_root_draw_dev(chan, root, felt_out, root_log);
+}
+
 // Decommitment gather: out[q * width + w] = addrs[q][w]  (width 1 = column values, 8 = 32-byte hashes).
 __global__ void k_gather_words(const uint32_t* const* addrs, uint32_t n, uint32_t width, uint32_t* out) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -244,6 +211,10 @@ void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* con
 void merkle_multi(const MerkleMultiArgs& a, double alg_bytes, hipStream_t st) {
   KProfScope kp("k_merkle_multi", alg_bytes, st);
   hipLaunchKernelGGL(k_merkle_multi, dim3((1u << a.top_log) / 256), dim3(256), 0, st, a);
+  CM_HIP(hipGetLastError());
+}
+void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log, hipStream_t st) {
+  hipLaunchKernelGGL(k_chan_mix_root_draw, dim3(1), dim3(64), 0, st, d_chan, d_root, d_felt_out, d_root_log);
   CM_HIP(hipGetLastError());
 }
 void merkle_tail(const MerkleTailArgs& a, hipStream_t st) {

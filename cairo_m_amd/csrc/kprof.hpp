@@ -15,9 +15,11 @@ struct KProf {
   struct Rec { const char* name; double bytes; hipEvent_t a, b; };
   struct Agg { uint64_t calls = 0; double ms = 0, bytes = 0; };
   bool on = false;
+  std::string only;  // when non-empty, only this kernel class is timed (keeps the event overhead out of a timed run)
   std::mutex mu;
   std::vector<Rec> recs;
   std::map<std::string, Agg> agg;
+  std::map<std::string, uint64_t> region_calls;  // extra launches inside timed regions
   static KProf& get() { static KProf k; return k; }
   void flush() {  // resolve pending event pairs (caller has synchronised the stream/device)
     std::lock_guard<std::mutex> lk(mu);
@@ -31,15 +33,56 @@ struct KProf {
       (void)hipEventDestroy(r.b);
     }
     recs.clear();
+    for (auto& kv : region_calls) agg[kv.first].calls += kv.second;
+    region_calls.clear();
   }
   void reset() { flush(); std::lock_guard<std::mutex> lk(mu); agg.clear(); }
+};
+
+// A fork/join region (independent launches spread over side streams) is timed as ONE interval on the main
+// stream: per-launch events on concurrent streams would each include the time spent sharing the GPU.
+// Launch scopes opened inside the region only add their algorithmic bytes / call count to it.
+struct KProfRegion;
+inline KProfRegion*& kprof_current_region() { static thread_local KProfRegion* r = nullptr; return r; }
+struct KProfRegion {
+  bool active;
+  const char* name;
+  double bytes = 0;
+  uint64_t calls = 0;
+  hipEvent_t a, b;
+  hipStream_t st;
+  KProfRegion(const char* nm, hipStream_t s) : name(nm), st(s) {
+    KProf& k = KProf::get();
+    active = k.on && (k.only.empty() || k.only == nm);
+    kprof_current_region() = this;
+    if (!active) return;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, st);
+  }
+  // call after the join, on the main stream
+  void close() {
+    if (kprof_current_region() == this) kprof_current_region() = nullptr;
+    if (!active) return;
+    active = false;
+    (void)hipEventRecord(b, st);
+    KProf& k = KProf::get();
+    std::lock_guard<std::mutex> lk(k.mu);
+    KProf::Rec r{name, bytes, a, b};
+    k.recs.push_back(r);
+    k.region_calls[name] += calls ? calls - 1 : 0;  // flush() counts the record itself as one call
+  }
+  ~KProfRegion() { close(); }
 };
 
 struct KProfScope {
   bool active;
   KProf::Rec r;
   hipStream_t st;
-  KProfScope(const char* name, double bytes, hipStream_t s) : active(KProf::get().on), st(s) {
+  KProfScope(const char* name, double bytes, hipStream_t s) : active(false), st(s) {
+    if (KProfRegion* reg = kprof_current_region()) { reg->bytes += bytes; reg->calls++; return; }
+    KProf& k = KProf::get();
+    active = k.on && (k.only.empty() || k.only == name);
     if (!active) return;
     r.name = name; r.bytes = bytes;
     (void)hipEventCreate(&r.a);

@@ -76,6 +76,9 @@ struct MerkleTree {
       // group of up to MERKLE_MULTI_LEVELS layers per launch (the top layer of a group needs >= 256 nodes)
       int levels = std::min<int>((int)MERKLE_MULTI_LEVELS, log - tail_top);
       if (log < 8) levels = 1;
+      // big layers are throughput-bound: one node per thread with every lane busy beats the fused kernel
+      // (whose parent levels run on half / quarter of the block); fusion pays only once launches are latency-bound
+      if (log >= (int)MERKLE_MULTI_MAX_TOP) levels = 1;
       if (levels == 1) {
         size_t c0 = ci;
         while (ci < cols.size() && col_logs[ci] == (uint32_t)log) ci++;

@@ -88,4 +88,48 @@ void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
   s.off += need;
 }
 
+// ---- fork/join side streams ---------------------------------------------------------------------------
+namespace {
+struct SideStreams {
+  hipStream_t s[Fork::N];
+  hipEvent_t done[Fork::N], fork_ev;
+  SideStreams() {
+    for (int i = 0; i < Fork::N; i++) {
+      CM_HIP(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+      CM_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    CM_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+  }
+};
+SideStreams& side() { static thread_local SideStreams* s = new SideStreams(); return *s; }
+}  // namespace
+
+Fork::Fork(hipStream_t main_stream) : main(main_stream) { CM_HIP(hipEventRecord(side().fork_ev, main)); }
+hipStream_t Fork::stream(int i) {
+  i = ((i % N) + N) % N;
+  SideStreams& ss = side();
+  if (!(used & (1u << i))) {
+    CM_HIP(hipStreamWaitEvent(ss.s[i], ss.fork_ev, 0));
+    used |= 1u << i;
+  }
+  return ss.s[i];
+}
+void Fork::join() {
+  if (joined) return;
+  joined = true;
+  SideStreams& ss = side();
+  for (int i = 0; i < N; i++)
+    if (used & (1u << i)) {
+      CM_HIP(hipEventRecord(ss.done[i], ss.s[i]));
+      CM_HIP(hipStreamWaitEvent(main, ss.done[i], 0));
+    }
+}
+Fork::~Fork() {
+  // never leave side work un-joined (exception paths): block the host instead of throwing from a destructor
+  if (!joined) {
+    SideStreams& ss = side();
+    for (int i = 0; i < N; i++) if (used & (1u << i)) (void)hipStreamSynchronize(ss.s[i]);
+  }
+}
+
 }  // namespace cm

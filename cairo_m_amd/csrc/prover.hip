@@ -12,6 +12,7 @@
 #include "host_channel.hpp"
 #include "proof.hpp"
 #include "kprof.hpp"
+#include "point_eval.hpp"
 #include <chrono>
 #include <memory>
 #include <mutex>
@@ -178,60 +179,6 @@ static Twiddles* cached_twiddles(uint32_t R, hipStream_t st) {
   return t;
 }
 
-// ---- host point evaluator (stwo FrameworkComponent::evaluate_constraint_quotients_at_point) ------------
-struct HostRelations {
-  QM31 z[air::N_RELATIONS], alpha_pow[air::N_RELATIONS][air::MAX_REL_SIZE];
-};
-struct PointEvalH : air::LogupStream<PointEvalH, QM31, QM31> {
-  const QM31 *tr, *it, *pp;
-  const HostRelations* rels;
-  const QM31* coeff;
-  int n_base;
-  QM31 cumsum_shift, prev_col, acc;
-  int ci = 0, ii = 0, kb = 0, kl = 0;
-  QM31 next() { return tr[ci++]; }
-  QM31 preproc(int id) { return pp[id]; }
-  QM31 c(uint32_t v) { return QM31(M31(v)); }
-  void constraint(QM31 x) { acc += coeff[kb++] * x; }
-  void constraint_q(QM31 x) { acc += coeff[n_base + kl++] * x; }
-  QM31 combine(int r, const QM31* v, int n) {
-    QM31 a;
-    for (int i = 0; i < n; i++) a += rels->alpha_pow[r][i] * v[i];
-    return a - rels->z[r];
-  }
-  QM31 ef_from(QM31 m) { return m; }
-  void on_entry(int, QM31, const QM31*, int) {}
-  static QM31 combine_ef(const QM31* c4) {
-    return c4[0] + c4[1] * QM31(M31(0), M31(1), M31(0), M31(0)) + c4[2] * QM31(M31(0), M31(0), M31(1), M31(0)) +
-           c4[3] * QM31(M31(0), M31(0), M31(0), M31(1));
-  }
-  void emit_batch(bool last, QM31 num, QM31 den) {
-    if (!last) {
-      QM31 cur = combine_ef(it + ii);
-      ii += 4;
-      QM31 diff = cur - prev_col;
-      prev_col = cur;
-      constraint_q(diff * den - num);
-    } else {
-      QM31 pr[4], cu[4];
-      for (int k = 0; k < 4; k++) { pr[k] = it[ii + 2 * k]; cu[k] = it[ii + 2 * k + 1]; }
-      ii += 8;
-      constraint_q((combine_ef(cu) - combine_ef(pr) - prev_col + cumsum_shift) * den - num);
-    }
-  }
-};
-static QM31 point_eval(int cid, const QM31* tr, const QM31* it, const QM31* pp, const HostRelations& rel, const QM31* coeff,
-                       int n_base, QM31 shift) {
-  PointEvalH e;
-  e.tr = tr; e.it = it; e.pp = pp; e.rels = &rel; e.coeff = coeff; e.n_base = n_base; e.cumsum_shift = shift;
-  switch (cid) {
-#define CM_X(id, T) case air::id: air::T::eval(e); break;
-    AIR_ALL_COMPONENTS(CM_X)
-#undef CM_X
-  }
-  return e.acc;
-}
-
 // coset_vanishing of CanonicCoset(log).coset at p (QM31 or M31 point)
 template <class F>
 static F coset_vanishing_canonic(uint32_t log, CPoint<F> p) {
@@ -354,16 +301,6 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     }
     tr_evals.alloc(logs, st);
   }
-  for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++)
-    launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), st);
-  launch_memory_trace(din.init_mem.p, (uint32_t)in.n_initial_memory, din.fin_mem.p, (uint32_t)in.n_final_memory, in.initial_root,
-                      in.final_root, clog[air::C_MEMORY], tr_evals.dev(tr0[air::C_MEMORY]), st);
-  launch_merkle_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree, in.initial_root,
-                      in.final_root, clog[air::C_MERKLE], tr_evals.dev(tr0[air::C_MERKLE]), st);
-  launch_clock_update_trace(din.clock_updates.p, (uint32_t)in.n_clock_updates, clog[air::C_CLOCK_UPDATE],
-                            tr_evals.dev(tr0[air::C_CLOCK_UPDATE]), st);
-  launch_poseidon2_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree,
-                         clog[air::C_POSEIDON2], tr_evals.dev(tr0[air::C_POSEIDON2]), st);
   {
     // multiplicity columns = histograms over every lookup of every opcode component (components/mod.rs:139-160)
     DevBuf flag(4);
@@ -376,8 +313,24 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     CM_HIP(hipMemsetAsync(h.rc16, 0, 4u << 16, st));
     CM_HIP(hipMemsetAsync(h.rc20, 0, 4u << 20, st));
     CM_HIP(hipMemsetAsync(h.bitwise, 0, 4u << 18, st));
-    for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++)
-      launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, st);
+    // components are independent: fork over side streams (trace then histogram of one component stay ordered)
+    KProfRegion kreg("k_trace_gen(region)", st);
+    Fork fk(st);
+    for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++) {
+      hipStream_t sc = fk.stream(c);
+      launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
+      launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, sc);
+    }
+    launch_memory_trace(din.init_mem.p, (uint32_t)in.n_initial_memory, din.fin_mem.p, (uint32_t)in.n_final_memory, in.initial_root,
+                        in.final_root, clog[air::C_MEMORY], tr_evals.dev(tr0[air::C_MEMORY]), fk.stream(air::C_MEMORY));
+    launch_merkle_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree, in.initial_root,
+                        in.final_root, clog[air::C_MERKLE], tr_evals.dev(tr0[air::C_MERKLE]), fk.stream(air::C_MERKLE));
+    launch_clock_update_trace(din.clock_updates.p, (uint32_t)in.n_clock_updates, clog[air::C_CLOCK_UPDATE],
+                              tr_evals.dev(tr0[air::C_CLOCK_UPDATE]), fk.stream(air::C_CLOCK_UPDATE));
+    launch_poseidon2_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree,
+                           clog[air::C_POSEIDON2], tr_evals.dev(tr0[air::C_POSEIDON2]), fk.stream(air::C_POSEIDON2));
+    fk.join();
+    kreg.close();
     uint32_t f = 0;
     CM_HIP(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
@@ -418,13 +371,17 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   {
     DevBuf d_sums(air::N_COMPONENTS * 16);
     std::vector<LogupTailJob> jobs(air::N_COMPONENTS);
+    KProfRegion kreg("k_logup(region)", st);
+    Fork fk(st);
     for (int c = 0; c < air::N_COMPONENTS; c++) {
       const air::ComponentInfo& info = air::component_info(c);
       launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
-                   drel.as<DevRelations>(), it_evals.dev(it0[c]), st);
+                   drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(c));
       for (int k = 0; k < 4; k++) jobs[c].col[k] = it_evals.ptrs[it0[c] + info.n_interaction - 4 + k];
       jobs[c].log_size = clog[c];
     }
+    fk.join();
+    kreg.close();
     logup_finalize_all(jobs, d_sums.u32(), st);
     uint32_t sums[air::N_COMPONENTS * 4];
     CM_HIP(hipMemcpyAsync(sums, d_sums.p, sizeof(sums), hipMemcpyDeviceToHost, st));
@@ -468,31 +425,73 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   for (size_t g = 0; g < total_constraints; g++) powers[g].to_u32(&powers_w[4 * g]);
   DevBuf d_powers = upload(powers_w, st);
   std::map<uint32_t, ColumnSet> accs;  // evaluation log -> 4 accumulator columns
-  for (int c = 0; c < air::N_COMPONENTS; c++) {
-    uint32_t el = clog[c] + 1;
-    if (!accs.count(el)) {
-      accs[el].alloc(std::vector<uint32_t>(4, el), st);
-      CM_HIP(hipMemsetAsync(accs[el].buf.p, 0, accs[el].buf.bytes, st));
-    }
+  std::map<uint32_t, std::vector<int>> cgroups;
+  for (int c = 0; c < air::N_COMPONENTS; c++) cgroups[clog[c] + 1].push_back(c);
+  for (auto& kv : cgroups) {
+    accs[kv.first].alloc(std::vector<uint32_t>(4, kv.first), st);
+    CM_HIP(hipMemsetAsync(accs[kv.first].buf.p, 0, accs[kv.first].buf.bytes, st));
   }
   CM_CHECK(cfg.log_blowup_factor == 1, "constraint evaluation reuses the committed LDE: log_blowup_factor must be 1");
-  for (int c = 0; c < air::N_COMPONENTS; c++) {
-    const air::ComponentInfo& info = air::component_info(c);
-    ConstraintArgs a;
-    a.tr = (const uint32_t* const*)P.trees[1].lde.dev(tr0[c]);
-    a.it = (const uint32_t* const*)P.trees[2].lde.dev(it0[c]);
-    a.pp = (const uint32_t* const*)P.trees[0].lde.dev();
-    a.rels = drel.as<DevRelations>();
-    a.coeff = d_powers.u32() + 4 * coff[c];
-    a.acc = accs[clog[c] + 1].dev();
-    a.log_size = clog[c];
-    a.n_base = info.n_base_constraints;
-    (pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]))).to_u32(a.cumsum_shift);
-    for (uint32_t k = 0; k < 2; k++) {
-      CPoint<M31> p = point_at_index(domain_index_at(clog[c] + 1, k));
-      a.denom_inv[k] = inv(coset_vanishing_canonic<M31>(clog[c], p)).v;
+  {
+    // Components are independent except for the shared per-size accumulator.  Small sizes (many idle
+    // components of 2^4 rows, each a latency-bound launch) get a private zeroed accumulator slot per
+    // component and run concurrently on side streams; the slots are summed afterwards (field addition is
+    // exact, so the order is irrelevant).  Large sizes keep the shared accumulator and one stream per size.
+    constexpr uint32_t SLOT_MAX_LOG = 15;
+    struct SlotGroup { uint32_t el; uint32_t n; size_t off_words; size_t tab0; };
+    std::vector<SlotGroup> sgroups;
+    std::vector<int> slot_of(air::N_COMPONENTS, -1);
+    std::vector<uint32_t*> slot_tab;
+    size_t slot_words = 0;
+    for (auto& kv : cgroups)
+      if (kv.second.size() > 1 && kv.first <= SLOT_MAX_LOG) {
+        SlotGroup g{kv.first, (uint32_t)kv.second.size(), slot_words, slot_tab.size()};
+        for (size_t k = 0; k < kv.second.size(); k++) slot_of[kv.second[k]] = (int)(slot_tab.size() / 4 + k);
+        slot_tab.resize(slot_tab.size() + 4 * kv.second.size());
+        slot_words += (size_t)4 * kv.second.size() << kv.first;
+        sgroups.push_back(g);
+      }
+    DevBuf slots(slot_words * 4), d_slot_tab;
+    if (slot_words) {
+      CM_HIP(hipMemsetAsync(slots.p, 0, slot_words * 4, st));
+      for (auto& g : sgroups)
+        for (uint32_t k = 0; k < 4 * g.n; k++) slot_tab[g.tab0 + k] = slots.u32() + g.off_words + ((size_t)k << g.el);
+      d_slot_tab = upload(slot_tab, st);
     }
-    launch_constraints(c, a, st);
+    KProfRegion kreg("k_constraints(region)", st);
+    Fork fk(st);
+    int gi = 0, small_rr = 0;
+    // large groups first (descending size) so the long kernels start early
+    for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it, ++gi) {
+      for (int c : it->second) {
+        const air::ComponentInfo& info = air::component_info(c);
+        ConstraintArgs a;
+        a.tr = (const uint32_t* const*)P.trees[1].lde.dev(tr0[c]);
+        a.it = (const uint32_t* const*)P.trees[2].lde.dev(it0[c]);
+        a.pp = (const uint32_t* const*)P.trees[0].lde.dev();
+        a.rels = drel.as<DevRelations>();
+        a.coeff = d_powers.u32() + 4 * coff[c];
+        hipStream_t sc;
+        if (slot_of[c] >= 0) {
+          a.acc = d_slot_tab.as<uint32_t*>() + 4 * slot_of[c];
+          sc = fk.stream(4 + (small_rr++ % 4));
+        } else {
+          a.acc = accs[it->first].dev();
+          sc = fk.stream(gi % 4);
+        }
+        a.log_size = clog[c];
+        a.n_base = info.n_base_constraints;
+        (pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]))).to_u32(a.cumsum_shift);
+        for (uint32_t k = 0; k < 2; k++) {
+          CPoint<M31> p = point_at_index(domain_index_at(clog[c] + 1, k));
+          a.denom_inv[k] = inv(coset_vanishing_canonic<M31>(clog[c], p)).v;
+        }
+        launch_constraints(c, a, sc);
+      }
+    }
+    fk.join();
+    kreg.close();
+    for (auto& g : sgroups) sum_slots(accs[g.el].dev(), slots.u32() + g.off_words, g.n, g.el, st);
   }
   P.tick("constraints");
   // DomainEvaluationAccumulator::finalize: ascending sizes, interpolate / extend / add
@@ -591,7 +590,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   // sanity check (stwo prove): composition OODS value == constraints at the sampled mask values
   {
     QM31 c4[4] = {pf.sampled_values[3][0][0], pf.sampled_values[3][1][0], pf.sampled_values[3][2][0], pf.sampled_values[3][3][0]};
-    QM31 comp = PointEvalH::combine_ef(c4);
+    QM31 comp = combine_ef(c4);
     QM31 ppv[air::N_PREPROC];
     for (int i = 0; i < air::N_PREPROC; i++) ppv[i] = pf.sampled_values[0][i][0];
     QM31 sum;
@@ -700,29 +699,75 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   P.tick("quotients");
 
   // ---- FRI commit ----
+  // The whole commit phase is enqueued without a host round trip: after each layer's Merkle tree a 1-thread
+  // kernel does the transcript step (mix_root, draw the folding challenge) on a device copy of the channel,
+  // and the fold kernels read the challenge from device memory.  The host replays the same steps on its own
+  // channel afterwards from the recorded roots and checks that the challenges agree.
   MerkleTree first_tree;
+  const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup_factor;
+  uint32_t layer_log = q_logs[0] - 1;
+  const uint32_t n_inner = layer_log > last_log ? layer_log - last_log : 0;
+  DevBuf d_chan(64), d_alphas((size_t)(n_inner + 1) * 16), d_roots((size_t)(n_inner + 1) * 32);
+  {
+    uint32_t cw[9];
+    memcpy(cw, ch.digest.data(), 32);
+    cw[8] = ch.n_sent;
+    stage_upload(d_chan.p, cw, sizeof(cw), st);
+  }
   {
     std::vector<const uint32_t*> cols;
     std::vector<uint32_t> logs;
     for (size_t k = 0; k < quotients.size(); k++) for (int c = 0; c < 4; c++) { cols.push_back(quotients[k].ptrs[c]); logs.push_back(q_logs[k]); }
     first_tree.commit(cols, logs, st);
-    first_tree.root(pf.fri_first.commitment.data(), st);
-    ch.mix_root(pf.fri_first.commitment);
+    chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
   }
-  QM31 circle_alpha = ch.draw_felt();
   struct InnerLayer { ColumnSet eval; uint32_t log; MerkleTree tree; hostch::Hash32 root; };
   std::vector<std::unique_ptr<InnerLayer>> inner;
-  uint32_t layer_log = q_logs[0] - 1;
-  const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup_factor;
   ColumnSet layer;
   layer.alloc(std::vector<uint32_t>(4, layer_log), st, false);
   CM_HIP(hipMemsetAsync(layer.buf.p, 0, layer.buf.bytes, st));
   size_t qi = 0;
+  const QM31 unused_alpha;
   while (layer_log > last_log) {
+    if (layer_log <= FRI_TAIL_MAX_LOG) {
+      // every remaining layer in one launch (k_fri_tail); buffers are laid out here so that the decommitment
+      // code sees ordinary InnerLayer objects afterwards
+      FriTailArgs ta;
+      memset(&ta, 0, sizeof(ta));
+      ta.tw = view(*P.tw);
+      ta.top_log = layer_log; ta.last_log = last_log;
+      ta.first_index = (uint32_t)inner.size() + 1;
+      ta.chan = d_chan.u32(); ta.alphas = d_alphas.u32(); ta.roots = d_roots.u32();
+      for (uint32_t l = layer_log; l > last_log; l--) {
+        std::unique_ptr<InnerLayer> il(new InnerLayer());
+        il->log = l;
+        if (l == layer_log) il->eval = std::move(layer);
+        else il->eval.alloc(std::vector<uint32_t>(4, l), st, false);
+        FriTailLayer& tl = ta.layers[l];
+        for (int c = 0; c < 4; c++) tl.cols[c] = il->eval.ptrs[c];
+        while (qi < quotients.size() && q_logs[qi] - 1 == l) {
+          CM_CHECK(tl.circle[0] == nullptr, "fri: two quotient groups of one size");
+          for (int c = 0; c < 4; c++) tl.circle[c] = quotients[qi].ptrs[c];
+          qi++;
+        }
+        MerkleTree& mt = il->tree;
+        mt.cols.assign(il->eval.ptrs.begin(), il->eval.ptrs.end());
+        mt.col_logs.assign(4, l);
+        mt.layers.resize(l + 1);
+        for (uint32_t k = 0; k <= l; k++) { mt.layers[k].alloc((size_t)32 << k); tl.merkle[k] = mt.layers[k].u32(); }
+        inner.push_back(std::move(il));
+      }
+      layer = ColumnSet();
+      layer.alloc(std::vector<uint32_t>(4, last_log), st, false);
+      for (int c = 0; c < 4; c++) ta.layers[last_log].cols[c] = layer.ptrs[c];
+      fri_tail(ta, st);
+      layer_log = last_log;
+      break;
+    }
     while (qi < quotients.size() && q_logs[qi] - 1 == layer_log) {
       const uint32_t* src[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
       uint32_t* dst[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
-      fold_circle_into_line(dst, src, q_logs[qi], *P.tw, circle_alpha, true, st);
+      fold_circle_into_line(dst, src, q_logs[qi], *P.tw, unused_alpha, true, st, d_alphas.u32());
       qi++;
     }
     std::unique_ptr<InnerLayer> il(new InnerLayer());
@@ -730,14 +775,13 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     il->eval = std::move(layer);
     std::vector<const uint32_t*> cols(il->eval.ptrs.begin(), il->eval.ptrs.end());
     il->tree.commit(cols, std::vector<uint32_t>(4, layer_log), st);
-    il->tree.root(il->root.data(), st);
-    ch.mix_root(il->root);
-    QM31 alpha = ch.draw_felt();
+    const size_t li = inner.size() + 1;
+    chan_mix_root_draw(d_chan.u32(), il->tree.layers[0].u32(), d_alphas.u32() + 4 * li, d_roots.u32() + 8 * li, st);
     layer = ColumnSet();
     layer.alloc(std::vector<uint32_t>(4, layer_log - 1), st, false);
     const uint32_t* src[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
     uint32_t* dst[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
-    fold_line(dst, src, layer_log, *P.tw, alpha, st);
+    fold_line(dst, src, layer_log, *P.tw, unused_alpha, st, d_alphas.u32() + 4 * li);
     layer_log--;
     inner.push_back(std::move(il));
   }
@@ -749,11 +793,25 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     std::vector<uint32_t> pos(n);
     for (uint32_t i = 0; i < n; i++) pos[i] = i;
     std::vector<QM31> vals;
+    std::vector<uint32_t> h_alphas((size_t)(n_inner + 1) * 4), h_roots((size_t)(n_inner + 1) * 8);
+    CM_HIP(hipMemcpyAsync(h_alphas.data(), d_alphas.p, h_alphas.size() * 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(h_roots.data(), d_roots.p, h_roots.size() * 4, hipMemcpyDeviceToHost, st));
     {
       GatherBatch gb;
       QGather g = plan_gather_q(c4, pos, gb);
-      gb.run(st);
+      gb.run(st);  // synchronises the stream: roots / challenges are on the host now
       finish_gather_q(g, gb, vals);
+    }
+    // host replay of the device-side transcript steps
+    CM_CHECK(inner.size() == n_inner, "fri: layer count mismatch");
+    for (size_t li = 0; li <= n_inner; li++) {
+      hostch::Hash32 root;
+      memcpy(root.data(), &h_roots[8 * li], 32);
+      ch.mix_root(root);
+      QM31 alpha = ch.draw_felt();
+      CM_CHECK(alpha == QM31::from_u32(&h_alphas[4 * li]), "fri: device transcript diverged from the host channel");
+      if (li == 0) pf.fri_first.commitment = root;
+      else inner[li - 1]->root = root;
     }
     for (uint32_t l = 0; l < last_log; l++) {
       uint32_t stride = 1u << l;
@@ -921,6 +979,12 @@ int32_t cm_proof_commitments(const cm_proof* p, uint8_t roots[4][32]) {
 int32_t cm_kprof_enable(int32_t on) {
   cm::KProf::get().reset();
   cm::KProf::get().on = on != 0;
+  cm::KProf::get().only.clear();
+  return 0;
+}
+// time only one kernel class (name as reported by cm_kprof_report); NULL / "" = all classes
+int32_t cm_kprof_filter(const char* name) {
+  cm::KProf::get().only = name ? name : "";
   return 0;
 }
 // JSON: {"kernel": {"calls": n, "ms": total, "bytes": algorithmic bytes}, ...}

@@ -215,6 +215,8 @@ int32_t cm_proof_commitments(const cm_proof* p, uint8_t roots[4][32]);
 /* Optional HIP-event kernel timing on the launch stream (bench.py `roofline`). */
 int32_t cm_kprof_enable(int32_t on);
 int32_t cm_kprof_report(char* buf, size_t buf_len);
+/* Restrict the timing to one kernel class (a key of cm_kprof_report); NULL or "" = every class. */
+int32_t cm_kprof_filter(const char* name);
 /* cells = sum over committed columns of trees 0,1,2 of 2^log_size. */
 int32_t cm_proof_stats(const cm_proof* p, uint64_t* cells, uint64_t* steps, double* phase_ms, uint32_t n_phases);
 

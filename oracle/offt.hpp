@@ -4,15 +4,19 @@
 // `tree_builder.extend_evals` / `.commit` (crates/prover/src/prover.rs:71-73, 80-82, 100-102).
 //
 // Basis: coefficient index bit 0 <-> y, bit 1 <-> x, bit k>=2 <-> pi^{k-1}(x), pi(x)=2x^2-1.
-// Twiddles are recomputed per call from the group law (no shared tables with the product).
+// Twiddles are computed from the group law (no shared tables with the product) and memoised per
+// (domain log size, layer) so that the many columns of one proof do not redo the same point walk.
 #pragma once
+#include <map>
+#include <memory>
+#include <mutex>
 #include "ocircle.hpp"
 
 namespace orc {
 
 // Twiddles of layer `layer` (0 = circle/y layer, i>=1 = line layers) for the canonic domain of
 // log size n:  tw[h] for butterfly group h.
-inline std::vector<M31> layer_twiddles(uint32_t n, uint32_t layer) {
+inline std::vector<M31> compute_layer_twiddles(uint32_t n, uint32_t layer) {
   Coset half = CanonicCoset(n).half_coset();  // size 2^(n-1)
   if (layer == 0) {
     size_t cnt = (size_t)1 << (n - 1);
@@ -35,6 +39,19 @@ inline std::vector<M31> layer_twiddles(uint32_t n, uint32_t layer) {
   return t;
 }
 
+// memoised (n, layer, inverse?) -> table; entries are never evicted (a few tens of MB for the test sizes)
+inline const std::vector<M31>& layer_twiddles(uint32_t n, uint32_t layer, bool inverse = false) {
+  static std::mutex mu;
+  static std::map<uint64_t, std::unique_ptr<std::vector<M31>>> cache;
+  const uint64_t key = ((uint64_t)n << 33) | ((uint64_t)layer << 1) | (inverse ? 1u : 0u);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return *it->second;
+  std::unique_ptr<std::vector<M31>> t(new std::vector<M31>(compute_layer_twiddles(n, layer)));
+  if (inverse) for (auto& x : *t) x = x.inverse();
+  return *(cache[key] = std::move(t));
+}
+
 // values: bit-reversed evaluations on CanonicCoset(n).circle_domain(); returns coefficients.
 inline std::vector<M31> interpolate(std::vector<M31> values) {
   size_t N = values.size();
@@ -42,8 +59,7 @@ inline std::vector<M31> interpolate(std::vector<M31> values) {
   while (((size_t)1 << n) < N) n++;
   assert(n >= 1);
   for (uint32_t layer = 0; layer < n; layer++) {
-    std::vector<M31> tw = layer_twiddles(n, layer);
-    for (auto& t : tw) t = t.inverse();
+    const std::vector<M31>& tw = layer_twiddles(n, layer, true);
     size_t stride = (size_t)1 << layer;
     for (size_t h = 0; h < (N >> (layer + 1)); h++) {
       for (size_t l = 0; l < stride; l++) {
@@ -65,7 +81,7 @@ inline std::vector<M31> evaluate(const std::vector<M31>& coeffs, uint32_t n) {
   std::vector<M31> values(N);
   for (size_t i = 0; i < coeffs.size(); i++) values[i] = coeffs[i];
   for (int layer = (int)n - 1; layer >= 0; layer--) {
-    std::vector<M31> tw = layer_twiddles(n, (uint32_t)layer);
+    const std::vector<M31>& tw = layer_twiddles(n, (uint32_t)layer);
     size_t stride = (size_t)1 << layer;
     for (size_t h = 0; h < (N >> (layer + 1)); h++) {
       for (size_t l = 0; l < stride; l++) {

@@ -4,6 +4,9 @@
 //   FriProver::{commit, decommit}  (PARITY UNPINNED — Stwo not vendored; restated from upstream).
 // Scalar/OpenMP, obviously-correct forms (per-element inverses, recomputed twiddles).
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "oair.hpp"
 #include "offt.hpp"
 #include "omerkle.hpp"
@@ -442,11 +445,24 @@ struct ProveOutput {
   Relations relations;
 };
 
+// optional phase timing to stderr (ORC_TIMING=1) — used to find the oracle's own slow spots
+struct OrcTick {
+  bool on; std::chrono::steady_clock::time_point t;
+  OrcTick() : on(getenv("ORC_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void operator()(const char* what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[oracle] %-22s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+#define ORC_TICK(x) tick(x)
 inline ProveOutput prove_segment(const cm_prover_input& in, const PcsConfig& cfg, bool keep_traces = false) {
   ProveOutput out;
   Proof& pf = out.proof;
   pf.config = cfg;
   Channel ch;
+  OrcTick tick;
   // PcsConfig::mix_into
   ch.mix_u64(cfg.pow_bits);
   ch.mix_u64(cfg.log_blowup);
@@ -458,11 +474,14 @@ inline ProveOutput prove_segment(const cm_prover_input& in, const PcsConfig& cfg
   mix_public_data(pf.public_data, ch);
   // tree 0: preprocessed
   std::vector<Col> pp = preprocessed_columns();
+  ORC_TICK("preproc gen");
   { std::vector<Col> c = pp; pcs.commit_evals(std::move(c), ch); }
+  ORC_TICK("preproc commit");
   // tree 1: execution trace
   std::string err;
   std::vector<ComponentTrace> cts = write_traces(in, err);
   if (!err.empty()) throw std::runtime_error(err);
+  ORC_TICK("write_traces");
   for (auto& ct : cts) { pf.claim_log_sizes.push_back(ct.log_size); ch.mix_u64(ct.log_size); }
   std::vector<TraceLocation> loc(cts.size());
   {
@@ -470,17 +489,20 @@ inline ProveOutput prove_segment(const cm_prover_input& in, const PcsConfig& cfg
     for (size_t c = 0; c < cts.size(); c++) { loc[c].tr0 = cols.size(); for (auto& col : cts[c].trace) cols.push_back(col); }
     pcs.commit_evals(std::move(cols), ch);
   }
+  ORC_TICK("trace commit");
   pf.interaction_pow = grind(ch, 2);  // relations::INTERACTION_POW_BITS
   ch.mix_u64(pf.interaction_pow);
   Relations rel = draw_relations(ch);
   // tree 2: interaction trace
   for (auto& ct : cts) gen_interaction_dispatch(ct, rel, pp);
+  ORC_TICK("interaction gen");
   for (auto& ct : cts) { pf.claimed_sums.push_back(ct.claimed_sum); ch.mix_felts(&ct.claimed_sum, 1); }
   {
     std::vector<Col> cols;
     for (size_t c = 0; c < cts.size(); c++) { loc[c].it0 = cols.size(); for (auto& col : cts[c].interaction) cols.push_back(col); }
     pcs.commit_evals(std::move(cols), ch);
   }
+  ORC_TICK("interaction commit");
   for (int t = 0; t < 3; t++) for (auto l : pcs.trees[t].poly_logs) out.cells += (uint64_t)1 << l;
   // ---- stwo prove ----
   QM31 random_coeff = ch.draw_felt();
@@ -504,6 +526,7 @@ inline ProveOutput prove_segment(const cm_prover_input& in, const PcsConfig& cfg
       g += air::component_info(cts[c].cid).n_constraints;
     }
   }
+  ORC_TICK("constraints");
   std::vector<Col> comp_poly;  // DomainEvaluationAccumulator::finalize
   for (auto& kv : accs) {
     std::vector<Col> vals = kv.second;
@@ -517,6 +540,7 @@ inline ProveOutput prove_segment(const cm_prover_input& in, const PcsConfig& cfg
   }
   if (ilog2(comp_poly[0].size()) != comp_log) throw std::runtime_error("composition log size mismatch");
   pcs.commit_polys(std::move(comp_poly), ch);
+  ORC_TICK("composition commit");
   PointQ oods = random_point(ch);
   // mask points
   std::vector<std::vector<std::vector<PointQ>>> pts(4);
@@ -543,6 +567,7 @@ inline ProveOutput prove_segment(const cm_prover_input& in, const PcsConfig& cfg
     for (auto& t : pf.sampled_values) for (auto& c : t) for (auto& s : c) flat.push_back(s);
     ch.mix_felts(flat);
   }
+  ORC_TICK("oods sampling");
   // sanity check: composition OODS value == constraints evaluated on the sampled mask (stwo prove)
   {
     QM31 comp_at_oods = PointEval::combine_ef(std::vector<QM31>{pf.sampled_values[3][0][0], pf.sampled_values[3][1][0],
@@ -589,6 +614,7 @@ inline ProveOutput prove_segment(const cm_prover_input& in, const PcsConfig& cfg
   {
     std::vector<const Column*> ptrs;
     for (auto& q : quotients) for (auto& c : q) ptrs.push_back(&c);
+    ORC_TICK("quotients");
     first_tree = MerkleProver::commit(ptrs);
     ch.mix_root(first_tree.root());
   }
@@ -647,6 +673,7 @@ inline ProveOutput prove_segment(const cm_prover_input& in, const PcsConfig& cfg
     pf.last_layer_log_size = cfg.log_last_layer;
     ch.mix_felts(pf.last_layer_poly);
   }
+  ORC_TICK("fri commit");
   pf.proof_of_work = grind(ch, cfg.pow_bits);
   ch.mix_u64(pf.proof_of_work);
   // FRI decommit

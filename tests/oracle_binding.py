@@ -1,5 +1,7 @@
 """ctypes binding of oracle/liboracle.so — the CPU restatement used as the parity checker."""
 import ctypes as C
+import os
+import os
 import numpy as np
 
 _u32p = C.POINTER(C.c_uint32)
@@ -9,8 +11,15 @@ def _p(a):
     return a.ctypes.data_as(_u32p)
 
 
+def oracle_threads():
+    """OpenMP threads the oracle runs with: its loops are short, so beyond a few tens of threads the
+    fork/join cost dominates (a 256-core host is slower than an 8-core one)."""
+    return int(os.environ.get("ORACLE_THREADS", min(16, os.cpu_count() or 1)))
+
+
 class Oracle:
     def __init__(self, so):
+        os.environ.setdefault("OMP_NUM_THREADS", str(oracle_threads()))  # read by libgomp when it loads
         self.L = C.CDLL(so)
         self.L.orc_grind.restype = C.c_uint64
 
