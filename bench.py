@@ -25,6 +25,22 @@ HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s 
 MODEL_BYTES_PER_CELL = 52.0  # SURVEY §8d algorithmic-bytes model for the whole path
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of one kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE need separate passes, so bench.py cannot collect them live; tools/pmc_traffic.py makes the
+    file from `rocprofv3 --pmc` runs of this same command).  None when no file covers the class."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        c = d["classes"].get(kernel_class)
+        return (c["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if c else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def cpu_baseline(sample_n):
     """Oracle (CPU restatement, 'port') on a bounded sample of the same workload family."""
     import subprocess
@@ -51,7 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--fib-n", type=int, default=FIB_N)
-    ap.add_argument("--cpu-sample-n", type=int, default=20)
+    ap.add_argument("--cpu-sample-n", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kprof", action="store_true", help="debug: no in-library HIP-event kernel timing")
     args = ap.parse_args()
@@ -131,8 +147,9 @@ def main():
         if dom:
             name, k = dom
             achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(name)
             roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_ms": k["ms"] / k["calls"], "launches": k["calls"],
                         "algorithmic_bytes_per_launch": k["bytes"] / k["calls"],
                         "whole_path_model": {"bytes_per_cell": MODEL_BYTES_PER_CELL,

@@ -32,6 +32,10 @@ size_t eval_at_point_scratch_words(uint32_t ncols, uint32_t n);
 void eval_at_point_batch(const uint32_t* const* d_coeffs, uint32_t ncols, uint32_t n, const QM31& px, const QM31& py,
                          uint32_t* d_scratch, uint32_t* d_out, hipStream_t st);
 
+// every (log size, point) sampling group of a proof in three launches; d_out receives 4 * ncols words per job
+struct EapJob { uint32_t log_n, ncols; const uint32_t* const* d_coeffs; QM31 px, py; uint32_t* d_out; };
+void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st);
+
 // Merkle
 void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
                   uint32_t* d_out, hipStream_t st);

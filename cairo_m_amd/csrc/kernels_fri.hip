@@ -38,11 +38,46 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
   for (uint32_t b = 0; b < a.n_batches; b++) {
     const QuotientBatch& qb = a.batches[b];
     QM31 num;
-    if (live)
+    if (S == 1) {
+      // Large domains are one row per lane: the per-column term coef_k * f_k(row) is accumulated as raw 64-bit
+      // products (4 per coordinate fit in a u64: 4 * (2^31-1)^2 + 2^32 < 2^64) and folded once per group of 4,
+      // and 8 column loads are issued before any arithmetic so the lane keeps 8 HBM requests in flight
+      // (one load + one QM31 multiply-add at a time ran at ~1 TB/s: latency-bound, not bandwidth-bound).
+      if (live) {
+        unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;  // < 2^32 between groups
+        auto fold = [](unsigned long long x) -> unsigned long long {
+          x = (x & P) + (x >> 31);
+          return (x & P) + (x >> 31);
+        };
+        uint32_t k = qb.begin;
+        for (; k + 8 <= qb.end; k += 8) {
+          uint32_t v[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = a.cols[a.col_index[k + j]][row];
+#pragma unroll
+          for (int g = 0; g < 2; g++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const uint32_t* c = a.coef_c + 4 * (k + 4 * g + j);
+              const unsigned long long x = v[4 * g + j];
+              q0 += x * c[0]; q1 += x * c[1]; q2 += x * c[2]; q3 += x * c[3];
+            }
+            q0 = fold(q0); q1 = fold(q1); q2 = fold(q2); q3 = fold(q3);
+          }
+        }
+        for (; k < qb.end; k++) {
+          const uint32_t* c = a.coef_c + 4 * k;
+          const unsigned long long x = a.cols[a.col_index[k]][row];
+          q0 = fold(q0 + x * c[0]); q1 = fold(q1 + x * c[1]); q2 = fold(q2 + x * c[2]); q3 = fold(q3 + x * c[3]);
+        }
+        num = QM31(M31::reduce(q0), M31::reduce(q1), M31::reduce(q2), M31::reduce(q3));
+      }
+    } else if (live) {
       for (uint32_t k = qb.begin + slice; k < qb.end; k += S) {
         M31 v(a.cols[a.col_index[k]][row]);
         num += QM31::from_u32(a.coef_c + 4 * k) * v;
       }
+    }
     if (S > 1) {
       __syncthreads();
       num.to_u32(red + 4 * threadIdx.x);

@@ -8,6 +8,8 @@
 // Data layout: one column = contiguous u32[2^log] in HBM holding canonical M31 values, evaluations in
 // bit-reversed order of the canonic circle domain (Stwo `BitReversedOrder`).  Batches of equal-size
 // columns are addressed through a device array of column pointers (blockIdx.y = column).
+#include <algorithm>
+#include <string.h>
 #include "field.hpp"
 #include "device_common.hpp"
 #include "engine.hpp"
@@ -141,7 +143,7 @@ __global__ void k_bit_reverse(uint32_t* const* cols, uint32_t log_n) {
 // Split i = (hi, lo) with lo = LOW_BITS bits: the per-point table lowtab[lo] (QM31, built by
 // k_point_table) is shared by every column of the batch; each block reduces one 2^LOW_BITS chunk
 // and multiplies by hightab[hi].  partial[col][chunk] -> k_reduce_partials sums chunks.
-constexpr uint32_t EAP_LOW_BITS = 10;
+constexpr uint32_t EAP_LOW_BITS = 12;
 
 // tab[i] = prod_{bits k of i} maps[first_bit + k], i < 2^nbits.  The <= 32 QM31 factors travel in the
 // kernel arguments (512 B), so sampling needs no host->device copy.
@@ -180,6 +182,87 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const uint32_t* partial
   if (threadIdx.x == 0) acc.to_u32(out + 4 * blockIdx.x);
 }
 
+
+// ---- all sampling jobs of a proof in three launches ------------------------------------------------------
+// A proof samples ~20 (log size, point) groups; as separate launches (4 each) the small groups are pure
+// launch latency.  Job descriptors + the per-bit point factors travel in ONE upload; blocks find their job
+// with a scalar scan over the (<= 64) block-range prefix.
+struct EapJobDev {
+  uint32_t log_n, ncols;
+  const uint32_t* const* coeffs;
+  uint32_t* out;                 // 4 * ncols words
+  uint32_t low_off, high_off;    // word offsets of the two tables in the scratch buffer
+  uint32_t partial_off;          // word offset of partial[ncols][nchunks][4]
+  uint32_t block_begin;          // first block of this job in k_eval_partial_multi
+  uint32_t col_begin;            // first (job, column) index of this job in k_reduce_partials_multi
+  uint32_t pad;
+  uint32_t maps[32 * 4];         // QM31 factor of index bit k
+};
+__global__ void __launch_bounds__(256) k_point_tables_multi(const EapJobDev* __restrict__ jobs, uint32_t* __restrict__ scratch) {
+  const EapJobDev& jb = jobs[blockIdx.y];
+  const uint32_t low = jb.log_n < EAP_LOW_BITS ? jb.log_n : EAP_LOW_BITS;
+  const uint32_t high = jb.log_n - low;
+  const bool hi_tab = blockIdx.z == 1;
+  const uint32_t nbits = hi_tab ? high : low, first_bit = hi_tab ? low : 0;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << nbits)) return;
+  QM31 r(M31(1));
+  for (uint32_t k = 0; k < nbits; k++)
+    if ((i >> k) & 1u) r = r * QM31::from_u32(jb.maps + 4 * (first_bit + k));
+  r.to_u32(scratch + (hi_tab ? jb.high_off : jb.low_off) + 4 * i);
+}
+__device__ __forceinline__ unsigned long long fold31x2(unsigned long long x) {
+  x = (x & P) + (x >> 31);
+  return (x & P) + (x >> 31);
+}
+__global__ void __launch_bounds__(256) k_eval_partial_multi(const EapJobDev* __restrict__ jobs, uint32_t njobs,
+                                                            uint32_t* __restrict__ scratch) {
+  uint32_t j = 0;
+  while (j + 1 < njobs && jobs[j + 1].block_begin <= blockIdx.x) j++;
+  const EapJobDev& jb = jobs[j];
+  const uint32_t low_bits = jb.log_n < EAP_LOW_BITS ? jb.log_n : EAP_LOW_BITS;
+  const uint32_t nchunks = 1u << (jb.log_n - low_bits);
+  const uint32_t b = blockIdx.x - jb.block_begin;
+  const uint32_t col = b / nchunks, chunk = b - col * nchunks;
+  const uint32_t* __restrict__ c = jb.coeffs[col] + ((size_t)chunk << low_bits);
+  const uint32_t* __restrict__ lowtab = scratch + jb.low_off;
+  // 16 coefficients per thread: raw 64-bit products, 4 per coordinate fit a u64 (4 * (2^31-1)^2 + 2^32 < 2^64),
+  // folded back below 2^32 after every group of 4
+  unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+#pragma unroll
+  for (uint32_t g = 0; g < (1u << EAP_LOW_BITS) / 1024; g++) {
+#pragma unroll
+    for (uint32_t it = 0; it < 4; it++) {
+      const uint32_t i = threadIdx.x + (g * 4 + it) * 256;
+      if (i < (1u << low_bits)) {
+        const unsigned long long x = c[i];
+        const uint4 t = *reinterpret_cast<const uint4*>(lowtab + 4 * i);
+        q0 += x * t.x; q1 += x * t.y; q2 += x * t.z; q3 += x * t.w;
+      }
+    }
+    q0 = fold31x2(q0); q1 = fold31x2(q1); q2 = fold31x2(q2); q3 = fold31x2(q3);
+  }
+  QM31 acc(M31::reduce(q0), M31::reduce(q1), M31::reduce(q2), M31::reduce(q3));
+  acc = block_reduce_qm31(acc);
+  if (threadIdx.x == 0) {
+    acc = acc * QM31::from_u32(scratch + jb.high_off + 4 * chunk);
+    acc.to_u32(scratch + jb.partial_off + 4 * ((size_t)col * nchunks + chunk));
+  }
+}
+__global__ void __launch_bounds__(256) k_reduce_partials_multi(const EapJobDev* __restrict__ jobs, uint32_t njobs,
+                                                               const uint32_t* __restrict__ scratch) {
+  uint32_t j = 0;
+  while (j + 1 < njobs && jobs[j + 1].col_begin <= blockIdx.x) j++;
+  const EapJobDev& jb = jobs[j];
+  const uint32_t low_bits = jb.log_n < EAP_LOW_BITS ? jb.log_n : EAP_LOW_BITS;
+  const uint32_t nchunks = 1u << (jb.log_n - low_bits);
+  const uint32_t col = blockIdx.x - jb.col_begin;
+  const uint32_t* p = scratch + jb.partial_off + 4 * (size_t)col * nchunks;
+  QM31 acc;
+  for (uint32_t i = threadIdx.x; i < nchunks; i += blockDim.x) acc += QM31::from_u32(p + 4 * i);
+  acc = block_reduce_qm31(acc);
+  if (threadIdx.x == 0) acc.to_u32(jb.out + 4 * col);
+}
 
 // ================================================================= host wrappers
 Twiddles* twiddles_create(uint32_t R, hipStream_t st) {
@@ -307,6 +390,41 @@ void eval_at_point_batch(const uint32_t* const* d_coeffs, uint32_t ncols, uint32
   hipLaunchKernelGGL(k_eval_at_point_partial, dim3(nchunks, ncols), dim3(256), 0, st, d_coeffs, n, d_low, d_high,
                      d_partial);
   hipLaunchKernelGGL(k_reduce_partials, dim3(ncols), dim3(256), 0, st, d_partial, nchunks, d_out);
+  CM_HIP(hipGetLastError());
+}
+
+void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st) {
+  if (jobs.empty()) return;
+  std::vector<EapJobDev> dj(jobs.size());
+  size_t words = 0;
+  uint32_t blocks = 0, cols = 0, max_tab_blocks = 1;
+  double bytes = 0;
+  for (size_t k = 0; k < jobs.size(); k++) {
+    const EapJob& j = jobs[k];
+    CM_CHECK(j.ncols > 0 && j.log_n < 32, "eval_at_point_multi: bad job");
+    EapJobDev& d = dj[k];
+    memset(&d, 0, sizeof(d));
+    const uint32_t low = j.log_n < EAP_LOW_BITS ? j.log_n : EAP_LOW_BITS, high = j.log_n - low;
+    d.log_n = j.log_n; d.ncols = j.ncols; d.coeffs = j.d_coeffs; d.out = j.d_out;
+    d.low_off = (uint32_t)words; words += (size_t)4 << low;
+    d.high_off = (uint32_t)words; words += (size_t)4 << high;
+    d.partial_off = (uint32_t)words; words += ((size_t)4 * j.ncols) << high;
+    CM_CHECK(words < ((size_t)1 << 32), "eval_at_point_multi: scratch too large");
+    d.block_begin = blocks; blocks += j.ncols << high;
+    d.col_begin = cols; cols += j.ncols;
+    j.py.to_u32(d.maps);
+    QM31 x = j.px;
+    for (uint32_t b = 1; b < j.log_n; b++) { x.to_u32(d.maps + 4 * b); x = double_x(x); }
+    max_tab_blocks = std::max(max_tab_blocks, ((1u << std::max(low, high)) + 255) / 256);
+    bytes += 4.0 * j.ncols * (double)((size_t)1 << j.log_n);
+  }
+  DevBuf d_jobs = upload(dj, st), scratch(words * 4);
+  const EapJobDev* djp = d_jobs.as<EapJobDev>();
+  const uint32_t nj = (uint32_t)jobs.size();
+  KProfScope kp("k_eval_at_point", bytes, st);
+  hipLaunchKernelGGL(k_point_tables_multi, dim3(max_tab_blocks, nj, 2), dim3(256), 0, st, djp, scratch.u32());
+  hipLaunchKernelGGL(k_eval_partial_multi, dim3(blocks), dim3(256), 0, st, djp, nj, scratch.u32());
+  hipLaunchKernelGGL(k_reduce_partials_multi, dim3(cols), dim3(256), 0, st, djp, nj, scratch.u32());
   CM_HIP(hipGetLastError());
 }
 

@@ -1,0 +1,155 @@
+// Merkle layer kernels for gfx950 (Blake2s, Stwo MerkleOps<Blake2sMerkleHasher>::commit_on_layer framing).
+// Kept in a header so that tools/merkle_lab.hip can time variants against exactly the shipped kernels.
+#pragma once
+#include "blake2s_dev.hpp"
+#include "engine.hpp"
+
+namespace cm {
+
+// hashes[i] = hash_node(children (prev[2i], prev[2i+1]) if prev != null, cols[*][i])
+__global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const uint32_t* __restrict__ prev,
+                                                      const uint32_t* const* __restrict__ cols, uint32_t n_cols,
+                                                      uint32_t* __restrict__ out) {
+  // The 64 B of child hashes per node (and the 32 B result) are moved with wave-contiguous 16-byte
+  // accesses and re-distributed through LDS: a direct per-lane read would touch every cache line of the
+  // wave's 4 KiB window four times.  Slot rotation by (node >> 2) keeps the 128-bit LDS reads conflict-free.
+  __shared__ uint4 stage[256 * 4];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = 1u << log_size;
+  const uint32_t blk0 = blockIdx.x * 256;
+  const uint32_t i = blk0 + tid;
+  const bool full_block = blk0 + 256 <= n;
+  uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t m[16];
+  if (prev) {
+    if (full_block) {
+      const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)blk0 * 16);
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        uint32_t q = k * 256 + tid, node = q >> 2, part = q & 3;
+        stage[node * 4 + ((part + (node >> 2)) & 3)] = p[q];
+      }
+      __syncthreads();
+      uint4 a = stage[tid * 4 + ((0 + (tid >> 2)) & 3)], b = stage[tid * 4 + ((1 + (tid >> 2)) & 3)];
+      uint4 c = stage[tid * 4 + ((2 + (tid >> 2)) & 3)], d = stage[tid * 4 + ((3 + (tid >> 2)) & 3)];
+      m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+      m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+      m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+      m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+      b2s_compress(h, m);
+    } else if (i < n) {
+      const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
+      uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+      m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+      m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+      m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+      m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+      b2s_compress(h, m);
+    }
+  }
+  if (i < n) {
+    for (uint32_t c0 = 0; c0 < n_cols; c0 += 16) {
+#pragma unroll
+      for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? cols[c0 + k][i] : 0u;
+      b2s_compress(h, m);
+    }
+  }
+  if (full_block) {
+    __syncthreads();
+    stage[tid * 2 + 0] = make_uint4(h[0], h[1], h[2], h[3]);
+    stage[tid * 2 + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+    __syncthreads();
+    uint4* o = reinterpret_cast<uint4*>(out + (size_t)blk0 * 8);
+    o[tid] = stage[tid];
+    o[256 + tid] = stage[256 + tid];
+  } else if (i < n) {
+    uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+  }
+}
+
+// K consecutive layers (top_log, top_log-1, ..., top_log-K+1) in one launch.  A block hashes 256 nodes of the
+// top layer, keeps them in LDS, then 128 parents, 64 grand-parents, ...  Every layer is written to HBM (the
+// decommitment gathers need it) but intermediate layers are never re-read from HBM, and a 2^22 tree needs
+// 5 launches instead of 16.  Mid-size layers are launch-latency-bound as separate kernels.
+__global__ void __launch_bounds__(256) k_merkle_multi(MerkleMultiArgs a) {
+  __shared__ uint32_t bufA[256 * 8];
+  __shared__ uint32_t bufB[128 * 8];
+  uint32_t* buf[2];
+  buf[0] = bufA;
+  buf[1] = bufB;
+  const uint32_t tid = threadIdx.x;
+  int cur = 0;
+  uint32_t active = 256;  // nodes of the current level handled by this block
+#pragma unroll 1
+  for (uint32_t lv = 0; lv < a.n_levels; lv++, active >>= 1) {
+    const uint32_t log = a.top_log - lv;
+    const uint32_t node0 = blockIdx.x * active;  // first node of this block at this level
+    if (tid < active) {
+      const uint32_t i = node0 + tid;
+      uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t m[16];
+      if (lv > 0 || a.prev) {
+        const uint32_t* p = (lv == 0) ? a.prev + (size_t)i * 16 : buf[cur ^ 1] + tid * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = p[k];
+        b2s_compress(h, m);
+      }
+      const uint32_t c_begin = a.col_begin[lv], c_end = a.col_end[lv];
+      for (uint32_t c0 = c_begin; c0 < c_end; c0 += 16) {
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? a.cols[c0 + k][i] : 0u;
+        b2s_compress(h, m);
+      }
+      uint4* o = reinterpret_cast<uint4*>(a.layers[lv] + (size_t)i * 8);
+      o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+      o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+#pragma unroll
+      for (int k = 0; k < 8; k++) buf[cur][tid * 8 + k] = h[k];
+    }
+    (void)log;
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// All layers 2^top_log .. 2^0 of a tree in ONE launch (one 1024-thread block): the small layers are pure
+// launch/dependency latency as separate kernels (26 trees x 10 layers per proof).  Hashes of the layer being
+// consumed stay in LDS; every layer is still written to HBM for the decommitment gathers.
+__global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
+  __shared__ uint32_t bufA[1024 * 8];
+  __shared__ uint32_t bufB[512 * 8];
+  uint32_t* buf[2];  // layer top -> A (<= 1024 nodes), top-1 -> B (<= 512), top-2 -> A, ...
+  buf[0] = bufA;
+  buf[1] = bufB;
+  const uint32_t tid = threadIdx.x;
+  int cur = 0;
+  for (int l = (int)a.top_log; l >= 0; l--) {
+    const uint32_t n = 1u << l;
+    if (tid < n) {
+      uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t m[16];
+      const bool from_global = (l == (int)a.top_log);
+      if (!from_global || a.prev) {
+        const uint32_t* p = from_global ? a.prev + (size_t)tid * 16 : buf[cur ^ 1] + tid * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = p[k];
+        b2s_compress(h, m);
+      }
+      const uint32_t c_begin = a.col_begin[l], c_end = a.col_end[l];
+      for (uint32_t c0 = c_begin; c0 < c_end; c0 += 16) {
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? a.cols[c0 + k][tid] : 0u;
+        b2s_compress(h, m);
+      }
+      uint32_t* o = a.layers[l] + (size_t)tid * 8;
+#pragma unroll
+      for (int k = 0; k < 8; k++) { o[k] = h[k]; buf[cur][tid * 8 + k] = h[k]; }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+}  // namespace cm

@@ -555,20 +555,20 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       }
     }
     std::vector<const uint32_t*> table;
-    size_t n_out = 0, scratch_words = 0;
+    size_t n_out = 0;
     for (auto& j : jobs) {
       j.off = table.size();
       j.out_off = n_out;
       for (auto& r : j.refs) table.push_back(P.trees[r.t].coeffs.ptrs[r.c]);
       n_out += j.refs.size();
-      scratch_words += eval_at_point_scratch_words((uint32_t)j.refs.size(), j.log);
     }
-    DevBuf d_table = upload(table, st), scratch(scratch_words * 4), dout(n_out * 16);
-    size_t soff = 0;
-    for (auto& j : jobs) {
-      eval_at_point_batch(d_table.as<const uint32_t*>() + j.off, (uint32_t)j.refs.size(), j.log, j.pt.x, j.pt.y,
-                          scratch.u32() + soff, dout.u32() + 4 * j.out_off, st);
-      soff += eval_at_point_scratch_words((uint32_t)j.refs.size(), j.log);
+    DevBuf d_table = upload(table, st), dout(n_out * 16);
+    {
+      std::vector<EapJob> ej;
+      for (auto& j : jobs)
+        ej.push_back(EapJob{j.log, (uint32_t)j.refs.size(), d_table.as<const uint32_t*>() + j.off, j.pt.x, j.pt.y,
+                            dout.u32() + 4 * j.out_off});
+      eval_at_point_multi(ej, st);
     }
     std::vector<uint32_t> w(n_out * 4);
     CM_HIP(hipMemcpyAsync(w.data(), dout.p, w.size() * 4, hipMemcpyDeviceToHost, st));
