@@ -70,6 +70,11 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kprof", action="store_true", help="debug: no in-library HIP-event kernel timing")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="independent segment proofs in flight per GPU (one host thread + stream set each)")
+    ap.add_argument("--pipelined", type=int, default=3,
+                    help="after the timed region, also measure throughput with this many segment proofs in flight "
+                         "(reported as the extra `pipelined` object, N=1 only; 0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,18 +108,53 @@ def main():
     # a few microseconds per launch (~2 ms per proof over ~500 launches), so in the timed region only the
     # dominant class keeps its events: `value` is not taxed by the instrumentation, and `roofline.achieved`
     # still comes from launches inside the timed region.
+    import threading
+    import queue
+
+    class Worker(threading.Thread):
+        """One host thread = one proof in flight (the library gives every host thread its own main stream,
+        side streams, device pool and pinned upload ring)."""
+        def __init__(self):
+            super().__init__(daemon=True)
+            self.q = queue.Queue()
+            self.done = queue.Queue()
+            self.start()
+
+        def run(self):
+            while True:
+                n = self.q.get()
+                last = None
+                try:
+                    for _ in range(n):
+                        p = be.prove_device(dev)
+                        last = p.stats()
+                        p.free()
+                    self.done.put(last)
+                except Exception as e:  # noqa: BLE001
+                    self.done.put(e)
+
+    workers = [Worker() for _ in range(max(1, args.inflight))]
+
+    def prove_n(n):
+        """n proofs spread over the workers; returns the stats of the last proof of worker 0."""
+        share = [n // len(workers) + (1 if i < n % len(workers) else 0) for i in range(len(workers))]
+        for w, k in zip(workers, share):
+            w.q.put(k)
+        res = [w.done.get() for w in workers]
+        for r in res:
+            if isinstance(r, Exception):
+                raise r
+        return next(r for r in res if r is not None)
+
     cells = None
     kprof_all = {}
-    for _ in range(args.warmup):
-        p = be.prove_device(dev)
-        cells = p.stats()["cells"]
-        p.free()
+    if args.warmup:
+        cells = prove_n(args.warmup * len(workers))["cells"]
     n_prof = 1
     if not args.no_kprof:  # one extra untimed, fully instrumented pass (after the cold-start warmup)
         be.L.cm_kprof_enable(C.c_int32(1))
-        p = be.prove_device(dev)
-        cells = p.stats()["cells"]
-        p.free()
+        workers[0].q.put(1)
+        cells = workers[0].done.get()["cells"]
         kprof_all = kprof_report()
     dom_name = max(kprof_all.items(), key=lambda kv: kv[1]["ms"])[0] if kprof_all else None
     be.L.cm_kprof_enable(C.c_int32(0 if args.no_kprof else 1))
@@ -122,13 +162,8 @@ def main():
         be.L.cm_kprof_filter(dom_name.encode())
     sync()
     t0 = time.perf_counter()
-    phases = None
-    for _ in range(args.steps):
-        p = be.prove_device(dev)
-        st = p.stats()
-        cells = st["cells"]
-        phases = st["phase_ms"]
-        p.free()
+    st = prove_n(args.steps)
+    cells, phases = st["cells"], st["phase_ms"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -138,6 +173,21 @@ def main():
         dist.barrier()
     kprof = kprof_report() if not args.no_kprof else {}
     be.L.cm_kprof_enable(C.c_int32(0))
+    pipelined = None
+    if world == 1 and args.pipelined > 1:
+        # SURVEY §8f-4 segment pipeline: continuation segments are independent proofs, so several can be in
+        # flight on one GPU (one host thread each); their launch gaps and host round trips overlap.
+        workers = [Worker() for _ in range(args.pipelined)]
+        prove_n(len(workers))          # every new host thread warms its own pool / streams
+        n_pipe = 4 * len(workers)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        prove_n(n_pipe)
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - tp
+        pipelined = {"inflight": len(workers), "proofs": n_pipe, "ms_per_proof": dtp * 1e3 / n_pipe,
+                     "value": n_pipe * cells / dtp, "unit": "M31 trace cells/s",
+                     "note": "throughput with several independent segment proofs in flight on the GPU (not the headline value)"}
 
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
@@ -167,8 +217,8 @@ def main():
                "config": {"workload": f"fibonacci_loop n={args.fib_n} ({inp.steps} VM steps, one segment, "
                                       f"{cells} committed trace cells), REGULAR_96_BITS PCS config, "
                                       "ProverInput resident in HBM", "cells_per_proof": cells,
-                          "vm_steps": inp.steps, "parallelism": f"{world} independent segment replica(s)"},
-               "phase_ms": phases, "roofline": roofline}
+                          "vm_steps": inp.steps, "parallelism": f"{world} independent segment replica(s) x {len(workers)} proof(s) in flight per GPU"},
+               "phase_ms": phases, "roofline": roofline, "pipelined": pipelined}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
         else:

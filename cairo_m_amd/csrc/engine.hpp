@@ -75,6 +75,10 @@ void pool_put(void* p);
 void pool_trim();
 void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st);
 
+// The prover's main stream of the calling host thread (created on first use, non-blocking): concurrent proofs
+// from different host threads run on different streams and overlap on the GPU.
+hipStream_t thread_main_stream();
+
 // Fork/join over a small set of side streams (thread-local, created once): independent per-component
 // launches of one phase run concurrently instead of serialising 34 tiny kernels on one stream.
 // Fork f(main); launch on f.stream(i) ...; f.join();  — every side stream first waits for everything

@@ -52,7 +52,10 @@ struct Pool {
     free_.clear();
   }
 };
-Pool& pool() { static Pool* p = new Pool(); return *p; }
+// One pool per host thread: a freed block may still be read by kernels queued on the freeing thread's stream,
+// so it may only be handed to work that is ordered after them, i.e. to the same thread (= same main stream).
+// Concurrent proofs (one host thread each) therefore never exchange blocks.
+Pool& pool() { static thread_local Pool* p = new Pool(); return *p; }
 
 struct Stage {
   std::mutex mu;
@@ -62,7 +65,7 @@ struct Stage {
     if (!base) CM_HIP(hipHostMalloc((void**)&base, size, hipHostMallocDefault));
   }
 };
-Stage& stage() { static Stage* s = new Stage(); return *s; }
+Stage& stage() { static thread_local Stage* s = new Stage(); return *s; }  // ring wrap syncs only the owner's stream
 }  // namespace
 
 void* pool_get(size_t bytes) { return pool().get(bytes); }
@@ -113,6 +116,11 @@ hipStream_t Fork::stream(int i) {
     used |= 1u << i;
   }
   return ss.s[i];
+}
+hipStream_t thread_main_stream() {
+  static thread_local hipStream_t s = nullptr;
+  if (!s) CM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
 }
 void Fork::join() {
   if (joined) return;

@@ -175,6 +175,7 @@ static Twiddles* cached_twiddles(uint32_t R, hipStream_t st) {
   auto it = cache.find(R);
   if (it != cache.end()) return it->second;
   Twiddles* t = twiddles_create(R, st);
+  CM_HIP(hipStreamSynchronize(st));  // other host threads use the tables from their own streams
   cache[R] = t;
   return t;
 }
@@ -239,6 +240,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   pf.config = cfg;
   Prover P;
   P.cfg = cfg;
+  P.st = thread_main_stream();
   hipStream_t st = P.st;
   P.t0 = std::chrono::steady_clock::now();
   auto t_start = P.t0;
@@ -356,7 +358,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     for (int i = 0; i < air::MAX_REL_SIZE; i++) hrel.alpha_pow[r][i].to_u32(drel_h.alpha_pow[r][i]);
   }
   DevBuf drel(sizeof(DevRelations));
-  CM_HIP(hipMemcpy(drel.p, &drel_h, sizeof(DevRelations), hipMemcpyHostToDevice));
+  stage_upload(drel.p, &drel_h, sizeof(DevRelations), st);
 
   // ---- tree 2: interaction trace (prover.rs:96-102) ----
   ColumnSet it_evals;
@@ -587,25 +589,6 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     ch.mix_felts(flat.data(), flat.size());
   }
   P.tick("oods_sampling");
-  // sanity check (stwo prove): composition OODS value == constraints at the sampled mask values
-  {
-    QM31 c4[4] = {pf.sampled_values[3][0][0], pf.sampled_values[3][1][0], pf.sampled_values[3][2][0], pf.sampled_values[3][3][0]};
-    QM31 comp = combine_ef(c4);
-    QM31 ppv[air::N_PREPROC];
-    for (int i = 0; i < air::N_PREPROC; i++) ppv[i] = pf.sampled_values[0][i][0];
-    QM31 sum;
-    for (int c = 0; c < air::N_COMPONENTS; c++) {
-      const air::ComponentInfo& info = air::component_info(c);
-      std::vector<QM31> tr, it;
-      for (int k = 0; k < info.n_trace; k++) tr.push_back(pf.sampled_values[1][tr0[c] + k][0]);
-      for (int k = 0; k < info.n_interaction; k++) for (auto& s : pf.sampled_values[2][it0[c] + k]) it.push_back(s);
-      QM31 shift = pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]));
-      QM31 num = point_eval(c, tr.data(), it.data(), ppv, hrel, &powers[coff[c]], info.n_base_constraints, shift);
-      sum += num * inv(coset_vanishing_canonic<QM31>(clog[c], oods));
-    }
-    if (sum != comp) throw CmError(10, "ConstraintsNotSatisfied: composition polynomial does not match the constraints at the OODS point");
-  }
-
   // ---- DEEP quotients (compute_fri_quotients) ----
   QM31 qcoeff = ch.draw_felt();
   struct Ref { int t; uint32_t c; };
@@ -786,6 +769,27 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     inner.push_back(std::move(il));
   }
   CM_CHECK(qi == quotients.size(), "fri: not every quotient column was folded");
+  // sanity check (stwo prove): composition OODS value == constraints at the sampled mask values.  Host-only
+  // work, so it runs here, while the GPU is busy with the (already enqueued) quotient and FRI kernels.
+  {
+    QM31 c4[4] = {pf.sampled_values[3][0][0], pf.sampled_values[3][1][0], pf.sampled_values[3][2][0], pf.sampled_values[3][3][0]};
+    QM31 comp = combine_ef(c4);
+    QM31 ppv[air::N_PREPROC];
+    for (int i = 0; i < air::N_PREPROC; i++) ppv[i] = pf.sampled_values[0][i][0];
+    QM31 sum;
+    for (int c = 0; c < air::N_COMPONENTS; c++) {
+      const air::ComponentInfo& info = air::component_info(c);
+      std::vector<QM31> tr, it;
+      for (int k = 0; k < info.n_trace; k++) tr.push_back(pf.sampled_values[1][tr0[c] + k][0]);
+      for (int k = 0; k < info.n_interaction; k++) for (auto& s : pf.sampled_values[2][it0[c] + k]) it.push_back(s);
+      QM31 shift = pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]));
+      QM31 num = point_eval(c, tr.data(), it.data(), ppv, hrel, &powers[coff[c]], info.n_base_constraints, shift);
+      sum += num * inv(coset_vanishing_canonic<QM31>(clog[c], oods));
+    }
+    if (sum != comp) throw CmError(10, "ConstraintsNotSatisfied: composition polynomial does not match the constraints at the OODS point");
+  }
+
+
   // last layer (2^last_log values): interpolate on the host, keep 2^log_last_layer coefficients
   {
     uint32_t n = 1u << last_log;
