@@ -496,25 +496,24 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     for (auto& g : sgroups) sum_slots(accs[g.el].dev(), slots.u32() + g.off_words, g.n, g.el, st);
   }
   P.tick("constraints");
-  // DomainEvaluationAccumulator::finalize: ascending sizes, interpolate / extend / add
+  // DomainEvaluationAccumulator::finalize.  Stwo walks the sizes upward: interpolate(vals_l + evaluate_l(cur)).
+  // Interpolation is linear and interpolate_l(evaluate_l(cur)) is cur zero-padded (coefficient bases nest),
+  // so the same coefficients come from interpolating every accumulator at its OWN size (independent, on side
+  // streams) and adding the zero-padded coefficient vectors — field arithmetic is exact, the result is
+  // bit-identical, and the extend/add chain over the large domains disappears.
   {
     CommittedTree& t = P.trees[3];
-    ColumnSet* cur = nullptr;
-    uint32_t cur_log = 0;
-    for (auto& kv : accs) {
-      ColumnSet& vals = kv.second;
-      if (cur) {
-        ColumnSet ext;
-        ext.alloc(std::vector<uint32_t>(4, kv.first), st);
-        evaluate((const uint32_t* const*)cur->dev(), ext.dev(), 4, cur_log, kv.first, *P.tw, st);
-        add_columns(vals.dev(), (const uint32_t* const*)ext.dev(), 4, 1u << kv.first, st);
-      }
-      interpolate(vals.dev(), 4, kv.first, *P.tw, st);
-      cur = &vals;
-      cur_log = kv.first;
+    {
+      Fork fk(st);
+      int k = 0;
+      for (auto it = accs.rbegin(); it != accs.rend(); ++it, ++k) interpolate(it->second.dev(), 4, it->first, *P.tw, fk.stream(k));
+      fk.join();
     }
-    CM_CHECK(cur && cur_log == comp_log, "composition polynomial log size mismatch");
-    t.coeffs = std::move(*cur);
+    ColumnSet& top = accs.rbegin()->second;
+    CM_CHECK(accs.rbegin()->first == comp_log, "composition polynomial log size mismatch");
+    for (auto& kv : accs)
+      if (kv.first != comp_log) add_columns(top.dev(), (const uint32_t* const*)kv.second.dev(), 4, 1u << kv.first, st);
+    t.coeffs = std::move(top);
     P.commit(t, nullptr, true);
   }
   P.tick("composition_commit");
