@@ -182,4 +182,25 @@ CM_HD uint32_t bit_reverse(uint32_t i, uint32_t log) {
 #endif
 }
 
+// Lazy accumulator for  sum_k c_k * x_k  with c_k in QM31 (4 canonical words) and x_k in M31: the 64-bit
+// products of one coordinate are added unreduced — four of them plus a folded remainder fit a u64
+// (4 * (2^31-1)^2 + 2^32 < 2^64) — and folded back below 2^32 after every fourth term.  On gfx950 this is
+// one v_mad_u64_u32 per coordinate-term instead of a multiply + Mersenne fold + modular add.
+struct QAcc {
+  unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+  int pending = 0;
+  static CM_HD unsigned long long fold(unsigned long long x) {
+    x = (x & P) + (x >> 31);
+    return (x & P) + (x >> 31);
+  }
+  CM_HD void add(const uint32_t* c4, M31 x) {
+    const unsigned long long v = x.v;
+    q0 += v * c4[0]; q1 += v * c4[1]; q2 += v * c4[2]; q3 += v * c4[3];
+    if (++pending == 4) { q0 = fold(q0); q1 = fold(q1); q2 = fold(q2); q3 = fold(q3); pending = 0; }
+  }
+  CM_HD QM31 value() const {
+    return QM31(M31::reduce(fold(q0)), M31::reduce(fold(q1)), M31::reduce(fold(q2)), M31::reduce(fold(q3)));
+  }
+};
+
 }  // namespace cm

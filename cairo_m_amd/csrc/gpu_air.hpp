@@ -23,9 +23,9 @@ struct DevRelations {
 };
 
 __device__ __forceinline__ QM31 dev_combine(const DevRelations* __restrict__ rel, int r, const M31* v, int n) {
-  QM31 acc = QM31::from_u32(rel->alpha_pow[r][0]) * v[0];
-  for (int i = 1; i < n; i++) acc += QM31::from_u32(rel->alpha_pow[r][i]) * v[i];
-  return acc - QM31::from_u32(rel->z[r]);
+  QAcc acc;  // sum_i alpha^i * v_i as unreduced 64-bit products (n <= MAX_REL_SIZE, unrolled after inlining)
+  for (int i = 0; i < n; i++) acc.add(rel->alpha_pow[r][i], v[i]);
+  return acc.value() - QM31::from_u32(rel->z[r]);
 }
 
 struct EmptyEF {};
@@ -90,7 +90,8 @@ struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
   uint32_t row;
   int ci = 0, batch = 0;
   QM31 prev;
-  __device__ M31 next() { return M31(cols[ci++][row]); }
+  const uint32_t* trv = nullptr;  // trace cells of this row already in registers (see k_logup)
+  __device__ M31 next() { return trv ? M31(trv[ci++]) : M31(cols[ci++][row]); }
   __device__ M31 preproc(int id) { return M31(pp[id][row]); }
   __device__ M31 c(uint32_t v) { return M31(v); }
   __device__ void constraint(M31) {}
@@ -119,10 +120,13 @@ struct DomainEval : air::LogupStream<DomainEval, M31, QM31> {
   QM31 cumsum_shift;
   int ci = 0, ii = 0, kb = 0, kl = 0;
   QM31 prev_col, acc;
-  __device__ M31 next() { return M31(tr[ci++][row]); }
+  QAcc base_acc;  // sum over the add_constraint constraints of rho^k * C_k, accumulated lazily
+  const uint32_t* trv = nullptr;  // trace cells of this row already in registers (see k_constraints)
+  __device__ M31 next() { return trv ? M31(trv[ci++]) : M31(tr[ci++][row]); }
   __device__ M31 preproc(int id) { return M31(pp[id][row]); }
   __device__ M31 c(uint32_t v) { return M31(v); }
-  __device__ void constraint(M31 x) { acc += QM31::from_u32(coeff + 4 * (kb++)) * x; }
+  __device__ void constraint(M31 x) { base_acc.add(coeff + 4 * (kb++), x); }
+  __device__ QM31 total() const { return acc + base_acc.value(); }
   __device__ void constraint_q(QM31 x) { acc += QM31::from_u32(coeff + 4 * (n_base + kl++)) * x; }
   __device__ QM31 combine(int r, const M31* v, int n) { return dev_combine(rels, r, v, n); }
   __device__ QM31 ef_from(M31 m) { return QM31(m); }
