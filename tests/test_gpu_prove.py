@@ -50,9 +50,26 @@ def test_felt_and_u32_programs_bit_exact(backend, oracle):
         inp.free()
 
 
-def test_full_size_proof_properties(backend):
+def test_u32_loop_program_bit_exact(backend, oracle):
+    """Looped u32 mix (stand-in for BASELINE configs[2], see tests/test_oracle_air.py::u32_loop_program):
+    thousands of live rows in the u32 / bitwise / range-check components instead of one each."""
+    from cairo_m_amd.lib import vm_run
+    from tests.test_oracle_air import u32_loop_program
+    inp = vm_run(u32_loop_program(400), entry_pc=0, args=(), n_returns=0)
+    assert inp.steps == 3 + 11 * 400 + 1
+    proof = backend.prove(inp)
+    got = proof.words()
+    want, _ = oracle.prove(inp.view)
+    assert got.size == want.size and np.array_equal(got, want)
+    assert oracle.verify(got)[0] == 0
+    proof.free()
+    inp.free()
+
+
+def test_full_size_proof_properties(backend, oracle):
     """fibonacci_loop at 2^20 steps (BASELINE configs[1]): too big for the oracle prover in a test, so check
-    size-independent properties: determinism (two runs give identical words) and the cell count formula."""
+    size-independent properties: determinism (two runs give identical words), the cell count formula, and
+    acceptance by the oracle verifier."""
     inp = synth_fibonacci(100_000)
     assert inp.steps == 1_000_012
     dev = backend.upload_input(inp)
@@ -62,6 +79,43 @@ def test_full_size_proof_properties(backend):
     assert np.array_equal(w1, w2)
     st = p1.stats()
     assert st["steps"] == 1_000_012 and st["cells"] > 4e7
+    # the oracle VERIFIER is cheap at any size: the full-size HIP proof must verify, a tampered one must not
+    rc, err = oracle.verify(w1)
+    assert rc == 0, err
+    bad = w1.copy()
+    bad[bad.size // 3] ^= 1
+    assert oracle.verify(bad)[0] != 0
     p1.free(); p2.free()
+    backend.free_input(dev)
+    inp.free()
+
+
+def test_metric_config_proof_verifies(backend, oracle):
+    """BASELINE metric config (fibonacci_loop n = 419 000, 4 190 012 steps, 2^22 rows): the HIP proof is accepted
+    by the oracle verifier; proofs from two concurrent host threads (the `pipelined` mode of bench.py: per-thread
+    streams / pools) are identical to the single-threaded one."""
+    import threading
+    inp = synth_fibonacci(419_000)
+    assert inp.steps == 4_190_012
+    dev = backend.upload_input(inp)
+    p0 = backend.prove_device(dev)
+    w0 = p0.words().copy()
+    assert p0.stats()["cells"] == 200_152_208
+    rc, err = oracle.verify(w0)
+    assert rc == 0, err
+    p0.free()
+    out = [None, None]
+
+    def work(i):
+        p = backend.prove_device(dev)
+        out[i] = p.words().copy()
+        p.free()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert np.array_equal(out[0], w0) and np.array_equal(out[1], w0)
     backend.free_input(dev)
     inp.free()

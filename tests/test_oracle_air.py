@@ -104,6 +104,43 @@ def test_u32_opcodes_constraints(oracle):
     inp.free()
 
 
+def u32_loop_program(n):
+    """Stand-in for BASELINE configs[2] (examples/sha256-cairo-m cannot be compiled here): a loop whose body is the
+    u32 mix of a SHA-256 round (add, and, xor, or, mul-by-constant and div/rem = the rotr idiom of
+    examples/sha256-cairo-m/src/sha256.cm:17-27) with the state fed back every iteration, driven by a felt
+    counter (store_fp_imm, jnz).  In-place updates ([x] = [x] + k) are not provable in the reference AIR (the
+    read and the write of one cell would share a clock), so the counter bounces between two cells like the
+    compiler's fibonacci loop does."""
+    A, B = 0x6A09E667, 0x00012345
+    lo = lambda v: v & 0xFFFF
+    hi = lambda v: v >> 16
+    return [
+        [23, lo(A), hi(A), 0],            # pc 0: u32 [0..1] = A
+        [23, lo(B), hi(B), 2],            # pc 1: u32 [2..3] = B
+        [9, n, 50],                       # pc 2: counter = n
+        [15, 0, 2, 4],                    # pc 3: [4..5] = A + B                      <- loop head
+        [36, 4, 2, 6],                    # pc 4: and
+        [38, 6, 0, 8],                    # pc 5: xor
+        [37, 8, 2, 10],                   # pc 6: or
+        [21, 10, 0x0101, 0x0001, 12],     # pc 7-8: mul imm
+        [22, 12, 1000, 0, 14, 16],        # pc 9-10: div/rem imm
+        [19, 14, 0xFFFF, 0xFFFF, 18],     # pc 11-12: add imm
+        [15, 18, 2, 0],                   # pc 13: A = [18..19] + B   (state feedback)
+        [4, 50, neg(1), 51],              # pc 14: t = counter - 1
+        [4, 51, 0, 50],                   # pc 15: counter = t
+        [14, 50, neg(13)],                # pc 16: jnz counter -> pc 3
+        [11],                             # pc 17: ret
+    ]
+
+
+def test_u32_loop_constraints(oracle):
+    inp = vm_run(u32_loop_program(60), entry_pc=0, args=(), n_returns=0)
+    assert inp.steps == 3 + 11 * 60 + 1
+    rc, err = oracle.assert_constraints(inp.view)
+    assert rc == 0, err
+    inp.free()
+
+
 CHAIN_PROG = [[9, 1, 0], [4, 0, 1, 1], [4, 1, 1, 0], [4, 0, 1, 1], [4, 1, 1, 0], [4, 0, 1, 1], [11]]
 
 
