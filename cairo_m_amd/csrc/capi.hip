@@ -21,6 +21,7 @@ inline uint32_t* P32(cm_handle h) { return (uint32_t*)(uintptr_t)h; }
 template <class F>
 int32_t guard(F&& f) {
   try {
+    bind_thread_to_library_device();  // hipSetDevice is per host thread
     f();
     return 0;
   } catch (const CmError& e) {
@@ -65,6 +66,7 @@ int32_t cm_init(int32_t device) {
       throw CmError(3, "cm_init: no HIP device available (libcairom_hip has no CPU fallback)");
     CM_CHECK(device >= 0 && device < ndev, "cm_init: device index out of range");
     CM_HIP(hipSetDevice(device));
+    set_library_device(device);
     g_inited = true;
   });
 }

@@ -75,6 +75,11 @@ void pool_put(void* p);
 void pool_trim();
 void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st);
 
+// The HIP device cm_init() selected (one device per process: one process per GPU).  hipSetDevice is per host
+// thread, so every host thread that enters the library is bound to that device on its first call.
+void set_library_device(int device);
+void bind_thread_to_library_device();
+
 // The prover's main stream of the calling host thread (created on first use, non-blocking): concurrent proofs
 // from different host threads run on different streams and overlap on the GPU.
 hipStream_t thread_main_stream();

@@ -117,9 +117,21 @@ hipStream_t Fork::stream(int i) {
   }
   return ss.s[i];
 }
+namespace { int g_library_device = -1; }
+void set_library_device(int device) { g_library_device = device; }
+void bind_thread_to_library_device() {
+  static thread_local int bound = -1;
+  if (g_library_device >= 0 && bound != g_library_device) {
+    CM_HIP(hipSetDevice(g_library_device));
+    bound = g_library_device;
+  }
+}
 hipStream_t thread_main_stream() {
   static thread_local hipStream_t s = nullptr;
-  if (!s) CM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  if (!s) {
+    bind_thread_to_library_device();
+    CM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  }
   return s;
 }
 void Fork::join() {

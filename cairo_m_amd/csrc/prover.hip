@@ -65,6 +65,7 @@ static PublicData make_public_data(const cm_prover_input& in) {  // PublicData::
 }
 
 DeviceInput* upload_input(const cm_prover_input& in) {
+  bind_thread_to_library_device();
   DeviceInput* d = new DeviceInput();
   d->meta = in;
   auto up = [](DevBuf& b, const void* p, size_t bytes) {
@@ -238,6 +239,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   std::unique_ptr<ProofData> out(new ProofData());
   ProofData& pf = *out;
   pf.config = cfg;
+  bind_thread_to_library_device();
   Prover P;
   P.cfg = cfg;
   P.st = thread_main_stream();
