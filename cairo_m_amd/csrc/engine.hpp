@@ -68,6 +68,9 @@ void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_fe
 uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st);
 // out[q * width + w] = addrs[q][w]  (decommitment gathers: width 1 = values, 8 = hashes)
 void gather_words(const uint32_t* const* d_addrs, uint32_t n, uint32_t width, uint32_t* d_out, hipStream_t st);
+// out[run.out_off + c] = run.d_cols[c][run.row]  (decommitment: one queried row of a run of columns)
+struct RowRun { const uint32_t* const* d_cols; uint32_t n_cols, row, out_off, pad; };
+void gather_runs(const RowRun* d_runs, uint32_t n_runs, uint32_t* d_out, hipStream_t st);
 
 // pool.cpp-style services implemented in pool.hip
 void* pool_get(size_t bytes);

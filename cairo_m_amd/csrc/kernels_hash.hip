@@ -54,6 +54,11 @@ __global__ void k_gather_words(const uint32_t* const* addrs, uint32_t n, uint32_
 }
 
 
+__global__ void __launch_bounds__(64) k_gather_runs(const RowRun* __restrict__ runs, uint32_t* __restrict__ out) {
+  const RowRun r = runs[blockIdx.x];
+  for (uint32_t c = threadIdx.x; c < r.n_cols; c += blockDim.x) out[r.out_off + c] = r.d_cols[c][r.row];
+}
+
 // ================================================================= host wrappers
 void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
                   uint32_t* d_out, hipStream_t st) {
@@ -70,6 +75,11 @@ void merkle_multi(const MerkleMultiArgs& a, double alg_bytes, hipStream_t st) {
 }
 void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log, hipStream_t st) {
   hipLaunchKernelGGL(k_chan_mix_root_draw, dim3(1), dim3(64), 0, st, d_chan, d_root, d_felt_out, d_root_log);
+  CM_HIP(hipGetLastError());
+}
+void gather_runs(const RowRun* d_runs, uint32_t n_runs, uint32_t* d_out, hipStream_t st) {
+  if (!n_runs) return;
+  hipLaunchKernelGGL(k_gather_runs, dim3(n_runs), dim3(64), 0, st, d_runs, d_out);
   CM_HIP(hipGetLastError());
 }
 void merkle_tail(const MerkleTailArgs& a, hipStream_t st) {

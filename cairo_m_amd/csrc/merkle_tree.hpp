@@ -22,16 +22,28 @@ struct MerkleDecommitment {
   std::vector<uint32_t> column_witness;
 };
 
-// One batched device->host gather of single words and 32-byte hashes at arbitrary device addresses.
+// One batched device->host gather of single words, 32-byte hashes and "row runs" (one row of a run of columns
+// given by a DEVICE pointer table: the kernel expands it, so the host neither builds nor uploads one address
+// per queried cell — a 2^22 proof queries ~3*10^5 cells).
 struct GatherBatch {
   std::vector<const uint32_t*> word_addrs, hash_addrs;
-  std::vector<uint32_t> words, hashes;  // results (hashes: 8 words each)
+  std::vector<RowRun> runs;
+  size_t run_words = 0;
+  std::vector<uint32_t> words, hashes, run_out;  // results (hashes: 8 words each)
   size_t add_word(const uint32_t* p) { word_addrs.push_back(p); return word_addrs.size() - 1; }
   size_t add_hash(const uint32_t* p) { hash_addrs.push_back(p); return hash_addrs.size() - 1; }
+  // values d_cols[c][row], c < n_cols  ->  run_out[returned offset + c]
+  size_t add_run(const uint32_t* const* d_cols, uint32_t n_cols, uint32_t row) {
+    size_t off = run_words;
+    runs.push_back(RowRun{d_cols, n_cols, row, (uint32_t)off, 0});
+    run_words += n_cols;
+    return off;
+  }
   void run(hipStream_t st) {
     words.resize(word_addrs.size());
     hashes.resize(hash_addrs.size() * 8);
-    DevBuf dw, dh, ow, oh;
+    run_out.resize(run_words);
+    DevBuf dw, dh, dr, ow, oh, orr;
     if (!word_addrs.empty()) {
       dw = upload(word_addrs, st);
       ow.alloc(words.size() * 4);
@@ -44,14 +56,21 @@ struct GatherBatch {
       gather_words(dh.as<const uint32_t*>(), (uint32_t)hash_addrs.size(), 8, oh.u32(), st);
       CM_HIP(hipMemcpyAsync(hashes.data(), oh.p, hashes.size() * 4, hipMemcpyDeviceToHost, st));
     }
+    if (!runs.empty()) {
+      dr = upload(runs, st);
+      orr.alloc(run_words * 4 + 4);
+      gather_runs(dr.as<RowRun>(), (uint32_t)runs.size(), orr.u32(), st);
+      CM_HIP(hipMemcpyAsync(run_out.data(), orr.p, run_words * 4, hipMemcpyDeviceToHost, st));
+    }
     CM_HIP(hipStreamSynchronize(st));
   }
 };
 
 struct DecommitPlan {
   size_t hash0 = 0, n_hash = 0;    // range in GatherBatch::hash_addrs
-  size_t word0 = 0;                // first index in GatherBatch::word_addrs
-  std::vector<uint8_t> is_query;   // per requested word: 1 -> queried_values, 0 -> column_witness
+  // requested column values in decommitment order: segments of single words or of one row run
+  struct Seg { uint32_t is_run, is_query; size_t off; uint32_t count; };
+  std::vector<Seg> segs;
 };
 
 struct MerkleTree {
@@ -131,7 +150,6 @@ struct MerkleTree {
   DecommitPlan plan_decommit(const std::map<uint32_t, std::vector<uint32_t>>& queries_per_log_size, GatherBatch& gb) const {
     DecommitPlan plan;
     plan.hash0 = gb.hash_addrs.size();
-    plan.word0 = gb.word_addrs.size();
     size_t ci = 0;
     std::vector<uint32_t> last;
     for (int layer_log = (int)layers.size() - 1; layer_log >= 0; layer_log--) {
@@ -157,7 +175,16 @@ struct MerkleTree {
         }
         bool isq = qi < colq.size() && colq[qi] == node;
         if (isq) qi++;
-        for (size_t c = c0; c < ci; c++) { gb.add_word(cols[c] + node); plan.is_query.push_back(isq); }
+        if (ci > c0) {
+          if (d_cols.p) {
+            size_t off = gb.add_run(d_cols.as<const uint32_t*>() + c0, (uint32_t)(ci - c0), node);
+            plan.segs.push_back(DecommitPlan::Seg{1u, isq ? 1u : 0u, off, (uint32_t)(ci - c0)});
+          } else {  // trees whose column table never went to the device (FRI tail layers: 4 columns)
+            size_t off = gb.word_addrs.size();
+            for (size_t c = c0; c < ci; c++) gb.add_word(cols[c] + node);
+            plan.segs.push_back(DecommitPlan::Seg{0u, isq ? 1u : 0u, off, (uint32_t)(ci - c0)});
+          }
+        }
         total.push_back(node);
       }
       last.swap(total);
@@ -169,10 +196,10 @@ struct MerkleTree {
                               MerkleDecommitment& d) {
     d.hash_witness.resize(plan.n_hash);
     for (size_t i = 0; i < plan.n_hash; i++) memcpy(d.hash_witness[i].data(), &gb.hashes[8 * (plan.hash0 + i)], 32);
-    for (size_t i = 0; i < plan.is_query.size(); i++) {
-      uint32_t v = gb.words[plan.word0 + i];
-      if (plan.is_query[i]) queried_values.push_back(v);
-      else d.column_witness.push_back(v);
+    for (const auto& sg : plan.segs) {
+      const uint32_t* v = (sg.is_run ? gb.run_out.data() : gb.words.data()) + sg.off;
+      std::vector<uint32_t>& dst = sg.is_query ? queried_values : d.column_witness;
+      dst.insert(dst.end(), v, v + sg.count);
     }
   }
   // single-tree convenience (per-op C ABI)
