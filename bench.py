@@ -22,6 +22,13 @@ sys.path.insert(0, ROOT)
 
 FIB_N = 419_000          # 10*n + 12 = 4,190,012 VM steps (~2^22), one segment
 HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# Integer-ALU ceilings of the two dominant kernel classes, from the measured gfx950 issue rates
+# (tools/valu_lab.hip: VOP2 int 2 cycles, VOP3 int 4 cycles, v_mad_u64_u32 5 cycles per wave-instruction per SIMD,
+# 1024 SIMDs, ~1.9 GHz sustained): a Blake2s compression is ~2890 issue cycles per wave, an M31 butterfly
+# (multiply + add + sub, arithmetic only) ~35.  DESIGN.md §3.
+ALU_PEAK = {"k_merkle_layer": (1024 * 1.9e9 / 2890 * 64, "Blake2s compressions/s"),
+            "k_fft_pass<fft>": (1024 * 1.9e9 / 35 * 64, "M31 butterflies/s"),
+            "k_fft_pass<ifft>": (1024 * 1.9e9 / 35 * 64, "M31 butterflies/s")}
 MODEL_BYTES_PER_CELL = 52.0  # SURVEY §8d algorithmic-bytes model for the whole path
 
 
@@ -201,6 +208,10 @@ def main():
             roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_ms": k["ms"] / k["calls"], "launches": k["calls"],
+                        "alu": ({"unit": ALU_PEAK[name][1], "achieved": k.get("work", 0.0) / (k["ms"] * 1e-3),
+                                 "peak": ALU_PEAK[name][0], "frac": k.get("work", 0.0) / (k["ms"] * 1e-3) / ALU_PEAK[name][0],
+                                 "note": "this class is integer-VALU-bound, not HBM-bound (DESIGN.md §3); peak from measured gfx950 issue rates"}
+                                if name in ALU_PEAK and k.get("work") else None),
                         "algorithmic_bytes_per_launch": k["bytes"] / k["calls"],
                         "whole_path_model": {"bytes_per_cell": MODEL_BYTES_PER_CELL,
                                              "achieved_GBs": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9,

@@ -48,6 +48,48 @@ __device__ __forceinline__ void b2s_compress(uint32_t (&h)[8], const uint32_t (&
   h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
 }
 
+// ---- quad-lane compression: one Blake2s state spread over 4 adjacent lanes ----------------------------------
+// Wide-and-short Merkle layers (few nodes, hundreds of columns) and the top levels of every tree are one
+// sequential compression chain per node; with one node per lane a lone wave needs ~2.7 us per compression.
+// Lane q of a quad holds column q of the 4x4 state (a = v[q], b = v[4+q], c = v[8+q], d = v[12+q]); the
+// diagonal step rotates b, c, d by 1, 2, 3 lanes with DPP quad_perm moves.  Every lane keeps all 16 message
+// words (the 4 lanes of a quad load the same addresses: one fetch) and selects its two words per G with
+// lane-id selects.  ~1.4 us per compression (tools/merkle_lab.hip), bit-identical to b2s_compress.
+#define CM_QP(p0, p1, p2, p3) ((p0) | ((p1) << 2) | ((p2) << 4) | ((p3) << 6))
+#define CM_QUAD_ROT(x, ctrl) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ uint32_t b2s_sel4(uint32_t q, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+  uint32_t lo = (q & 1u) ? x1 : x0, hi = (q & 1u) ? x3 : x2;
+  return (q & 2u) ? hi : lo;
+}
+#define CM_QG(x, y)                             \
+  a = a + b + (x); d = rotr(d ^ a, 16);         \
+  c = c + d;       b = rotr(b ^ c, 12);         \
+  a = a + b + (y); d = rotr(d ^ a, 8);          \
+  c = c + d;       b = rotr(b ^ c, 7);
+#define CM_QROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                           \
+  CM_QG(b2s_sel4(q, m[s0], m[s2], m[s4], m[s6]), b2s_sel4(q, m[s1], m[s3], m[s5], m[s7]))                         \
+  b = CM_QUAD_ROT(b, CM_QP(1, 2, 3, 0)); c = CM_QUAD_ROT(c, CM_QP(2, 3, 0, 1)); d = CM_QUAD_ROT(d, CM_QP(3, 0, 1, 2)); \
+  CM_QG(b2s_sel4(q, m[s8], m[s10], m[s12], m[s14]), b2s_sel4(q, m[s9], m[s11], m[s13], m[s15]))                   \
+  b = CM_QUAD_ROT(b, CM_QP(3, 0, 1, 2)); c = CM_QUAD_ROT(c, CM_QP(2, 3, 0, 1)); d = CM_QUAD_ROT(d, CM_QP(1, 2, 3, 0));
+// h0 = h[q], h1 = h[4 + q] of the node's chaining value; q = lane & 3; all 4 lanes of the quad must be active
+__device__ __forceinline__ void b2s_compress_quad(uint32_t& h0, uint32_t& h1, const uint32_t (&m)[16], uint32_t q) {
+  uint32_t a = h0, b = h1;
+  uint32_t c = b2s_sel4(q, 0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au);
+  uint32_t d = b2s_sel4(q, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u);
+  CM_QROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  CM_QROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+  CM_QROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+  CM_QROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+  CM_QROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+  CM_QROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+  CM_QROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+  CM_QROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+  CM_QROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+  CM_QROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+  h0 ^= a ^ c;
+  h1 ^= b ^ d;
+}
+
 // ---- device-side Fiat-Shamir steps for the FRI commit phase -----------------------------------------------
 // Between two FRI layers the transcript only does mix_root(layer root) and draw_felt() (the folding
 // challenge).  Doing those two hashes in a 1-thread kernel keeps the whole commit phase on the stream:

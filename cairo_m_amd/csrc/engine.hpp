@@ -39,8 +39,8 @@ void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st);
 // Merkle
 void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
                   uint32_t* d_out, hipStream_t st);
-// layers 2^top_log .. 2^0 in one launch (top_log <= 10)
-constexpr uint32_t MERKLE_TAIL_LOG = 7;
+// layers 2^top_log .. 2^0 in one launch (top_log <= MERKLE_TAIL_LOG)
+constexpr uint32_t MERKLE_TAIL_LOG = 8;  // 256 nodes = one 1024-thread block of lane quads
 struct MerkleTailArgs {
   uint32_t top_log;
   const uint32_t* prev;                       // hashes of layer top_log + 1, or null
@@ -50,6 +50,10 @@ struct MerkleTailArgs {
   uint32_t* layers[MERKLE_TAIL_LOG + 1];      // output buffer of layer l
 };
 void merkle_tail(const MerkleTailArgs& a, hipStream_t st);
+// one layer with one node per quad of lanes (wide-and-short layers)
+void merkle_layer_quad(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
+                       uint32_t* d_out, hipStream_t st);
+constexpr uint32_t MERKLE_QUAD_MAX_LOG = 12, MERKLE_QUAD_MIN_COLS = 64;
 // up to MERKLE_MULTI_LEVELS consecutive layers per launch (top layer must have >= 256 nodes)
 constexpr uint32_t MERKLE_MULTI_LEVELS = 4;
 constexpr uint32_t MERKLE_MULTI_MAX_TOP = 19;  // layers of 2^19 nodes and more get their own launch

@@ -64,8 +64,16 @@ void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* con
                   uint32_t* d_out, hipStream_t st) {
   uint32_t n = 1u << log_size;
   // algorithmic bytes: column values once + 64 B of child hashes in, 32 B out per node
-  KProfScope kp("k_merkle_layer", (4.0 * ncols + (d_prev ? 64.0 : 0.0) + 32.0) * (double)n, st);
+  KProfScope kp("k_merkle_layer", (4.0 * ncols + (d_prev ? 64.0 : 0.0) + 32.0) * (double)n, st,
+                /* Blake2s compressions */ (double)n * ((d_prev ? 1.0 : 0.0) + (double)((ncols + 15) / 16)));
   hipLaunchKernelGGL(k_merkle_layer, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
+  CM_HIP(hipGetLastError());
+}
+void merkle_layer_quad(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
+                       uint32_t* d_out, hipStream_t st) {
+  uint32_t n = 1u << log_size;
+  KProfScope kp("k_merkle_layer_quad", (4.0 * ncols + (d_prev ? 64.0 : 0.0) + 32.0) * (double)n, st);
+  hipLaunchKernelGGL(k_merkle_layer_quad, dim3((4 * n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
   CM_HIP(hipGetLastError());
 }
 void merkle_multi(const MerkleMultiArgs& a, double alg_bytes, hipStream_t st) {

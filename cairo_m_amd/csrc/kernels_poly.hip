@@ -323,7 +323,8 @@ static void launch_pass(const uint32_t* const* d_src, uint32_t* const* d_dst, ui
   size_t lds = (size_t)4 << tile_log;
   // algorithmic bytes of one pass: every element written once; read once unless it is implicit zero padding
   KProfScope kp(INV ? "k_fft_pass<ifft>" : "k_fft_pass<fft>",
-                4.0 * ncols * ((double)(1u << n) + (double)(in_len < (1u << n) ? in_len : (1u << n))), st);
+                4.0 * ncols * ((double)(1u << n) + (double)(in_len < (1u << n) ? in_len : (1u << n))), st,
+                /* butterflies */ (double)ncols * (double)(1u << (n - 1)) * (double)(hi - lo));
   if (tile_log == FFT_TILE_LOG && fft_pass_r8_supported(W, M, lo)) launch_fft_pass_r8(INV, a, ntiles, ncols, st);
   else hipLaunchKernelGGL(k_fft_pass<INV>, dim3(ntiles, ncols), dim3(256), lds, st, a);
 }

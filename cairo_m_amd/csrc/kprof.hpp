@@ -12,8 +12,8 @@
 namespace cm {
 
 struct KProf {
-  struct Rec { const char* name; double bytes; hipEvent_t a, b; };
-  struct Agg { uint64_t calls = 0; double ms = 0, bytes = 0; };
+  struct Rec { const char* name; double bytes; hipEvent_t a, b; double work = 0; };
+  struct Agg { uint64_t calls = 0; double ms = 0, bytes = 0, work = 0; };  // work: ALU units (Blake2s compressions, butterflies)
   bool on = false;
   std::string only;  // when non-empty, only this kernel class is timed (keeps the event overhead out of a timed run)
   std::mutex mu;
@@ -27,7 +27,7 @@ struct KProf {
       float ms = 0;
       if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
         Agg& g = agg[r.name];
-        g.calls++; g.ms += ms; g.bytes += r.bytes;
+        g.calls++; g.ms += ms; g.bytes += r.bytes; g.work += r.work;
       }
       (void)hipEventDestroy(r.a);
       (void)hipEventDestroy(r.b);
@@ -68,7 +68,7 @@ struct KProfRegion {
     (void)hipEventRecord(b, st);
     KProf& k = KProf::get();
     std::lock_guard<std::mutex> lk(k.mu);
-    KProf::Rec r{name, bytes, a, b};
+    KProf::Rec r{name, bytes, a, b, 0.0};
     k.recs.push_back(r);
     k.region_calls[name] += calls ? calls - 1 : 0;  // flush() counts the record itself as one call
   }
@@ -79,12 +79,12 @@ struct KProfScope {
   bool active;
   KProf::Rec r;
   hipStream_t st;
-  KProfScope(const char* name, double bytes, hipStream_t s) : active(false), st(s) {
+  KProfScope(const char* name, double bytes, hipStream_t s, double work = 0) : active(false), st(s) {
     if (KProfRegion* reg = kprof_current_region()) { reg->bytes += bytes; reg->calls++; return; }
     KProf& k = KProf::get();
     active = k.on && (k.only.empty() || k.only == name);
     if (!active) return;
-    r.name = name; r.bytes = bytes;
+    r.name = name; r.bytes = bytes; r.work = work;
     (void)hipEventCreate(&r.a);
     (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.a, st);

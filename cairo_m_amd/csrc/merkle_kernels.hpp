@@ -118,38 +118,67 @@ __global__ void __launch_bounds__(256) k_merkle_multi(MerkleMultiArgs a) {
 // launch/dependency latency as separate kernels (26 trees x 10 layers per proof).  Hashes of the layer being
 // consumed stay in LDS; every layer is still written to HBM for the decommitment gathers.
 __global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
-  __shared__ uint32_t bufA[1024 * 8];
-  __shared__ uint32_t bufB[512 * 8];
-  uint32_t* buf[2];  // layer top -> A (<= 1024 nodes), top-1 -> B (<= 512), top-2 -> A, ...
+  // One node per QUAD of lanes (b2s_compress_quad): these layers have <= 256 nodes, so lanes are plentiful and
+  // the sequential compression chain per node (up to ~70 compressions for the 2^5-row idle components) is all
+  // that matters.
+  __shared__ uint32_t bufA[256 * 8];
+  __shared__ uint32_t bufB[128 * 8];
+  uint32_t* buf[2];  // layer top -> A (<= 256 nodes), top-1 -> B (<= 128), top-2 -> A, ...
   buf[0] = bufA;
   buf[1] = bufB;
-  const uint32_t tid = threadIdx.x;
+  const uint32_t node = threadIdx.x >> 2, q = threadIdx.x & 3u;
   int cur = 0;
   for (int l = (int)a.top_log; l >= 0; l--) {
     const uint32_t n = 1u << l;
-    if (tid < n) {
-      uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (node < n) {
+      uint32_t h0 = 0, h1 = 0;
       uint32_t m[16];
       const bool from_global = (l == (int)a.top_log);
       if (!from_global || a.prev) {
-        const uint32_t* p = from_global ? a.prev + (size_t)tid * 16 : buf[cur ^ 1] + tid * 16;
+        const uint32_t* p = from_global ? a.prev + (size_t)node * 16 : buf[cur ^ 1] + node * 16;
 #pragma unroll
         for (int k = 0; k < 16; k++) m[k] = p[k];
-        b2s_compress(h, m);
+        b2s_compress_quad(h0, h1, m, q);
       }
       const uint32_t c_begin = a.col_begin[l], c_end = a.col_end[l];
       for (uint32_t c0 = c_begin; c0 < c_end; c0 += 16) {
 #pragma unroll
-        for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? a.cols[c0 + k][tid] : 0u;
-        b2s_compress(h, m);
+        for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? a.cols[c0 + k][node] : 0u;
+        b2s_compress_quad(h0, h1, m, q);
       }
-      uint32_t* o = a.layers[l] + (size_t)tid * 8;
-#pragma unroll
-      for (int k = 0; k < 8; k++) { o[k] = h[k]; buf[cur][tid * 8 + k] = h[k]; }
+      uint32_t* o = a.layers[l] + (size_t)node * 8;
+      o[q] = h0; o[4 + q] = h1;
+      buf[cur][node * 8 + q] = h0; buf[cur][node * 8 + 4 + q] = h1;
     }
     __syncthreads();
     cur ^= 1;
   }
+}
+
+// One layer, one node per quad of lanes: for mid-size layers that carry hundreds of columns (poseidon2: 443
+// columns at 2^10 rows) the chain length per node dominates, not the node count.
+__global__ void __launch_bounds__(256) k_merkle_layer_quad(uint32_t log_size, const uint32_t* __restrict__ prev,
+                                                           const uint32_t* const* __restrict__ cols, uint32_t n_cols,
+                                                           uint32_t* __restrict__ out) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t i = t >> 2, q = t & 3u;
+  if (i >= (1u << log_size)) return;  // whole quads drop out together
+  uint32_t h0 = 0, h1 = 0;
+  uint32_t m[16];
+  if (prev) {
+    const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
+    uint4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
+    m[0] = x0.x; m[1] = x0.y; m[2] = x0.z; m[3] = x0.w; m[4] = x1.x; m[5] = x1.y; m[6] = x1.z; m[7] = x1.w;
+    m[8] = x2.x; m[9] = x2.y; m[10] = x2.z; m[11] = x2.w; m[12] = x3.x; m[13] = x3.y; m[14] = x3.z; m[15] = x3.w;
+    b2s_compress_quad(h0, h1, m, q);
+  }
+  for (uint32_t c0 = 0; c0 < n_cols; c0 += 16) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? cols[c0 + k][i] : 0u;
+    b2s_compress_quad(h0, h1, m, q);
+  }
+  out[(size_t)i * 8 + q] = h0;
+  out[(size_t)i * 8 + 4 + q] = h1;
 }
 
 }  // namespace cm

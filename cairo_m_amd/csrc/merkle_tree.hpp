@@ -98,12 +98,26 @@ struct MerkleTree {
       // big layers are throughput-bound: one node per thread with every lane busy beats the fused kernel
       // (whose parent levels run on half / quarter of the block); fusion pays only once launches are latency-bound
       if (log >= (int)MERKLE_MULTI_MAX_TOP) levels = 1;
-      if (levels == 1) {
+      // a mid-size layer carrying many columns is one long compression chain per node: quad-lane kernel
+      size_t n_here = 0;
+      while (ci + n_here < cols.size() && col_logs[ci + n_here] == (uint32_t)log) n_here++;
+      const bool wide = log <= (int)MERKLE_QUAD_MAX_LOG && n_here >= MERKLE_QUAD_MIN_COLS;
+      if (!wide && levels > 1) {  // a fused group must stop in front of a wide layer further down
+        size_t cj = ci + n_here;
+        for (int lv = 1; lv < levels; lv++) {
+          size_t cnt = 0;
+          while (cj + cnt < cols.size() && col_logs[cj + cnt] == (uint32_t)(log - lv)) cnt++;
+          if (log - lv <= (int)MERKLE_QUAD_MAX_LOG && cnt >= MERKLE_QUAD_MIN_COLS) { levels = lv; break; }
+          cj += cnt;
+        }
+      }
+      if (levels == 1 || wide) {
         size_t c0 = ci;
-        while (ci < cols.size() && col_logs[ci] == (uint32_t)log) ci++;
+        ci += n_here;
         layers[log].alloc((size_t)32 << log);
         const uint32_t* prev = (log < (int)max_log) ? layers[log + 1].u32() : nullptr;
-        merkle_layer((uint32_t)log, prev, d_cols.as<const uint32_t*>() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
+        if (wide) merkle_layer_quad((uint32_t)log, prev, d_cols.as<const uint32_t*>() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
+        else merkle_layer((uint32_t)log, prev, d_cols.as<const uint32_t*>() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
         log--;
         continue;
       }

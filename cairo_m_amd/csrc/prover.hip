@@ -1003,7 +1003,7 @@ int32_t cm_kprof_report(char* buf, size_t buf_len) {
     if (!first) s += ",";
     first = false;
     s += "\"" + kv.first + "\":{\"calls\":" + std::to_string(kv.second.calls) + ",\"ms\":" + std::to_string(kv.second.ms) +
-         ",\"bytes\":" + std::to_string(kv.second.bytes) + "}";
+         ",\"bytes\":" + std::to_string(kv.second.bytes) + ",\"work\":" + std::to_string(kv.second.work) + "}";
   }
   s += "}";
   if (buf && buf_len) { size_t n = s.size() < buf_len - 1 ? s.size() : buf_len - 1; memcpy(buf, s.data(), n); buf[n] = 0; }

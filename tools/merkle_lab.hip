@@ -138,6 +138,99 @@ __global__ void __launch_bounds__(64) k_layer_wide(uint32_t log_size, const uint
   o[1] = make_uint4(h[4], h[5], h[6], h[7]);
 }
 
+
+// ---- variant 4: one node per QUAD of lanes (wide-and-short layers are one sequential Blake2s chain per node:
+// spreading the 4 columns of the 4x4 state over 4 lanes shortens the chain ~3x).  Lane q of a quad holds state
+// column q: a = v[q], b = v[4+q], c = v[8+q], d = v[12+q]; the diagonal step rotates b, c, d by 1, 2, 3 lanes
+// with DPP quad_perm moves.  Every lane keeps all 16 message words (same addresses inside the quad: one fetch).
+#define QP(p0, p1, p2, p3) ((p0) | ((p1) << 2) | ((p2) << 4) | ((p3) << 6))
+#define quad_rot(x, ctrl) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ uint32_t sel4(uint32_t q, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+  uint32_t lo = (q & 1u) ? x1 : x0, hi = (q & 1u) ? x3 : x2;
+  return (q & 2u) ? hi : lo;
+}
+#define QG(x, y)                                \
+  a = a + b + (x); d = rotr(d ^ a, 16);         \
+  c = c + d;       b = rotr(b ^ c, 12);         \
+  a = a + b + (y); d = rotr(d ^ a, 8);          \
+  c = c + d;       b = rotr(b ^ c, 7);
+#define QROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                      \
+  QG(sel4(q, m[s0], m[s2], m[s4], m[s6]), sel4(q, m[s1], m[s3], m[s5], m[s7]))                            \
+  b = quad_rot(b, QP(1, 2, 3, 0)); c = quad_rot(c, QP(2, 3, 0, 1)); d = quad_rot(d, QP(3, 0, 1, 2));      \
+  QG(sel4(q, m[s8], m[s10], m[s12], m[s14]), sel4(q, m[s9], m[s11], m[s13], m[s15]))                      \
+  b = quad_rot(b, QP(3, 0, 1, 2)); c = quad_rot(c, QP(2, 3, 0, 1)); d = quad_rot(d, QP(1, 2, 3, 0));
+// h0 = h[q], h1 = h[4 + q] of the node's chaining value
+__device__ __forceinline__ void b2s_compress_quad(uint32_t& h0, uint32_t& h1, const uint32_t (&m)[16], uint32_t q) {
+  uint32_t a = h0, b = h1;
+  uint32_t c = sel4(q, 0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au);
+  uint32_t d = sel4(q, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u);
+  QROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  QROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+  QROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+  QROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+  QROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+  QROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+  QROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+  QROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+  QROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+  QROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+  h0 ^= a ^ c;
+  h1 ^= b ^ d;
+}
+__global__ void __launch_bounds__(256) k_layer_quad(uint32_t log_size, const uint32_t* __restrict__ prev,
+                                                    const uint32_t* const* __restrict__ cols, uint32_t n_cols,
+                                                    uint32_t* __restrict__ out) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t i = t >> 2, q = t & 3u;
+  if (i >= (1u << log_size)) return;  // whole quads drop out together
+  uint32_t h0 = 0, h1 = 0;
+  uint32_t m[16];
+  if (prev) {
+    const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
+    uint4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
+    m[0] = x0.x; m[1] = x0.y; m[2] = x0.z; m[3] = x0.w; m[4] = x1.x; m[5] = x1.y; m[6] = x1.z; m[7] = x1.w;
+    m[8] = x2.x; m[9] = x2.y; m[10] = x2.z; m[11] = x2.w; m[12] = x3.x; m[13] = x3.y; m[14] = x3.z; m[15] = x3.w;
+    b2s_compress_quad(h0, h1, m, q);
+  }
+  for (uint32_t c0 = 0; c0 < n_cols; c0 += 16) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? cols[c0 + k][i] : 0u;
+    b2s_compress_quad(h0, h1, m, q);
+  }
+  out[(size_t)i * 8 + q] = h0;
+  out[(size_t)i * 8 + 4 + q] = h1;
+}
+
+__global__ void __launch_bounds__(256) k_layer_quad_pf(uint32_t log_size, const uint32_t* __restrict__ prev,
+                                                       const uint32_t* const* __restrict__ cols, uint32_t n_cols,
+                                                       uint32_t* __restrict__ out) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t i = t >> 2, q = t & 3u;
+  if (i >= (1u << log_size)) return;
+  uint32_t h0 = 0, h1 = 0;
+  uint32_t m[16], nx[16];
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) nx[k] = (k < n_cols) ? cols[k][i] : 0u;
+  if (prev) {
+    const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
+    uint4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
+    m[0] = x0.x; m[1] = x0.y; m[2] = x0.z; m[3] = x0.w; m[4] = x1.x; m[5] = x1.y; m[6] = x1.z; m[7] = x1.w;
+    m[8] = x2.x; m[9] = x2.y; m[10] = x2.z; m[11] = x2.w; m[12] = x3.x; m[13] = x3.y; m[14] = x3.z; m[15] = x3.w;
+    b2s_compress_quad(h0, h1, m, q);
+  }
+  for (uint32_t c0 = 0; c0 < n_cols; c0 += 16) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = nx[k];
+    if (c0 + 16 < n_cols) {
+#pragma unroll
+      for (uint32_t k = 0; k < 16; k++) nx[k] = (c0 + 16 + k < n_cols) ? cols[c0 + 16 + k][i] : 0u;
+    }
+    b2s_compress_quad(h0, h1, m, q);
+  }
+  out[(size_t)i * 8 + q] = h0;
+  out[(size_t)i * 8 + 4 + q] = h1;
+}
+
 __global__ void k_fill(uint32_t* p, size_t n, uint32_t seed) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -228,6 +321,16 @@ int main() {
       CK(hipMemset(out1, 0, n * 32));
       float ms = time_it([&] { hipLaunchKernelGGL(k_layer_wide, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, s.log, prev, d_ptrs, s.ncols, out1); });
       report("v3 wave-blocks+prefetch", ms, out1);
+    }
+    {
+      CK(hipMemset(out1, 0, n * 32));
+      float ms = time_it([&] { hipLaunchKernelGGL(k_layer_quad, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, s.log, prev, d_ptrs, s.ncols, out1); });
+      report("v4 quad-lane Blake2s", ms, out1);
+    }
+    {
+      CK(hipMemset(out1, 0, n * 32));
+      float ms = time_it([&] { hipLaunchKernelGGL(k_layer_quad_pf, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, s.log, prev, d_ptrs, s.ncols, out1); });
+      report("v5 quad + prefetch", ms, out1);
     }
     CK(hipFree(colbuf)); CK(hipFree(d_ptrs)); if (prev) CK(hipFree(prev)); CK(hipFree(out0)); CK(hipFree(out1));
   }
