@@ -119,3 +119,18 @@ def test_metric_config_proof_verifies(backend, oracle):
     assert np.array_equal(out[0], w0) and np.array_equal(out[1], w0)
     backend.free_input(dev)
     inp.free()
+
+
+def test_2pow24_rows_segment_verifies(backend, oracle):
+    """BASELINE configs[3] workload on ONE GPU: fibonacci_loop with 16 770 012 steps (2^24 rows, 7.7e8 committed
+    cells, largest column 2^23 rows -> 2^25-point composition LDE).  The oracle verifier accepts the proof."""
+    inp = synth_fibonacci(1_677_000)
+    assert inp.steps == 16_770_012
+    dev = backend.upload_input(inp)
+    p = backend.prove_device(dev)
+    assert p.stats()["cells"] > 7e8
+    rc, err = oracle.verify(p.words())
+    assert rc == 0, err
+    p.free()
+    backend.free_input(dev)
+    inp.free()
