@@ -38,6 +38,7 @@ struct LogupTailJob {
   uint32_t* col[4];     // last 4 interaction columns (trace domain, bit-reversed circle order)
   uint32_t log_size;
   uint32_t tmp_off, btot_off;  // filled by logup_finalize_all
+  uint32_t id, pad;            // index of the job in the caller's list (claimed sums / shifts)
 };
 void logup_finalize_all(const std::vector<LogupTailJob>& jobs, uint32_t* d_sums, hipStream_t st);
 void launch_preproc(int pp_id, uint32_t log_size, uint32_t* d_col, hipStream_t st);
