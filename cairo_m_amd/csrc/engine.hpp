@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
+#include <string.h>
+#include <utility>
 #include "field.hpp"
 #include "device_common.hpp"
 
@@ -145,5 +147,25 @@ inline DevBuf upload(const std::vector<T>& v, hipStream_t st) {
   if (!v.empty()) stage_upload(b.p, v.data(), v.size() * sizeof(T), st);
   return b;
 }
+
+// Several small host tables -> ONE host->device copy.  add() records where the device address of a table has
+// to be stored; flush() uploads the concatenation and patches those pointers.  The returned buffer owns the
+// tables and must outlive their users.
+struct UploadBatch {
+  std::vector<uint8_t> blob;
+  std::vector<std::pair<void**, size_t>> fixups;
+  template <class T, class U>
+  void add(const std::vector<T>& v, U** out_dev_ptr) {
+    size_t off = (blob.size() + 15) & ~(size_t)15;
+    blob.resize(off + v.size() * sizeof(T));
+    if (!v.empty()) memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+    fixups.push_back({(void**)out_dev_ptr, off});
+  }
+  DevBuf flush(hipStream_t st) {
+    DevBuf b = upload(blob, st);
+    for (auto& f : fixups) *f.first = (uint8_t*)b.p + f.second;
+    return b;
+  }
+};
 
 }  // namespace cm

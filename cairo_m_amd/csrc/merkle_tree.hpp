@@ -79,16 +79,28 @@ struct MerkleTree {
   std::vector<uint32_t> col_logs;        // same order
   DevBuf d_cols;                         // device copy of `cols`
 
-  void commit(const std::vector<const uint32_t*>& columns, const std::vector<uint32_t>& logs, hipStream_t st) {
+  const uint32_t* const* d_cols_view = nullptr;  // device copy of `cols` inside somebody else's upload (UploadBatch)
+  const uint32_t* const* dcols() const { return d_cols_view ? d_cols_view : d_cols.as<const uint32_t*>(); }
+
+  // sort the columns (stable, by size descending): fills `cols` / `col_logs`
+  void prepare(const std::vector<const uint32_t*>& columns, const std::vector<uint32_t>& logs) {
     std::vector<uint32_t> order(columns.size());
     for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return logs[a] > logs[b]; });
     cols.clear(); col_logs.clear();
     for (auto i : order) { cols.push_back(columns[i]); col_logs.push_back(logs[i]); }
+    d_cols_view = nullptr;
+  }
+  void commit(const std::vector<const uint32_t*>& columns, const std::vector<uint32_t>& logs, hipStream_t st) {
+    prepare(columns, logs);
+    d_cols = upload(cols, st);
+    commit_prepared(st);
+  }
+  // after prepare(); the device copy of `cols` is either d_cols or d_cols_view
+  void commit_prepared(hipStream_t st) {
     uint32_t max_log = cols.empty() ? 0 : col_logs[0];
     layers.clear();
     layers.resize(max_log + 1);
-    d_cols = upload(cols, st);
     size_t ci = 0;
     const int tail_top = (int)std::min<uint32_t>(max_log, MERKLE_TAIL_LOG);
     for (int log = (int)max_log; log > tail_top;) {
@@ -116,8 +128,8 @@ struct MerkleTree {
         ci += n_here;
         layers[log].alloc((size_t)32 << log);
         const uint32_t* prev = (log < (int)max_log) ? layers[log + 1].u32() : nullptr;
-        if (wide) merkle_layer_quad((uint32_t)log, prev, d_cols.as<const uint32_t*>() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
-        else merkle_layer((uint32_t)log, prev, d_cols.as<const uint32_t*>() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
+        if (wide) merkle_layer_quad((uint32_t)log, prev, dcols() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
+        else merkle_layer((uint32_t)log, prev, dcols() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
         log--;
         continue;
       }
@@ -125,7 +137,7 @@ struct MerkleTree {
       a.top_log = (uint32_t)log;
       a.n_levels = (uint32_t)levels;
       a.prev = (log < (int)max_log) ? layers[log + 1].u32() : nullptr;
-      a.cols = d_cols.as<const uint32_t*>();
+      a.cols = dcols();
       double bytes = 0;
       for (int lv = 0; lv < levels; lv++) {
         int l = log - lv;
@@ -144,7 +156,7 @@ struct MerkleTree {
       MerkleTailArgs a;
       a.top_log = (uint32_t)tail_top;
       a.prev = (tail_top < (int)max_log) ? layers[tail_top + 1].u32() : nullptr;
-      a.cols = d_cols.as<const uint32_t*>();
+      a.cols = dcols();
       for (int log = tail_top; log >= 0; log--) {
         a.col_begin[log] = (uint32_t)ci;
         while (ci < cols.size() && col_logs[ci] == (uint32_t)log) ci++;
@@ -190,8 +202,8 @@ struct MerkleTree {
         bool isq = qi < colq.size() && colq[qi] == node;
         if (isq) qi++;
         if (ci > c0) {
-          if (d_cols.p) {
-            size_t off = gb.add_run(d_cols.as<const uint32_t*>() + c0, (uint32_t)(ci - c0), node);
+          if (dcols()) {
+            size_t off = gb.add_run(dcols() + c0, (uint32_t)(ci - c0), node);
             plan.segs.push_back(DecommitPlan::Seg{1u, isq ? 1u : 0u, off, (uint32_t)(ci - c0)});
           } else {  // trees whose column table never went to the device (FRI tail layers: 4 columns)
             size_t off = gb.word_addrs.size();

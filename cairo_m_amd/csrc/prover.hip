@@ -88,6 +88,7 @@ struct ColumnSet {
   std::vector<uint32_t> logs;
   std::vector<uint32_t*> ptrs;
   DevBuf buf, d_ptrs;
+  uint32_t** d_view = nullptr;  // device pointer table living in somebody else's upload (UploadBatch)
   void alloc(const std::vector<uint32_t>& logs_, hipStream_t st, bool upload_ptrs = true) {
     logs = logs_;
     size_t total = 0;
@@ -96,9 +97,11 @@ struct ColumnSet {
     ptrs.resize(logs.size());
     size_t off = 0;
     for (size_t i = 0; i < logs.size(); i++) { ptrs[i] = buf.u32() + off; off += (size_t)1 << logs[i]; }
+    d_view = nullptr;
     if (upload_ptrs) d_ptrs = upload(ptrs, st);
   }
   uint32_t* const* dev(size_t first = 0) const {
+    if (d_view) return d_view + first;
     CM_CHECK(d_ptrs.p, "ColumnSet::dev(): pointer table was not uploaded");
     return d_ptrs.as<uint32_t*>() + first;
   }
@@ -116,6 +119,7 @@ struct CommittedTree {
   ColumnSet coeffs, lde;
   MerkleTree merkle;
   hostch::Hash32 root;
+  DevBuf tables;  // one upload: pointer tables of coeffs / lde / the FFT groups / the Merkle column order
 };
 
 struct Prover {
@@ -137,12 +141,14 @@ struct Prover {
   // IFFT src(evals, trace domain) -> tree.coeffs; LDE -> tree.lde; Merkle; mix root.
   // If `in_place`, coeffs aliases src (src is consumed).
   void commit(CommittedTree& t, ColumnSet* evals, bool from_coeffs) {
-    const std::vector<uint32_t>& logs = from_coeffs ? t.coeffs.logs : evals->logs;
-    if (!from_coeffs) t.coeffs.alloc(logs, st);
+    const std::vector<uint32_t> logs = from_coeffs ? t.coeffs.logs : evals->logs;
+    UploadBatch ub;
+    if (!from_coeffs) { t.coeffs.alloc(logs, st, false); ub.add(t.coeffs.ptrs, &t.coeffs.d_view); }
     std::vector<uint32_t> lde_logs(logs);
     for (auto& l : lde_logs) l += cfg.log_blowup_factor;
-    t.lde.alloc(lde_logs, st);
-    // one pointer-table upload for all size groups of the tree: [src | coeffs | lde] per group
+    t.lde.alloc(lde_logs, st, false);
+    ub.add(t.lde.ptrs, &t.lde.d_view);
+    // pointer table of all size groups of the tree: [src | coeffs | lde] per group
     struct Grp { uint32_t log, n; size_t off; };
     std::vector<Grp> grps;
     std::vector<const uint32_t*> table;
@@ -153,16 +159,20 @@ struct Prover {
       for (auto i : kv.second) table.push_back(t.lde.ptrs[i]);
       grps.push_back(g);
     }
-    DevBuf d_table = upload(table, st);
+    const uint32_t** d_table = nullptr;
+    ub.add(table, &d_table);
+    std::vector<const uint32_t*> cols(t.lde.ptrs.begin(), t.lde.ptrs.end());
+    t.merkle.prepare(cols, t.lde.logs);
+    ub.add(t.merkle.cols, &t.merkle.d_cols_view);
+    t.tables = ub.flush(st);   // ONE host->device copy for the whole tree
     for (auto& g : grps) {
-      const uint32_t* const* dsrc = d_table.as<const uint32_t*>() + g.off;
-      uint32_t* const* dco = (uint32_t* const*)(d_table.as<uint32_t*>() + g.off + g.n);
-      uint32_t* const* dld = (uint32_t* const*)(d_table.as<uint32_t*>() + g.off + 2 * g.n);
+      const uint32_t* const* dsrc = d_table + g.off;
+      uint32_t* const* dco = (uint32_t* const*)(d_table + g.off + g.n);
+      uint32_t* const* dld = (uint32_t* const*)(d_table + g.off + 2 * g.n);
       if (!from_coeffs) interpolate_oop(dsrc, dco, g.n, g.log, *tw, st);
       evaluate((const uint32_t* const*)dco, dld, g.n, g.log, g.log + cfg.log_blowup_factor, *tw, st);
     }
-    std::vector<const uint32_t*> cols(t.lde.ptrs.begin(), t.lde.ptrs.end());
-    t.merkle.commit(cols, t.lde.logs, st);
+    t.merkle.commit_prepared(st);
     t.merkle.root(t.root.data(), st);
     ch.mix_root(t.root);
   }
@@ -313,10 +323,15 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     h.rc8 = tr_evals.ptrs[tr0[air::C_RC8]]; h.rc16 = tr_evals.ptrs[tr0[air::C_RC16]];
     h.rc20 = tr_evals.ptrs[tr0[air::C_RC20]]; h.bitwise = tr_evals.ptrs[tr0[air::C_BITWISE]];
     h.error_flag = flag.u32();
-    CM_HIP(hipMemsetAsync(h.rc8, 0, 4u << 8, st));
-    CM_HIP(hipMemsetAsync(h.rc16, 0, 4u << 16, st));
-    CM_HIP(hipMemsetAsync(h.rc20, 0, 4u << 20, st));
-    CM_HIP(hipMemsetAsync(h.bitwise, 0, 4u << 18, st));
+    if (h.rc16 == h.rc8 + (1u << 8) && h.rc20 == h.rc16 + (1u << 16) && h.bitwise == h.rc20 + (1u << 20)) {
+      // the four multiplicity columns are adjacent in the trace arena: one memset
+      CM_HIP(hipMemsetAsync(h.rc8, 0, 4 * ((size_t)(1u << 8) + (1u << 16) + (1u << 20) + (1u << 18)), st));
+    } else {
+      CM_HIP(hipMemsetAsync(h.rc8, 0, 4u << 8, st));
+      CM_HIP(hipMemsetAsync(h.rc16, 0, 4u << 16, st));
+      CM_HIP(hipMemsetAsync(h.rc20, 0, 4u << 20, st));
+      CM_HIP(hipMemsetAsync(h.bitwise, 0, 4u << 18, st));
+    }
     // components are independent: fork over side streams (trace then histogram of one component stay ordered)
     KProfRegion kreg("k_trace_gen(region)", st);
     Fork fk(st);
@@ -428,12 +443,26 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   std::vector<uint32_t> powers_w(4 * total_constraints);
   for (size_t g = 0; g < total_constraints; g++) powers[g].to_u32(&powers_w[4 * g]);
   DevBuf d_powers = upload(powers_w, st);
-  std::map<uint32_t, ColumnSet> accs;  // evaluation log -> 4 accumulator columns
+  // accumulators: 4 columns per evaluation log.  The top size gets its own ColumnSet (it becomes the coefficient
+  // set of tree 3), all smaller sizes share one — two pointer-table uploads and two memsets instead of one pair
+  // per size.
+  struct AccRef { ColumnSet* set; size_t first; uint32_t* const* dev() const { return set->dev(first); } };
+  std::map<uint32_t, AccRef> accs;  // evaluation log -> its 4 accumulator columns
   std::map<uint32_t, std::vector<int>> cgroups;
   for (int c = 0; c < air::N_COMPONENTS; c++) cgroups[clog[c] + 1].push_back(c);
-  for (auto& kv : cgroups) {
-    accs[kv.first].alloc(std::vector<uint32_t>(4, kv.first), st);
-    CM_HIP(hipMemsetAsync(accs[kv.first].buf.p, 0, accs[kv.first].buf.bytes, st));
+  ColumnSet acc_top, acc_rest;
+  {
+    std::vector<uint32_t> rest_logs;
+    for (auto& kv : cgroups)
+      if (kv.first != comp_log) { accs[kv.first] = AccRef{&acc_rest, rest_logs.size()}; rest_logs.insert(rest_logs.end(), 4, kv.first); }
+    CM_CHECK(cgroups.count(comp_log), "composition polynomial log size mismatch");
+    accs[comp_log] = AccRef{&acc_top, 0};
+    acc_top.alloc(std::vector<uint32_t>(4, comp_log), st);
+    CM_HIP(hipMemsetAsync(acc_top.buf.p, 0, acc_top.buf.bytes, st));
+    if (!rest_logs.empty()) {
+      acc_rest.alloc(rest_logs, st);
+      CM_HIP(hipMemsetAsync(acc_rest.buf.p, 0, acc_rest.buf.bytes, st));
+    }
   }
   CM_CHECK(cfg.log_blowup_factor == 1, "constraint evaluation reuses the committed LDE: log_blowup_factor must be 1");
   {
@@ -480,7 +509,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
           a.acc = d_slot_tab.as<uint32_t*>() + 4 * slot_of[c];
           sc = fk.stream(4 + (small_rr++ % 4));
         } else {
-          a.acc = accs[it->first].dev();
+          a.acc = accs.at(it->first).dev();
           sc = fk.stream(gi % 4);
         }
         a.log_size = clog[c];
@@ -495,7 +524,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     }
     fk.join();
     kreg.close();
-    for (auto& g : sgroups) sum_slots(accs[g.el].dev(), slots.u32() + g.off_words, g.n, g.el, st);
+    for (auto& g : sgroups) sum_slots(accs.at(g.el).dev(), slots.u32() + g.off_words, g.n, g.el, st);
   }
   P.tick("constraints");
   // DomainEvaluationAccumulator::finalize.  Stwo walks the sizes upward: interpolate(vals_l + evaluate_l(cur)).
@@ -511,11 +540,9 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       for (auto it = accs.rbegin(); it != accs.rend(); ++it, ++k) interpolate(it->second.dev(), 4, it->first, *P.tw, fk.stream(k));
       fk.join();
     }
-    ColumnSet& top = accs.rbegin()->second;
-    CM_CHECK(accs.rbegin()->first == comp_log, "composition polynomial log size mismatch");
     for (auto& kv : accs)
-      if (kv.first != comp_log) add_columns(top.dev(), (const uint32_t* const*)kv.second.dev(), 4, 1u << kv.first, st);
-    t.coeffs = std::move(top);
+      if (kv.first != comp_log) add_columns(acc_top.dev(), (const uint32_t* const*)kv.second.dev(), 4, 1u << kv.first, st);
+    t.coeffs = std::move(acc_top);
     P.commit(t, nullptr, true);
   }
   P.tick("composition_commit");
@@ -698,19 +725,41 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     cw[8] = ch.n_sent;
     stage_upload(d_chan.p, cw, sizeof(cw), st);
   }
+  struct InnerLayer { ColumnSet eval; uint32_t log; MerkleTree tree; hostch::Hash32 root; };
+  std::vector<std::unique_ptr<InnerLayer>> inner;
+  // every layer above the single-launch tail is allocated up front so that the column tables of all their
+  // Merkle trees (and of the first-layer tree) travel in ONE host->device copy
+  std::vector<std::unique_ptr<InnerLayer>> pre;
+  DevBuf fri_tables;
   {
+    UploadBatch ub;
     std::vector<const uint32_t*> cols;
     std::vector<uint32_t> logs;
     for (size_t k = 0; k < quotients.size(); k++) for (int c = 0; c < 4; c++) { cols.push_back(quotients[k].ptrs[c]); logs.push_back(q_logs[k]); }
-    first_tree.commit(cols, logs, st);
+    first_tree.prepare(cols, logs);
+    ub.add(first_tree.cols, &first_tree.d_cols_view);
+    for (uint32_t l = layer_log; l > last_log && l > FRI_TAIL_MAX_LOG; l--) {
+      std::unique_ptr<InnerLayer> il(new InnerLayer());
+      il->log = l;
+      il->eval.alloc(std::vector<uint32_t>(4, l), st, false);
+      std::vector<const uint32_t*> lc(il->eval.ptrs.begin(), il->eval.ptrs.end());
+      il->tree.prepare(lc, std::vector<uint32_t>(4, l));
+      ub.add(il->tree.cols, &il->tree.d_cols_view);
+      pre.push_back(std::move(il));
+    }
+    fri_tables = ub.flush(st);
+    first_tree.commit_prepared(st);
     chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
   }
-  struct InnerLayer { ColumnSet eval; uint32_t log; MerkleTree tree; hostch::Hash32 root; };
-  std::vector<std::unique_ptr<InnerLayer>> inner;
   ColumnSet layer;
-  layer.alloc(std::vector<uint32_t>(4, layer_log), st, false);
-  CM_HIP(hipMemsetAsync(layer.buf.p, 0, layer.buf.bytes, st));
-  size_t qi = 0;
+  if (!pre.empty()) {
+    // the first pre-allocated layer is the accumulation target of the circle folds
+    CM_HIP(hipMemsetAsync(pre[0]->eval.buf.p, 0, pre[0]->eval.buf.bytes, st));
+  } else {
+    layer.alloc(std::vector<uint32_t>(4, layer_log), st, false);
+    CM_HIP(hipMemsetAsync(layer.buf.p, 0, layer.buf.bytes, st));
+  }
+  size_t qi = 0, pi = 0;
   const QM31 unused_alpha;
   while (layer_log > last_log) {
     if (layer_log <= FRI_TAIL_MAX_LOG) {
@@ -748,26 +797,31 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       layer_log = last_log;
       break;
     }
+    // layers above the tail: buffers and tree tables were prepared above (pre[pi])
+    InnerLayer* cur = pre[pi].get();
     while (qi < quotients.size() && q_logs[qi] - 1 == layer_log) {
       const uint32_t* src[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
-      uint32_t* dst[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
+      uint32_t* dst[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
       fold_circle_into_line(dst, src, q_logs[qi], *P.tw, unused_alpha, true, st, d_alphas.u32());
       qi++;
     }
-    std::unique_ptr<InnerLayer> il(new InnerLayer());
-    il->log = layer_log;
-    il->eval = std::move(layer);
-    std::vector<const uint32_t*> cols(il->eval.ptrs.begin(), il->eval.ptrs.end());
-    il->tree.commit(cols, std::vector<uint32_t>(4, layer_log), st);
+    cur->tree.commit_prepared(st);
     const size_t li = inner.size() + 1;
-    chan_mix_root_draw(d_chan.u32(), il->tree.layers[0].u32(), d_alphas.u32() + 4 * li, d_roots.u32() + 8 * li, st);
-    layer = ColumnSet();
-    layer.alloc(std::vector<uint32_t>(4, layer_log - 1), st, false);
-    const uint32_t* src[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
-    uint32_t* dst[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
+    chan_mix_root_draw(d_chan.u32(), cur->tree.layers[0].u32(), d_alphas.u32() + 4 * li, d_roots.u32() + 8 * li, st);
+    // fold into the next layer: the next pre-allocated one, or a fresh buffer that the tail / last layer takes over
+    uint32_t* dst[4];
+    if (pi + 1 < pre.size()) {
+      for (int c = 0; c < 4; c++) dst[c] = pre[pi + 1]->eval.ptrs[c];
+    } else {
+      layer = ColumnSet();
+      layer.alloc(std::vector<uint32_t>(4, layer_log - 1), st, false);
+      for (int c = 0; c < 4; c++) dst[c] = layer.ptrs[c];
+    }
+    const uint32_t* src[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
     fold_line(dst, src, layer_log, *P.tw, unused_alpha, st, d_alphas.u32() + 4 * li);
     layer_log--;
-    inner.push_back(std::move(il));
+    inner.push_back(std::move(pre[pi]));
+    pi++;
   }
   CM_CHECK(qi == quotients.size(), "fri: not every quotient column was folded");
   // sanity check (stwo prove): composition OODS value == constraints at the sampled mask values.  Host-only
