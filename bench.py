@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--no-kprof", action="store_true", help="debug: no in-library HIP-event kernel timing")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent segment proofs in flight per GPU (one host thread + stream set each)")
+    ap.add_argument("--dist-backend", default="nccl", help="debug: gloo lets 2 ranks share one GPU (with --force-device 0)")
+    ap.add_argument("--force-device", type=int, default=-1, help="debug: every rank uses this device")
     ap.add_argument("--pipelined", type=int, default=3,
                     help="after the timed region, also measure throughput with this many segment proofs in flight "
                          "(reported as the extra `pipelined` object, N=1 only; 0 = skip)")
@@ -92,8 +94,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.force_device >= 0:
+            local_rank = args.force_device
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from cairo_m_amd import Backend
     from cairo_m_amd.lib import synth_fibonacci
@@ -174,7 +181,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         dist.barrier()
