@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
   const uint32_t high = blockIdx.x >> low_fixed_bits;
   const uint32_t base = (high << a.hi) | (lowf << M);
   const uint32_t t = threadIdx.x;
-  const uint32_t lo = a.lo;
+  const uint32_t lo = (W == 11) ? 0u : a.lo;  // the contiguous pass starts at layer 0: fold the shifts away
+  const bool padded = a.in_len < (1u << a.n);   // only the first pass of an LDE reads implicit zeros
   auto gidx = [&](uint32_t li) -> uint32_t { return base | ((li >> M) << lo) | (li & ((1u << M) - 1)); };
   M31 v[8];
 #pragma unroll
@@ -58,10 +59,15 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
     }
     const bool staged_in = (rr == 0) && INVERSE && M == 0;
     if (rr == 0 && !staged_in) {
+      if (padded) {
 #pragma unroll
-      for (uint32_t e = 0; e < 8; e++) {
-        uint32_t gi = gidx(li[e]);
-        v[e] = M31(gi < a.in_len ? src[gi] : 0u);
+        for (uint32_t e = 0; e < 8; e++) {
+          uint32_t gi = gidx(li[e]);
+          v[e] = M31(gi < a.in_len ? src[gi] : 0u);
+        }
+      } else {  // no per-element bounds test: 8 loads issue back to back instead of 8 exec-masked branches
+#pragma unroll
+        for (uint32_t e = 0; e < 8; e++) v[e] = M31(src[gidx(li[e])]);
       }
     } else {
       if (staged_in) {
@@ -70,7 +76,7 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
         for (uint32_t it = 0; it < 2; it++) {
           uint32_t w0 = (it * 256 + t) * 4;
           uint4 q = make_uint4(0, 0, 0, 0);
-          if (base + w0 < a.in_len) q = *reinterpret_cast<const uint4*>(src + base + w0);
+          if (!padded || base + w0 < a.in_len) q = *reinterpret_cast<const uint4*>(src + base + w0);
           tile[phys(w0)] = q.x; tile[phys(w0 + 1)] = q.y; tile[phys(w0 + 2)] = q.z; tile[phys(w0 + 3)] = q.w;
         }
         __syncthreads();

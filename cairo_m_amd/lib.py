@@ -8,7 +8,8 @@ import ctypes as C
 import os
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcairom_hip.so")
+# CAIROM_HIP_LIB: development override (A/B timing of two builds inside one GPU session); the shipped path is in-tree
+LIB_PATH = os.environ.get("CAIROM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcairom_hip.so")
 _u32p = C.POINTER(C.c_uint32)
 _u64p = C.POINTER(C.c_uint64)
 
