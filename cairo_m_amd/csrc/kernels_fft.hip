@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
         }
       } else {  // no per-element bounds test: 8 loads issue back to back instead of 8 exec-masked branches
 #pragma unroll
-        for (uint32_t e = 0; e < 8; e++) v[e] = M31(src[gidx(li[e])]);
+        for (uint32_t e = 0; e < 8; e++) { const uint32_t gi = gidx(li[e]); __builtin_assume(gi < (1u << 29)); v[e] = M31(src[gi]); }
       }
     } else {
       if (staged_in) {
@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
         const uint32_t g0 = e & ~((1u << k) - 1);  // j = 0 element of this group
         const uint32_t j = e & ((1u << k) - 1);
         const uint32_t h = (gidx(li[g0]) >> (layer + 1)) + (j >> (s + 1));
+        __builtin_assume(h < (1u << 29));  // byte offset fits 32 bits: saddr + 32-bit voffset addressing
         M31 w(twp[h]);
         M31 x = v[e], y = v[e1];
         if (INVERSE) { v[e] = x + y; v[e1] = (x - y) * w; }
