@@ -1,0 +1,327 @@
+// Device-side adapter: `import_from_runner_output` (/root/reference/crates/prover/src/adapter/mod.rs:97-193,
+// adapter/memory.rs:271-535) for one runner segment, with the O(steps) part on the GPU.
+//
+// The reference walks the memory log sequentially through a HashMap<address, (value, clock, multiplicity)>
+// to find, for every access, the previous access of the same cell.  Here:
+//   1. per step: opcode from the (immutable) program words at `pc`, entry / operand counts  -> exclusive scans
+//      give every step its slice of the memory log (checked against the log: first entry address == pc);
+//   2. all log entries are sorted by (address, entry index) with one 64-bit radix sort (hipCUB): the
+//      predecessor in the sorted order IS the previous access of the cell (or the segment's initial memory);
+//   3. clock-update rows (gaps > 2^20 - 1) are counted per entry, scanned and scattered in log order;
+//   4. steps are bucketed per opcode component with a stable 5-bit radix sort, bundles and data accesses are
+//      written straight into the device-resident ProverInput;
+//   5. one record per touched cell (first value, last value, last clock) is compacted for the host, which
+//      builds the boundary-memory rows, public multiplicities and the two partial Merkle trees (small:
+//      O(touched cells), shared with the host adapter).
+// Output order is identical to the host adapter (host_adapter.hpp) — tests compare the two field by field.
+#include "../../include/cairom_hip.h"
+#include "engine.hpp"
+#include "host_adapter.hpp"
+#include <hipcub/hipcub.hpp>
+
+namespace cm {
+
+struct DeviceInput;  // prover.hip
+DeviceInput* make_device_input(const cm_prover_input& meta_host_small, DevBuf (&bundles)[CM_N_OPCODE_COMPONENTS], DevBuf& data_accesses,
+                               DevBuf& clock_updates);
+
+namespace {
+
+struct OpTable { uint8_t size[64], acc[64], comp[64], valid[64]; };
+
+__global__ void k_step_counts(const uint32_t* __restrict__ trace, uint32_t n_steps, const uint32_t* __restrict__ init_mem,
+                              uint32_t n_init, OpTable tab, uint32_t* __restrict__ n_entries, uint32_t* __restrict__ n_acc,
+                              uint32_t* __restrict__ comp, uint32_t* __restrict__ err) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_steps) return;
+  uint32_t pc = trace[2 * t];
+  uint32_t op = pc < n_init ? init_mem[4 * (size_t)pc] : 64u;
+  if (op >= 64u || !tab.valid[op]) { atomicOr(err, 1u); n_entries[t] = 0; n_acc[t] = 0; comp[t] = 0; return; }
+  n_entries[t] = 1u + (tab.size[op] > 4 ? 1u : 0u) + tab.acc[op];
+  n_acc[t] = tab.acc[op];
+  comp[t] = tab.comp[op];
+}
+// keys[e] = (address << 32) | e ; clock of entry e = step + 1
+__global__ void k_entry_keys(const uint32_t* __restrict__ trace, uint32_t n_steps, const uint32_t* __restrict__ entry_off,
+                             const uint32_t* __restrict__ n_entries, const uint32_t* __restrict__ mem /*5 words each*/,
+                             uint32_t n_mem, unsigned long long* __restrict__ keys, uint32_t* __restrict__ entry_clock,
+                             uint32_t* __restrict__ err) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_steps) return;
+  uint32_t e0 = entry_off[t], n = n_entries[t];
+  if (e0 + n > n_mem) { atomicOr(err, 2u); return; }
+  if (n && mem[5 * (size_t)e0] != trace[2 * t]) atomicOr(err, 4u);  // first entry of a step is the fetch at pc
+  for (uint32_t k = 0; k < n; k++) {
+    uint32_t e = e0 + k;
+    keys[e] = ((unsigned long long)mem[5 * (size_t)e] << 32) | e;
+    entry_clock[e] = t + 1;
+  }
+}
+// sorted position i -> previous access of the same cell
+__global__ void k_prev_links(const unsigned long long* __restrict__ sorted, uint32_t n_mem, const uint32_t* __restrict__ mem,
+                             const uint32_t* __restrict__ entry_clock, const uint32_t* __restrict__ init_mem, uint32_t n_init,
+                             uint32_t* __restrict__ prev_clock /*adjusted*/, uint32_t* __restrict__ prev_val0,
+                             uint32_t* __restrict__ cu_count, uint32_t* __restrict__ cu_prev /*unadjusted prev clock*/,
+                             uint32_t* __restrict__ head_flag) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_mem) return;
+  unsigned long long k = sorted[i];
+  uint32_t addr = (uint32_t)(k >> 32), e = (uint32_t)k;
+  bool head = i == 0 || (uint32_t)(sorted[i - 1] >> 32) != addr;
+  head_flag[i] = head ? 1u : 0u;
+  uint32_t pclk, pv0;
+  if (head) {
+    pclk = 0;
+    pv0 = addr < n_init ? init_mem[4 * (size_t)addr] : mem[5 * (size_t)e + 1];
+  } else {
+    uint32_t pe = (uint32_t)sorted[i - 1];
+    pclk = entry_clock[pe];
+    pv0 = mem[5 * (size_t)pe + 1];
+  }
+  uint32_t clk = entry_clock[e];
+  uint32_t delta = clk - pclk;
+  uint32_t steps = delta > air::RC20_LIMIT ? delta / air::RC20_LIMIT : 0u;
+  cu_count[e] = steps;
+  cu_prev[e] = pclk;
+  prev_clock[e] = pclk + steps * air::RC20_LIMIT;
+  prev_val0[e] = pv0;
+}
+// run heads broadcast their sorted position (inclusive max-scan of head ? i : 0 done by hipCUB): the "initial value"
+// of a cell outside the initial memory is the value of its first access
+__global__ void k_head_pos(const uint32_t* __restrict__ head_flag, uint32_t n, uint32_t* __restrict__ pos) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos[i] = head_flag[i] ? i : 0u;
+}
+__global__ void k_entry_head(const unsigned long long* __restrict__ sorted, const uint32_t* __restrict__ head_pos, uint32_t n,
+                             uint32_t* __restrict__ head_entry) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) head_entry[(uint32_t)sorted[i]] = (uint32_t)sorted[head_pos[i]];
+}
+__global__ void k_clock_updates(const uint32_t* __restrict__ mem, uint32_t n_mem, const uint32_t* __restrict__ cu_count,
+                                const uint32_t* __restrict__ cu_off, const uint32_t* __restrict__ cu_prev,
+                                const uint32_t* __restrict__ head_entry, const uint32_t* __restrict__ init_mem, uint32_t n_init,
+                                cm_clock_update* __restrict__ out) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_mem) return;
+  uint32_t n = cu_count[e];
+  if (!n) return;
+  uint32_t addr = mem[5 * (size_t)e];
+  const uint32_t* iv = addr < n_init ? init_mem + 4 * (size_t)addr : mem + 5 * (size_t)head_entry[e] + 1;
+  uint32_t pclk = cu_prev[e];
+  for (uint32_t k = 0; k < n; k++) {
+    cm_clock_update u;
+    u.address = addr; u.prev_clock = pclk;
+    for (int j = 0; j < 4; j++) u.value[j] = iv[j];
+    out[cu_off[e] + k] = u;
+    pclk += air::RC20_LIMIT;
+  }
+}
+__global__ void k_iota(uint32_t* p, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+// sorted[] is non-decreasing with values < 32: ends[v] = index after the last occurrence of v
+__global__ void k_run_ends(const uint32_t* __restrict__ sorted, uint32_t n, uint32_t* __restrict__ ends) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i + 1 == n || sorted[i + 1] != sorted[i]) ends[sorted[i]] = i + 1;
+}
+struct BundleDst { cm_bundle* p[CM_N_OPCODE_COMPONENTS]; uint32_t start[CM_N_OPCODE_COMPONENTS + 1]; };
+// i = position in the component-sorted (stable) order of the steps
+__global__ void k_bundles(const uint32_t* __restrict__ sorted_step, uint32_t n_steps, const uint32_t* __restrict__ trace,
+                          const uint32_t* __restrict__ comp, const uint32_t* __restrict__ entry_off,
+                          const uint32_t* __restrict__ n_entries, const uint32_t* __restrict__ n_acc,
+                          const uint32_t* __restrict__ acc_off, const uint32_t* __restrict__ mem,
+                          const uint32_t* __restrict__ prev_clock, const uint32_t* __restrict__ prev_val0, BundleDst dst,
+                          cm_data_access* __restrict__ accesses, OpTable tab) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_steps) return;
+  uint32_t t = sorted_step[i], c = comp[t];
+  uint32_t e0 = entry_off[t], ne = n_entries[t], na = n_acc[t];
+  uint32_t ninst = ne - na;  // 1 or 2 instruction-word entries
+  cm_bundle b;
+  b.pc = trace[2 * t]; b.fp = trace[2 * t + 1]; b.clock = t + 1; b.inst_prev_clock = prev_clock[e0];
+  const uint32_t* w = mem + 5 * (size_t)e0 + 1;
+  const uint32_t sz = tab.size[w[0] & 63u];  // only the instruction's own words are kept (adapter/mod.rs:132-150)
+#pragma unroll
+  for (int k = 0; k < 4; k++) b.inst[k] = (uint32_t)k < sz ? w[k] : 0u;
+  b.inst[4] = sz > 4 ? w[5] : 0u;
+  b.inst[5] = sz > 5 ? w[6] : 0u;
+  b.span_start = acc_off[t]; b.span_len = na;
+  dst.p[c][i - dst.start[c]] = b;
+  for (uint32_t k = 0; k < na; k++) {
+    uint32_t e = e0 + ninst + k;
+    cm_data_access a;
+    a.address = mem[5 * (size_t)e]; a.prev_clock = prev_clock[e]; a.prev_value = prev_val0[e]; a.value = mem[5 * (size_t)e + 1];
+    accesses[acc_off[t] + k] = a;
+  }
+}
+// one record per touched cell: (address, first entry, last entry), compacted by the head flags' exclusive scan
+struct CellRec { uint32_t addr, first_entry, last_entry, last_clock; };
+__global__ void k_cells(const unsigned long long* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ head_flag,
+                        const uint32_t* __restrict__ head_rank /*exclusive scan of head_flag*/,
+                        const uint32_t* __restrict__ entry_clock, CellRec* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t addr = (uint32_t)(sorted[i] >> 32);
+  bool tail = i + 1 == n || (uint32_t)(sorted[i + 1] >> 32) != addr;
+  const uint32_t run = head_rank[i] - (head_flag[i] ? 0u : 1u);  // exclusive scan counts this run's head for i > head
+  if (head_flag[i]) { out[run].addr = addr; out[run].first_entry = (uint32_t)sorted[i]; }
+  if (tail) { out[run].last_entry = (uint32_t)sorted[i]; out[run].last_clock = entry_clock[(uint32_t)sorted[i]]; }
+}
+
+template <class F>
+void with_temp(F&& f) {  // hipCUB two-phase calls
+  size_t bytes = 0;
+  f(nullptr, bytes);
+  DevBuf tmp(bytes ? bytes : 4);
+  f(tmp.p, bytes);
+}
+inline dim3 grid1(uint32_t n) { return dim3((n + 255) / 256); }
+
+}  // namespace
+
+// host tail shared with the host adapter: boundary memory rows, public multiplicities, partial Merkle trees
+DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
+  bind_thread_to_library_device();
+  hipStream_t st = thread_main_stream();
+  CM_CHECK(seg.n_trace >= 2, "adapter: empty trace");
+  const uint32_t n_steps = (uint32_t)(seg.n_trace - 1), n_mem = (uint32_t)seg.n_memory_trace, n_init = (uint32_t)seg.n_initial_memory;
+  CM_CHECK(seg.n_memory_trace < (1ull << 32) && seg.n_trace < (1ull << 32), "adapter: segment too large");
+  // ---- upload the runner output ----
+  DevBuf d_trace(seg.n_trace * 8), d_mem((size_t)n_mem * 20 + 4), d_init((size_t)n_init * 16 + 4), d_err(4);
+  CM_HIP(hipMemcpyAsync(d_trace.p, seg.trace, seg.n_trace * 8, hipMemcpyHostToDevice, st));
+  if (n_mem) CM_HIP(hipMemcpyAsync(d_mem.p, seg.memory_trace, (size_t)n_mem * 20, hipMemcpyHostToDevice, st));
+  if (n_init) CM_HIP(hipMemcpyAsync(d_init.p, seg.initial_memory, (size_t)n_init * 16, hipMemcpyHostToDevice, st));
+  CM_HIP(hipMemsetAsync(d_err.p, 0, 4, st));
+  OpTable tab;
+  memset(&tab, 0, sizeof(tab));
+  for (uint32_t op = 0; op < 64; op++) {
+    host::OpInfo oi;
+    if (host::op_info(op, oi) && air::component_of_opcode(op) >= 0) {
+      tab.valid[op] = 1; tab.size[op] = (uint8_t)oi.size_m31; tab.acc[op] = (uint8_t)oi.accesses;
+      tab.comp[op] = (uint8_t)air::component_of_opcode(op);
+    }
+  }
+  // ---- 1. per-step counts and offsets ----
+  DevBuf d_ne((size_t)n_steps * 4 + 4), d_na((size_t)n_steps * 4 + 4), d_comp((size_t)n_steps * 4 + 4), d_eoff((size_t)n_steps * 4 + 4),
+      d_aoff((size_t)n_steps * 4 + 4);
+  hipLaunchKernelGGL(k_step_counts, grid1(n_steps), dim3(256), 0, st, d_trace.u32(), n_steps, d_init.u32(), n_init, tab, d_ne.u32(),
+                     d_na.u32(), d_comp.u32(), d_err.u32());
+  with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_ne.u32(), d_eoff.u32(), (int)n_steps, st)); });
+  with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_na.u32(), d_aoff.u32(), (int)n_steps, st)); });
+  // ---- 2. sort the log by (address, entry index) ----
+  uint32_t n_acc = 0;
+  DevBuf d_keys((size_t)n_mem * 8 + 8), d_sorted((size_t)n_mem * 8 + 8), d_eclk((size_t)n_mem * 4 + 4);
+  hipLaunchKernelGGL(k_entry_keys, grid1(n_steps), dim3(256), 0, st, d_trace.u32(), n_steps, d_eoff.u32(), d_ne.u32(), d_mem.u32(), n_mem,
+                     d_keys.as<unsigned long long>(), d_eclk.u32(), d_err.u32());
+  {
+    // totals + error flag are needed on the host before the sort sizes are trusted
+    uint32_t last[4] = {0, 0, 0, 0}, err = 0;
+    CM_HIP(hipMemcpyAsync(&last[0], d_eoff.u32() + (n_steps - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(&last[1], d_ne.u32() + (n_steps - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(&last[2], d_aoff.u32() + (n_steps - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(&last[3], d_na.u32() + (n_steps - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    CM_CHECK(!(err & 1u), "adapter: invalid opcode (or an opcode without a prover component)");
+    CM_CHECK(!(err & 2u) && last[0] + last[1] == n_mem, "adapter: memory trace length does not match the instructions executed");
+    CM_CHECK(!(err & 4u), "adapter: a step's first memory entry is not the instruction fetch at pc");
+    n_acc = last[2] + last[3];
+  }
+  with_temp([&](void* t, size_t& b) {
+    CM_HIP(hipcub::DeviceRadixSort::SortKeys(t, b, d_keys.as<unsigned long long>(), d_sorted.as<unsigned long long>(), (int)n_mem, 0, 62, st));
+  });
+  // ---- 3. previous accesses, clock updates ----
+  DevBuf d_pclk((size_t)n_mem * 4 + 4), d_pv0((size_t)n_mem * 4 + 4), d_cuc((size_t)n_mem * 4 + 4), d_cup((size_t)n_mem * 4 + 4),
+      d_head((size_t)n_mem * 4 + 4), d_hpos((size_t)n_mem * 4 + 4), d_hent((size_t)n_mem * 4 + 4), d_cuoff((size_t)n_mem * 4 + 4),
+      d_hrank((size_t)n_mem * 4 + 4);
+  hipLaunchKernelGGL(k_prev_links, grid1(n_mem), dim3(256), 0, st, d_sorted.as<unsigned long long>(), n_mem, d_mem.u32(), d_eclk.u32(),
+                     d_init.u32(), n_init, d_pclk.u32(), d_pv0.u32(), d_cuc.u32(), d_cup.u32(), d_head.u32());
+  hipLaunchKernelGGL(k_head_pos, grid1(n_mem), dim3(256), 0, st, d_head.u32(), n_mem, d_hpos.u32());
+  with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::InclusiveScan(t, b, d_hpos.u32(), d_hpos.u32(), hipcub::Max(), (int)n_mem, st)); });
+  hipLaunchKernelGGL(k_entry_head, grid1(n_mem), dim3(256), 0, st, d_sorted.as<unsigned long long>(), d_hpos.u32(), n_mem, d_hent.u32());
+  with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_cuc.u32(), d_cuoff.u32(), (int)n_mem, st)); });
+  with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_head.u32(), d_hrank.u32(), (int)n_mem, st)); });
+  uint32_t n_cu = 0, n_cells = 0;
+  {
+    uint32_t a[2] = {0, 0}, c[2] = {0, 0};
+    CM_HIP(hipMemcpyAsync(&a[0], d_cuoff.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(&a[1], d_cuc.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(&c[0], d_hrank.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(&c[1], d_head.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    n_cu = a[0] + a[1];
+    n_cells = c[0] + c[1];
+  }
+  DevBuf d_cu((size_t)n_cu * sizeof(cm_clock_update) + 4);
+  hipLaunchKernelGGL(k_clock_updates, grid1(n_mem), dim3(256), 0, st, d_mem.u32(), n_mem, d_cuc.u32(), d_cuoff.u32(), d_cup.u32(),
+                     d_hent.u32(), d_init.u32(), n_init, d_cu.as<cm_clock_update>());
+  // ---- 4. bundles per opcode component (stable 5-bit sort of the steps), data accesses ----
+  DevBuf d_steps((size_t)n_steps * 4 + 4), d_steps_sorted((size_t)n_steps * 4 + 4), d_comp_sorted((size_t)n_steps * 4 + 4);
+  hipLaunchKernelGGL(k_iota, grid1(n_steps), dim3(256), 0, st, d_steps.u32(), n_steps);
+  with_temp([&](void* t, size_t& b) {
+    CM_HIP(hipcub::DeviceRadixSort::SortPairs(t, b, d_comp.u32(), d_comp_sorted.u32(), d_steps.u32(), d_steps_sorted.u32(), (int)n_steps, 0, 5, st));
+  });
+  // component counts: the sorted component array is non-decreasing -> count = upper bound difference
+  DevBuf d_counts(32 * 4);
+  CM_HIP(hipMemsetAsync(d_counts.p, 0, 32 * 4, st));
+  hipLaunchKernelGGL(k_run_ends, grid1(n_steps), dim3(256), 0, st, d_comp_sorted.u32(), n_steps, d_counts.u32());
+  uint32_t ends[32];
+  CM_HIP(hipMemcpyAsync(ends, d_counts.p, sizeof(ends), hipMemcpyDeviceToHost, st));
+  CM_HIP(hipStreamSynchronize(st));
+  uint64_t counts[CM_N_OPCODE_COMPONENTS] = {0};
+  {
+    uint32_t prev_end = 0;  // ends[c] = one past the last step of component c in sorted order (0 if absent)
+    for (int c = 0; c < CM_N_OPCODE_COMPONENTS; c++)
+      if (ends[c]) { counts[c] = ends[c] - prev_end; prev_end = ends[c]; }
+  }
+  DevBuf bundles[CM_N_OPCODE_COMPONENTS];
+  BundleDst dst;
+  uint32_t run = 0;
+  for (int c = 0; c < CM_N_OPCODE_COMPONENTS; c++) {
+    bundles[c].alloc(counts[c] * sizeof(cm_bundle) + 4);
+    dst.p[c] = bundles[c].as<cm_bundle>();
+    dst.start[c] = run;
+    run += (uint32_t)counts[c];
+  }
+  dst.start[CM_N_OPCODE_COMPONENTS] = run;
+  DevBuf d_acc((size_t)n_acc * sizeof(cm_data_access) + 4);
+  hipLaunchKernelGGL(k_bundles, grid1(n_steps), dim3(256), 0, st, d_steps_sorted.u32(), n_steps, d_trace.u32(), d_comp.u32(), d_eoff.u32(),
+                     d_ne.u32(), d_na.u32(), d_aoff.u32(), d_mem.u32(), d_pclk.u32(), d_pv0.u32(), dst, d_acc.as<cm_data_access>(), tab);
+  // ---- 5. touched cells -> host: boundary memory, multiplicities, Merkle trees ----
+  DevBuf d_cells((size_t)n_cells * sizeof(CellRec) + 16);
+  hipLaunchKernelGGL(k_cells, grid1(n_mem), dim3(256), 0, st, d_sorted.as<unsigned long long>(), n_mem, d_head.u32(), d_hrank.u32(),
+                     d_eclk.u32(), d_cells.as<CellRec>());
+  std::vector<CellRec> cells(n_cells);
+  CM_HIP(hipMemcpyAsync(cells.data(), d_cells.p, (size_t)n_cells * sizeof(CellRec), hipMemcpyDeviceToHost, st));
+  CM_HIP(hipGetLastError());
+  CM_HIP(hipStreamSynchronize(st));
+  std::map<uint32_t, host::MemState> initial_memory, final_memory;
+  for (uint32_t a = 0; a < n_init; a++) {
+    host::MemState s{{seg.initial_memory[4 * (size_t)a], seg.initial_memory[4 * (size_t)a + 1], seg.initial_memory[4 * (size_t)a + 2],
+                      seg.initial_memory[4 * (size_t)a + 3]}, 0u, 0u};
+    initial_memory[a] = s;
+    final_memory[a] = s;
+  }
+  auto val = [&](uint32_t e) { const uint32_t* w = seg.memory_trace + 5 * (size_t)e + 1; return host::Cell{w[0], w[1], w[2], w[3]}; };
+  for (const CellRec& c : cells) {
+    auto it = initial_memory.find(c.addr);
+    if (it != initial_memory.end()) it->second.mult = 1;
+    else initial_memory[c.addr] = host::MemState{val(c.first_entry), 0u, 1u};
+    final_memory[c.addr] = host::MemState{val(c.last_entry), c.last_clock, host::M31_NEG1};
+  }
+  host::ProverInputOwned tail;
+  for (int i = 0; i < 2; i++) { tail.program_range[i] = seg.program_range[i]; tail.input_range[i] = seg.input_range[i]; tail.output_range[i] = seg.output_range[i]; }
+  host::finish_boundary_memory(initial_memory, final_memory, tail);
+  // ---- assemble the device-resident ProverInput ----
+  cm_prover_input meta = tail.view();
+  meta.initial_pc = seg.trace[0]; meta.initial_fp = seg.trace[1];
+  meta.final_pc = seg.trace[2 * (size_t)n_steps]; meta.final_fp = seg.trace[2 * (size_t)n_steps + 1];
+  for (int c = 0; c < CM_N_OPCODE_COMPONENTS; c++) { meta.bundles[c] = nullptr; meta.n_bundles[c] = counts[c]; }
+  meta.data_accesses = nullptr; meta.n_data_accesses = n_acc;
+  meta.clock_updates = nullptr; meta.n_clock_updates = n_cu;
+  return make_device_input(meta, bundles, d_acc, d_cu);
+}
+
+}  // namespace cm

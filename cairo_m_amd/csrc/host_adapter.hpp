@@ -347,6 +347,35 @@ struct MemoryTracker {
   }
 };
 
+// Tail of import_internal shared by the host and the device adapter: public-range multiplicities
+// (adapter/memory.rs:427-461), boundary memory rows in ascending address order, the two partial Merkle trees.
+// out.program_range / input_range / output_range must be set.
+inline void finish_boundary_memory(std::map<uint32_t, MemState>& initial_memory, std::map<uint32_t, MemState>& final_memory,
+                                   ProverInputOwned& out) {
+  const uint32_t* prog = out.program_range;
+  const uint32_t* inp = out.input_range;
+  const uint32_t* outp = out.output_range;
+  // update_multiplicities (adapter/memory.rs:427-461)
+  for (uint32_t addr = prog[0]; addr < prog[1]; addr++) {
+    auto i = initial_memory.find(addr); if (i != initial_memory.end()) i->second.mult = 0;
+    auto f = final_memory.find(addr); if (f != final_memory.end() && f->second.mult == 0) f->second.mult = M31_NEG1;
+  }
+  for (uint32_t addr = inp[0]; addr < inp[1]; addr++) {
+    auto i = initial_memory.find(addr); if (i != initial_memory.end()) i->second.mult = 0;
+    auto f = final_memory.find(addr); if (f != final_memory.end() && f->second.mult == 0) f->second.mult = M31_NEG1;
+  }
+  for (uint32_t addr = outp[0]; addr < outp[1]; addr++) {
+    auto f = final_memory.find(addr); if (f != final_memory.end()) f->second.mult = 0;
+    auto i = initial_memory.find(addr); if (i != initial_memory.end()) i->second.mult = 1;
+  }
+  for (auto& kv : initial_memory)
+    out.initial_memory.push_back(cm_memory_cell{kv.first, {kv.second.value[0], kv.second.value[1], kv.second.value[2], kv.second.value[3]}, kv.second.clock, kv.second.mult});
+  for (auto& kv : final_memory)
+    out.final_memory.push_back(cm_memory_cell{kv.first, {kv.second.value[0], kv.second.value[1], kv.second.value[2], kv.second.value[3]}, kv.second.clock, kv.second.mult});
+  out.initial_root = build_partial_merkle_tree(initial_memory, true, prog, inp, outp, out.initial_tree);
+  out.final_root = build_partial_merkle_tree(final_memory, false, prog, inp, outp, out.final_tree);
+}
+
 // import_internal (adapter/mod.rs:97-193)
 inline ProverInputOwned import_segment(const Segment& seg, const uint32_t prog[2], const uint32_t inp[2],
                                        const uint32_t outp[2]) {
@@ -403,25 +432,7 @@ inline ProverInputOwned import_segment(const Segment& seg, const uint32_t prog[2
   out.n_steps = seg.trace.size() - 1;
   out.final_pc = seg.trace.back()[0];
   out.final_fp = seg.trace.back()[1];
-  // update_multiplicities (adapter/memory.rs:427-461)
-  for (uint32_t addr = prog[0]; addr < prog[1]; addr++) {
-    auto i = initial_memory.find(addr); if (i != initial_memory.end()) i->second.mult = 0;
-    auto f = final_memory.find(addr); if (f != final_memory.end() && f->second.mult == 0) f->second.mult = M31_NEG1;
-  }
-  for (uint32_t addr = inp[0]; addr < inp[1]; addr++) {
-    auto i = initial_memory.find(addr); if (i != initial_memory.end()) i->second.mult = 0;
-    auto f = final_memory.find(addr); if (f != final_memory.end() && f->second.mult == 0) f->second.mult = M31_NEG1;
-  }
-  for (uint32_t addr = outp[0]; addr < outp[1]; addr++) {
-    auto f = final_memory.find(addr); if (f != final_memory.end()) f->second.mult = 0;
-    auto i = initial_memory.find(addr); if (i != initial_memory.end()) i->second.mult = 1;
-  }
-  for (auto& kv : initial_memory)
-    out.initial_memory.push_back(cm_memory_cell{kv.first, {kv.second.value[0], kv.second.value[1], kv.second.value[2], kv.second.value[3]}, kv.second.clock, kv.second.mult});
-  for (auto& kv : final_memory)
-    out.final_memory.push_back(cm_memory_cell{kv.first, {kv.second.value[0], kv.second.value[1], kv.second.value[2], kv.second.value[3]}, kv.second.clock, kv.second.mult});
-  out.initial_root = build_partial_merkle_tree(initial_memory, true, prog, inp, outp, out.initial_tree);
-  out.final_root = build_partial_merkle_tree(final_memory, false, prog, inp, outp, out.final_tree);
+  finish_boundary_memory(initial_memory, final_memory, out);
   return out;
 }
 

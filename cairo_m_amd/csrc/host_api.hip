@@ -44,6 +44,53 @@ int32_t cm_vm_run(const uint32_t* instr_words, const uint32_t* instr_lens, uint3
 int32_t cm_synth_fibonacci(uint32_t n, uint64_t max_steps, uint32_t segment_index, cm_host_input** out) {
   return build(cm::host::fibonacci_loop_program(), 0, {n}, 1, max_steps, segment_index, out, nullptr);
 }
+struct cm_host_segment {
+  cm::host::Segment seg;
+  std::vector<uint32_t> trace, mem, init;
+  cm_runner_segment view;
+};
+static int32_t build_segment(const std::vector<std::vector<uint32_t>>& program, uint32_t entry_pc, const std::vector<uint32_t>& args,
+                             uint32_t n_returns, uint64_t max_steps, uint32_t segment_index, cm_host_segment** out,
+                             uint32_t* n_segments_out) {
+  try {
+    uint32_t plen = 0;
+    std::vector<cm::host::Segment> segs = cm::host::run_program(program, entry_pc, args, n_returns, max_steps, &plen);
+    if (n_segments_out) *n_segments_out = (uint32_t)segs.size();
+    if (segment_index >= segs.size()) return cm_set_last_error("segment index out of range");
+    cm_host_segment* h = new cm_host_segment();
+    h->seg = std::move(segs[segment_index]);
+    for (auto& t : h->seg.trace) { h->trace.push_back(t[0]); h->trace.push_back(t[1]); }
+    for (auto& e : h->seg.memory_trace) { h->mem.push_back(e.addr); for (int k = 0; k < 4; k++) h->mem.push_back(e.value[k]); }
+    for (auto& c : h->seg.initial_memory) for (int k = 0; k < 4; k++) h->init.push_back(c[k]);
+    cm_runner_segment& v = h->view;
+    v.trace = h->trace.data(); v.n_trace = h->seg.trace.size();
+    v.memory_trace = h->mem.data(); v.n_memory_trace = h->seg.memory_trace.size();
+    v.initial_memory = h->init.data(); v.n_initial_memory = h->seg.initial_memory.size();
+    v.program_range[0] = 0; v.program_range[1] = plen;
+    v.input_range[0] = plen; v.input_range[1] = plen + (uint32_t)args.size();
+    v.output_range[0] = plen + (uint32_t)args.size(); v.output_range[1] = plen + (uint32_t)args.size() + n_returns;
+    *out = h;
+    return 0;
+  } catch (const std::exception& e) {
+    return cm_set_last_error(e.what());
+  }
+}
+int32_t cm_vm_segment(const uint32_t* instr_words, const uint32_t* instr_lens, uint32_t n_instr, uint32_t entry_pc,
+                      const uint32_t* args, uint32_t n_args, uint32_t n_returns, uint64_t max_steps, uint32_t segment_index,
+                      cm_host_segment** out, uint32_t* n_segments_out) {
+  std::vector<std::vector<uint32_t>> program;
+  size_t off = 0;
+  for (uint32_t i = 0; i < n_instr; i++) {
+    program.emplace_back(instr_words + off, instr_words + off + instr_lens[i]);
+    off += instr_lens[i];
+  }
+  return build_segment(program, entry_pc, std::vector<uint32_t>(args, args + n_args), n_returns, max_steps, segment_index, out, n_segments_out);
+}
+int32_t cm_synth_fibonacci_segment(uint32_t n, uint64_t max_steps, uint32_t segment_index, cm_host_segment** out) {
+  return build_segment(cm::host::fibonacci_loop_program(), 0, {n}, 1, max_steps, segment_index, out, nullptr);
+}
+const cm_runner_segment* cm_host_segment_view(const cm_host_segment* h) { return &h->view; }
+int32_t cm_host_segment_free(cm_host_segment* h) { delete h; return 0; }
 const cm_prover_input* cm_host_input_view(const cm_host_input* h) { return &h->view; }
 uint64_t cm_host_input_steps(const cm_host_input* h) { return h->owned.n_steps; }
 int32_t cm_host_input_free(cm_host_input* h) { delete h; return 0; }

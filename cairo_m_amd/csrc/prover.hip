@@ -13,6 +13,7 @@
 #include "proof.hpp"
 #include "kprof.hpp"
 #include "point_eval.hpp"
+#include "host_adapter.hpp"
 #include <chrono>
 #include <memory>
 #include <mutex>
@@ -81,6 +82,52 @@ DeviceInput* upload_input(const cm_prover_input& in) {
   up(d->fin_tree, in.final_tree, in.n_final_tree * sizeof(cm_merkle_node));
   d->public_data = make_public_data(in);
   return d;
+}
+
+// device adapter (adapter_device.hip): bulk arrays already live in HBM, the small boundary-memory / Merkle-tree
+// arrays come from the host (pointers in `meta`, valid during the call)
+DeviceInput* make_device_input(const cm_prover_input& meta, DevBuf (&bundles)[CM_N_OPCODE_COMPONENTS], DevBuf& data_accesses,
+                               DevBuf& clock_updates) {
+  DeviceInput* d = new DeviceInput();
+  d->meta = meta;
+  auto up = [](DevBuf& b, const void* p, size_t bytes) {
+    b.alloc(bytes);
+    if (bytes) CM_HIP(hipMemcpy(b.p, p, bytes, hipMemcpyHostToDevice));
+  };
+  for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) d->bundles[i] = std::move(bundles[i]);
+  d->data_accesses = std::move(data_accesses);
+  d->clock_updates = std::move(clock_updates);
+  up(d->init_mem, meta.initial_memory, meta.n_initial_memory * sizeof(cm_memory_cell));
+  up(d->fin_mem, meta.final_memory, meta.n_final_memory * sizeof(cm_memory_cell));
+  up(d->init_tree, meta.initial_tree, meta.n_initial_tree * sizeof(cm_merkle_node));
+  up(d->fin_tree, meta.final_tree, meta.n_final_tree * sizeof(cm_merkle_node));
+  d->public_data = make_public_data(meta);
+  // the host pointers of `meta` die with the caller's temporaries
+  for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) d->meta.bundles[i] = nullptr;
+  d->meta.data_accesses = nullptr; d->meta.initial_memory = nullptr; d->meta.final_memory = nullptr;
+  d->meta.clock_updates = nullptr; d->meta.initial_tree = nullptr; d->meta.final_tree = nullptr;
+  return d;
+}
+DeviceInput* adapt_segment_device(const cm_runner_segment& seg);  // adapter_device.hip
+// copy a device-resident input back to the host (tests)
+void download_input(const DeviceInput& d, host::ProverInputOwned& o) {
+  CM_HIP(hipDeviceSynchronize());
+  const cm_prover_input& m = d.meta;
+  o.initial_pc = m.initial_pc; o.initial_fp = m.initial_fp; o.final_pc = m.final_pc; o.final_fp = m.final_fp;
+  o.initial_root = m.initial_root; o.final_root = m.final_root;
+  for (int i = 0; i < 2; i++) { o.program_range[i] = m.program_range[i]; o.input_range[i] = m.input_range[i]; o.output_range[i] = m.output_range[i]; }
+  auto down = [](auto& vec, const DevBuf& b, uint64_t n) {
+    vec.resize(n);
+    if (n) CM_HIP(hipMemcpy(vec.data(), b.p, n * sizeof(vec[0]), hipMemcpyDeviceToHost));
+  };
+  o.n_steps = 0;
+  for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) { down(o.bundles[i], d.bundles[i], m.n_bundles[i]); o.n_steps += m.n_bundles[i]; }
+  down(o.data_accesses, d.data_accesses, m.n_data_accesses);
+  down(o.initial_memory, d.init_mem, m.n_initial_memory);
+  down(o.final_memory, d.fin_mem, m.n_final_memory);
+  down(o.clock_updates, d.clock_updates, m.n_clock_updates);
+  down(o.initial_tree, d.init_tree, m.n_initial_tree);
+  down(o.final_tree, d.fin_tree, m.n_final_tree);
 }
 
 // ---- column sets -------------------------------------------------------------------------------------------
@@ -996,6 +1043,18 @@ static cm_pcs_config default_cfg() { return cm_pcs_config{16, 1, 0, 80}; }
 extern "C" {
 int32_t cm_input_upload(const cm_prover_input* input, cm_device_input** out) {
   return pguard([&] { cm_device_input* h = new cm_device_input(); h->d = cm::upload_input(*input); *out = h; });
+}
+struct cm_host_input { cm::host::ProverInputOwned owned; cm_prover_input view; };  // = host_api.hip
+int32_t cm_adapt_segment_device(const cm_runner_segment* seg, cm_device_input** out) {
+  return pguard([&] { cm_device_input* h = new cm_device_input(); h->d = cm::adapt_segment_device(*seg); *out = h; });
+}
+int32_t cm_device_input_download(const cm_device_input* in, cm_host_input** out) {
+  return pguard([&] {
+    cm_host_input* h = new cm_host_input();
+    cm::download_input(*in->d, h->owned);
+    h->view = h->owned.view();
+    *out = h;
+  });
 }
 int32_t cm_input_free(cm_device_input* h) { if (h) { delete h->d; delete h; } return 0; }
 int32_t cm_prove_device(const cm_device_input* input, const cm_pcs_config* config, cm_proof** out) {

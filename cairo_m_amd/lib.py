@@ -270,3 +270,101 @@ Backend.prove = _backend_prove
 Backend.upload_input = _backend_upload
 Backend.prove_device = _backend_prove_device
 Backend.free_input = lambda self, h: self.L.cm_input_free(h)
+
+
+# ---- runner segments and the device-side adapter (include/cairom_hip.h: cm_runner_segment) -----------------
+N_OPCODE_COMPONENTS = 26
+
+
+class ProverInputView(C.Structure):
+    """cm_prover_input (read-only mirror, used to compare adapters field by field)."""
+    _fields_ = [("regs", C.c_uint32 * 4),
+                ("bundles", C.c_void_p * N_OPCODE_COMPONENTS), ("n_bundles", C.c_uint64 * N_OPCODE_COMPONENTS),
+                ("data_accesses", C.c_void_p), ("n_data_accesses", C.c_uint64),
+                ("initial_memory", C.c_void_p), ("n_initial_memory", C.c_uint64),
+                ("final_memory", C.c_void_p), ("n_final_memory", C.c_uint64),
+                ("clock_updates", C.c_void_p), ("n_clock_updates", C.c_uint64),
+                ("initial_tree", C.c_void_p), ("n_initial_tree", C.c_uint64),
+                ("final_tree", C.c_void_p), ("n_final_tree", C.c_uint64),
+                ("roots", C.c_uint32 * 2), ("ranges", C.c_uint32 * 6)]
+
+
+def prover_input_arrays(view_ptr):
+    """cm_prover_input* -> dict of numpy arrays / scalars (copies)."""
+    v = C.cast(view_ptr, C.POINTER(ProverInputView)).contents
+
+    def arr(ptr, n, words):
+        if not n:
+            return np.zeros((0, words), dtype=np.uint32)
+        return np.ctypeslib.as_array(C.cast(ptr, _u32p), shape=(int(n), words)).copy()
+
+    out = {"regs": list(v.regs), "roots": list(v.roots), "ranges": list(v.ranges)}
+    for i in range(N_OPCODE_COMPONENTS):
+        out[f"bundles{i}"] = arr(v.bundles[i], v.n_bundles[i], 12)
+    out["data_accesses"] = arr(v.data_accesses, v.n_data_accesses, 4)
+    out["initial_memory"] = arr(v.initial_memory, v.n_initial_memory, 7)
+    out["final_memory"] = arr(v.final_memory, v.n_final_memory, 7)
+    out["clock_updates"] = arr(v.clock_updates, v.n_clock_updates, 6)
+    out["initial_tree"] = arr(v.initial_tree, v.n_initial_tree, 8)
+    out["final_tree"] = arr(v.final_tree, v.n_final_tree, 8)
+    return out
+
+
+class HostSegment:
+    """Raw output of the synthetic VM for one segment (trace, memory log, memory at segment start)."""
+
+    def __init__(self, lib, handle):
+        self.L = lib
+        self.h = handle
+        self.L.cm_host_segment_view.restype = C.c_void_p
+
+    @property
+    def view(self):
+        return C.c_void_p(self.L.cm_host_segment_view(self.h))
+
+    def free(self):
+        if self.h:
+            self.L.cm_host_segment_free(self.h)
+            self.h = None
+
+
+def synth_fibonacci_segment(n, max_steps=1 << 30, segment=0, lib=None):
+    L = lib or load_library()
+    h = C.c_void_p()
+    rc = L.cm_synth_fibonacci_segment(C.c_uint32(n), C.c_uint64(max_steps), C.c_uint32(segment), C.byref(h))
+    if rc:
+        raise _lib_error(L, rc)
+    return HostSegment(L, h)
+
+
+def vm_segment(program, entry_pc=0, args=(), n_returns=0, max_steps=1 << 30, segment=0, lib=None):
+    L = lib or load_library()
+    words = np.array([w for ins in program for w in ins], dtype=np.uint32)
+    lens = np.array([len(ins) for ins in program], dtype=np.uint32)
+    a = np.array(list(args), dtype=np.uint32)
+    h = C.c_void_p()
+    nseg = C.c_uint32(0)
+    rc = L.cm_vm_segment(_p(words), _p(lens), C.c_uint32(len(program)), C.c_uint32(entry_pc), _p(a), C.c_uint32(len(a)),
+                         C.c_uint32(n_returns), C.c_uint64(max_steps), C.c_uint32(segment), C.byref(h), C.byref(nseg))
+    if rc:
+        raise _lib_error(L, rc)
+    hs = HostSegment(L, h)
+    hs.n_segments = nseg.value
+    return hs
+
+
+def _backend_adapt_segment(self, host_segment):
+    """import_from_runner_output on the GPU: runner segment -> device-resident ProverInput."""
+    h = C.c_void_p()
+    self._ck(self.L.cm_adapt_segment_device(host_segment.view, C.byref(h)))
+    return h
+
+
+def _backend_download_input(self, dev_input):
+    h = C.c_void_p()
+    self._ck(self.L.cm_device_input_download(dev_input, C.byref(h)))
+    return HostInput(self.L, h)
+
+
+Backend.adapt_segment = _backend_adapt_segment
+Backend.download_input = _backend_download_input

@@ -212,6 +212,32 @@ int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* 
 int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out);
 /* The four commitment roots (trees 0..3), 32 bytes each. */
 int32_t cm_proof_commitments(const cm_proof* p, uint8_t roots[4][32]);
+/* ---- device-side adapter -----------------------------------------------------------------
+ * One runner segment in the runner's own terms: the VM trace, the memory access log and the memory at
+ * segment start (crates/runner/src/vm/mod.rs:306-375, crates/common/src/execution.rs:28-66).
+ * cm_adapt_segment_device = import_from_runner_output (crates/prover/src/adapter/mod.rs:97-193) with the
+ * per-step work (previous-access tracking, clock updates, opcode bucketing) on the GPU; the result is the
+ * device-resident ProverInput cm_prove_device consumes.  Same row order as the host adapter (cm_vm_run). */
+typedef struct {
+  const uint32_t* trace;           /* (pc, fp) pairs: n_trace = steps + 1 entries */
+  uint64_t n_trace;
+  const uint32_t* memory_trace;    /* (address, v0, v1, v2, v3): 5 words per logged access, in execution order */
+  uint64_t n_memory_trace;
+  const uint32_t* initial_memory;  /* 4 words per cell: addresses 0 .. n_initial_memory-1 at segment start */
+  uint64_t n_initial_memory;
+  uint32_t program_range[2], input_range[2], output_range[2];
+} cm_runner_segment;
+int32_t cm_adapt_segment_device(const cm_runner_segment* seg, cm_device_input** out);
+/* Copy a device-resident ProverInput back (tests: device adapter vs host adapter). */
+int32_t cm_device_input_download(const cm_device_input* in, cm_host_input** out);
+/* The synthetic VM's raw output for one segment (what cm_vm_run feeds to the host adapter). */
+typedef struct cm_host_segment cm_host_segment;
+int32_t cm_vm_segment(const uint32_t* instr_words, const uint32_t* instr_lens, uint32_t n_instr, uint32_t entry_pc,
+                      const uint32_t* args, uint32_t n_args, uint32_t n_returns, uint64_t max_steps,
+                      uint32_t segment_index, cm_host_segment** out, uint32_t* n_segments_out);
+int32_t cm_synth_fibonacci_segment(uint32_t n, uint64_t max_steps, uint32_t segment_index, cm_host_segment** out);
+const cm_runner_segment* cm_host_segment_view(const cm_host_segment* h);
+int32_t cm_host_segment_free(cm_host_segment* h);
 /* Optional HIP-event kernel timing on the launch stream (bench.py `roofline`). */
 int32_t cm_kprof_enable(int32_t on);
 int32_t cm_kprof_report(char* buf, size_t buf_len);

@@ -81,3 +81,26 @@ def test_poseidon2_host_matches_reference_kat():
     s = np.array(kat["input"], dtype=np.uint32)
     L.cm_poseidon2_permute(s.ctypes.data_as(C.POINTER(C.c_uint32)))
     assert [f"{int(x):08x}" for x in s] == kat["output_hex"]
+
+
+def test_runner_segment_view_matches_host_input():
+    """cm_vm_segment / cm_synth_fibonacci_segment expose the raw runner output (the device adapter's input):
+    trace = steps + 1 states, the memory log holds one entry per instruction word cell and operand access."""
+    import ctypes as C
+    from cairo_m_amd.lib import prover_input_arrays, synth_fibonacci, synth_fibonacci_segment
+
+    class Seg(C.Structure):
+        _fields_ = [("trace", C.c_void_p), ("n_trace", C.c_uint64), ("memory_trace", C.c_void_p), ("n_memory_trace", C.c_uint64),
+                    ("initial_memory", C.c_void_p), ("n_initial_memory", C.c_uint64), ("ranges", C.c_uint32 * 6)]
+
+    hi, hs = synth_fibonacci(25), synth_fibonacci_segment(25)
+    seg = C.cast(hs.view, C.POINTER(Seg)).contents
+    a = prover_input_arrays(hi.view)
+    assert seg.n_trace == hi.steps + 1 == 10 * 25 + 12 + 1
+    n_acc = a["data_accesses"].shape[0]
+    # fibonacci uses one-word instructions only: entries = steps (fetches) + operand accesses
+    assert seg.n_memory_trace == hi.steps + n_acc
+    assert list(seg.ranges) == a["ranges"]
+    tr = np.ctypeslib.as_array(C.cast(seg.trace, C.POINTER(C.c_uint32)), shape=(int(seg.n_trace), 2))
+    assert [int(tr[0][0]), int(tr[0][1]), int(tr[-1][0]), int(tr[-1][1])] == a["regs"]
+    hi.free(); hs.free()

@@ -1,0 +1,68 @@
+"""Device-side adapter (cm_adapt_segment_device) vs the host adapter (cm_vm_run / cm_synth_fibonacci,
+the sequential restatement of adapter/mod.rs:97-193 that tests/test_adapter.py pins with the reference's
+Memory::push known-answer tests): every array of the ProverInput must be identical, element by element, and the
+proof built from the device-adapted input must be bit-identical to the proof of the host-adapted one."""
+import numpy as np
+import pytest
+
+from cairo_m_amd.lib import (prover_input_arrays, synth_fibonacci, synth_fibonacci_segment, vm_run, vm_segment)
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        if isinstance(a[k], list):
+            assert a[k] == b[k], k
+        else:
+            assert a[k].shape == b[k].shape, (k, a[k].shape, b[k].shape)
+            assert np.array_equal(a[k], b[k]), (k, np.nonzero(a[k] != b[k])[0][:5])
+
+
+def _check(backend, host_input, host_segment, prove=True):
+    dev = backend.adapt_segment(host_segment)
+    back = backend.download_input(dev)
+    _same(prover_input_arrays(host_input.view), prover_input_arrays(back.view))
+    if prove:
+        p1 = backend.prove_device(dev)
+        p2 = backend.prove(host_input)
+        assert np.array_equal(p1.words(), p2.words())
+        p1.free(); p2.free()
+    back.free()
+    backend.free_input(dev)
+
+
+@pytest.mark.parametrize("n", [3, 1000])
+def test_fibonacci_segment(backend, n):
+    hi, hs = synth_fibonacci(n), synth_fibonacci_segment(n)
+    _check(backend, hi, hs)
+    hi.free(); hs.free()
+
+
+def test_all_opcode_programs(backend):
+    from tests.test_oracle_air import felt_program, u32_program, u32_loop_program
+    for prog, nret in ((felt_program(), 1), (u32_program(), 0), (u32_loop_program(50), 0)):
+        hi = vm_run(prog, entry_pc=0, args=(), n_returns=nret)
+        hs = vm_segment(prog, entry_pc=0, args=(), n_returns=nret)
+        _check(backend, hi, hs)
+        hi.free(); hs.free()
+
+
+def test_continuation_segments(backend):
+    """segments cut every max_steps: the device adapter starts from the memory at segment start"""
+    from tests.test_oracle_air import CHAIN_PROG
+    for s in range(4):
+        hi = vm_run(CHAIN_PROG, max_steps=2, segment=s)
+        hs = vm_segment(CHAIN_PROG, max_steps=2, segment=s)
+        _check(backend, hi, hs, prove=False)
+        hi.free(); hs.free()
+
+
+def test_metric_config_with_clock_updates(backend):
+    """fibonacci_loop n = 419 000 (4.19M steps): cells idle for more than 2^20 - 1 steps produce clock-update rows."""
+    hi, hs = synth_fibonacci(419_000), synth_fibonacci_segment(419_000)
+    a = prover_input_arrays(hi.view)
+    assert a["clock_updates"].shape[0] > 0
+    _check(backend, hi, hs)
+    hi.free(); hs.free()
