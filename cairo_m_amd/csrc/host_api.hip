@@ -91,6 +91,53 @@ int32_t cm_synth_fibonacci_segment(uint32_t n, uint64_t max_steps, uint32_t segm
 }
 const cm_runner_segment* cm_host_segment_view(const cm_host_segment* h) { return &h->view; }
 int32_t cm_host_segment_free(cm_host_segment* h) { delete h; return 0; }
+// ---- runner artifacts (wire formats of the reference) ---------------------------------------
+// trace file: per state `fp` then `pc`, little-endian u32 (crates/common/src/execution.rs:28-40; reader
+// IoTraceEntry {fp, pc}, crates/prover/src/adapter/io.rs:38-43).  memory trace file: optional
+// MemoryTraceMetadata {program_length: u32} header (io.rs:76-80) then per access `address, v0, v1, v2, v3`
+// little-endian u32 (execution.rs:52-66; IoMemoryEntry, io.rs:56-60).  The reference does not serialise the
+// initial memory or the public ranges yet (adapter/mod.rs:215-237 `unimplemented!`): the caller supplies them.
+static void put_le32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+static uint32_t get_le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+int32_t cm_segment_serialize_trace(const cm_runner_segment* s, uint8_t* out, uint64_t cap, uint64_t* len) {
+  *len = s->n_trace * 8;
+  if (!out) return 0;
+  if (cap < *len) return cm_set_last_error("cm_segment_serialize_trace: buffer too small");
+  for (uint64_t i = 0; i < s->n_trace; i++) {
+    put_le32(out + 8 * i, s->trace[2 * i + 1]);      // fp
+    put_le32(out + 8 * i + 4, s->trace[2 * i]);      // pc
+  }
+  return 0;
+}
+int32_t cm_segment_serialize_memory_trace(const cm_runner_segment* s, int32_t with_header, uint8_t* out, uint64_t cap, uint64_t* len) {
+  const uint64_t hdr = with_header ? 4 : 0;
+  *len = hdr + s->n_memory_trace * 20;
+  if (!out) return 0;
+  if (cap < *len) return cm_set_last_error("cm_segment_serialize_memory_trace: buffer too small");
+  if (with_header) put_le32(out, s->program_range[1] - s->program_range[0]);
+  for (uint64_t i = 0; i < s->n_memory_trace; i++)
+    for (int k = 0; k < 5; k++) put_le32(out + hdr + 20 * i + 4 * k, s->memory_trace[5 * i + k]);
+  return 0;
+}
+int32_t cm_segment_from_artifacts(const uint8_t* trace, uint64_t trace_len, const uint8_t* mem, uint64_t mem_len, int32_t mem_has_header,
+                                  const uint32_t* initial_memory, uint64_t n_initial_memory, const uint32_t ranges[6],
+                                  cm_host_segment** out) {
+  if (trace_len % 8) return cm_set_last_error("trace file: length is not a multiple of 8 bytes (fp, pc)");
+  const uint64_t hdr = mem_has_header ? 4 : 0;
+  if (mem_len < hdr || (mem_len - hdr) % 20) return cm_set_last_error("memory trace file: bad length (header + 20-byte records)");
+  if (mem_has_header && get_le32(mem) != ranges[1] - ranges[0]) return cm_set_last_error("memory trace header: program_length does not match the program range");
+  cm_host_segment* h = new cm_host_segment();
+  for (uint64_t i = 0; i < trace_len / 8; i++) { h->trace.push_back(get_le32(trace + 8 * i + 4)); h->trace.push_back(get_le32(trace + 8 * i)); }
+  for (uint64_t i = 0; i < (mem_len - hdr) / 4; i++) h->mem.push_back(get_le32(mem + hdr + 4 * i));
+  h->init.assign(initial_memory, initial_memory + 4 * n_initial_memory);
+  cm_runner_segment& v = h->view;
+  v.trace = h->trace.data(); v.n_trace = trace_len / 8;
+  v.memory_trace = h->mem.data(); v.n_memory_trace = (mem_len - hdr) / 20;
+  v.initial_memory = h->init.data(); v.n_initial_memory = n_initial_memory;
+  for (int i = 0; i < 2; i++) { v.program_range[i] = ranges[i]; v.input_range[i] = ranges[2 + i]; v.output_range[i] = ranges[4 + i]; }
+  *out = h;
+  return 0;
+}
 const cm_prover_input* cm_host_input_view(const cm_host_input* h) { return &h->view; }
 uint64_t cm_host_input_steps(const cm_host_input* h) { return h->owned.n_steps; }
 int32_t cm_host_input_free(cm_host_input* h) { delete h; return 0; }

@@ -237,6 +237,16 @@ int32_t cm_vm_segment(const uint32_t* instr_words, const uint32_t* instr_lens, u
                       uint32_t segment_index, cm_host_segment** out, uint32_t* n_segments_out);
 int32_t cm_synth_fibonacci_segment(uint32_t n, uint64_t max_steps, uint32_t segment_index, cm_host_segment** out);
 const cm_runner_segment* cm_host_segment_view(const cm_host_segment* h);
+/* Runner artifact wire formats (crates/common/src/execution.rs:28-66, crates/prover/src/adapter/io.rs:38-80):
+ * trace = (fp, pc) little-endian u32 pairs; memory trace = [u32 program_length header] + (address, v0..v3)
+ * records.  out == NULL only reports *len.  The reference does not serialise the initial memory and the public
+ * ranges (adapter/mod.rs:215-237): cm_segment_from_artifacts takes them from the caller
+ * (ranges = program, input, output [start, end)). */
+int32_t cm_segment_serialize_trace(const cm_runner_segment* s, uint8_t* out, uint64_t cap, uint64_t* len);
+int32_t cm_segment_serialize_memory_trace(const cm_runner_segment* s, int32_t with_header, uint8_t* out, uint64_t cap, uint64_t* len);
+int32_t cm_segment_from_artifacts(const uint8_t* trace, uint64_t trace_len, const uint8_t* mem, uint64_t mem_len,
+                                  int32_t mem_has_header, const uint32_t* initial_memory, uint64_t n_initial_memory,
+                                  const uint32_t ranges[6], cm_host_segment** out);
 int32_t cm_host_segment_free(cm_host_segment* h);
 /* Optional HIP-event kernel timing on the launch stream (bench.py `roofline`). */
 int32_t cm_kprof_enable(int32_t on);

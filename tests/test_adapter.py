@@ -104,3 +104,46 @@ def test_runner_segment_view_matches_host_input():
     tr = np.ctypeslib.as_array(C.cast(seg.trace, C.POINTER(C.c_uint32)), shape=(int(seg.n_trace), 2))
     assert [int(tr[0][0]), int(tr[0][1]), int(tr[-1][0]), int(tr[-1][1])] == a["regs"]
     hi.free(); hs.free()
+
+
+def test_runner_artifact_wire_formats():
+    """Byte layout of the runner artifacts (execution.rs:28-66: `fp` before `pc`; address + 4 value words; optional
+    u32 program_length header, io.rs:76-80) and the round trip segment -> files -> segment."""
+    import ctypes as C
+    from cairo_m_amd.lib import load_library, synth_fibonacci_segment, HostSegment
+    L = load_library()
+
+    class Seg(C.Structure):
+        _fields_ = [("trace", C.c_void_p), ("n_trace", C.c_uint64), ("memory_trace", C.c_void_p), ("n_memory_trace", C.c_uint64),
+                    ("initial_memory", C.c_void_p), ("n_initial_memory", C.c_uint64), ("ranges", C.c_uint32 * 6)]
+
+    def arrays(view):
+        s = C.cast(view, C.POINTER(Seg)).contents
+        f = lambda p, n: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(int(n),)).copy()
+        return f(s.trace, 2 * s.n_trace), f(s.memory_trace, 5 * s.n_memory_trace), f(s.initial_memory, 4 * s.n_initial_memory), list(s.ranges)
+
+    hs = synth_fibonacci_segment(7)
+    tr, mem, init, ranges = arrays(hs.view)
+    n = C.c_uint64(0)
+    assert L.cm_segment_serialize_trace(hs.view, None, C.c_uint64(0), C.byref(n)) == 0 and n.value == 4 * tr.size
+    tb = (C.c_uint8 * n.value)()
+    assert L.cm_segment_serialize_trace(hs.view, tb, C.c_uint64(n.value), C.byref(n)) == 0
+    words = np.frombuffer(bytes(tb), dtype="<u4").reshape(-1, 2)
+    assert np.array_equal(words[:, 0], tr.reshape(-1, 2)[:, 1])      # fp first
+    assert np.array_equal(words[:, 1], tr.reshape(-1, 2)[:, 0])      # then pc
+    assert L.cm_segment_serialize_memory_trace(hs.view, 1, None, C.c_uint64(0), C.byref(n)) == 0 and n.value == 4 + 4 * mem.size
+    mb = (C.c_uint8 * n.value)()
+    assert L.cm_segment_serialize_memory_trace(hs.view, 1, mb, C.c_uint64(n.value), C.byref(n)) == 0
+    mw = np.frombuffer(bytes(mb), dtype="<u4")
+    assert mw[0] == ranges[1] - ranges[0] and np.array_equal(mw[1:], mem)
+    h2 = C.c_void_p()
+    r = (C.c_uint32 * 6)(*ranges)
+    assert L.cm_segment_from_artifacts(tb, C.c_uint64(len(tb)), mb, C.c_uint64(len(mb)), 1, init.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       C.c_uint64(init.size // 4), r, C.byref(h2)) == 0
+    back = HostSegment(L, h2)
+    tr2, mem2, init2, ranges2 = arrays(back.view)
+    assert np.array_equal(tr, tr2) and np.array_equal(mem, mem2) and np.array_equal(init, init2) and ranges == ranges2
+    # a truncated file is rejected
+    assert L.cm_segment_from_artifacts(tb, C.c_uint64(len(tb) - 3), mb, C.c_uint64(len(mb)), 1, init.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       C.c_uint64(init.size // 4), r, C.byref(h2)) != 0
+    back.free(); hs.free()
