@@ -191,15 +191,17 @@ def main():
     if world == 1 and args.pipelined > 1:
         # SURVEY §8f-4 segment pipeline: continuation segments are independent proofs, so several can be in
         # flight on one GPU (one host thread each); their launch gaps and host round trips overlap.
-        workers = [Worker() for _ in range(args.pipelined)]
-        prove_n(len(workers))          # every new host thread warms its own pool / streams
-        n_pipe = 4 * len(workers)
+        n_pipe = 4 * args.pipelined
+        for p in be.prove_many([dev] * args.pipelined, inflight=args.pipelined):   # every worker warms its own pool
+            p.free()
         torch.cuda.synchronize()
         tp = time.perf_counter()
-        prove_n(n_pipe)
+        proofs = be.prove_many([dev] * n_pipe, inflight=args.pipelined)
         torch.cuda.synchronize()
         dtp = time.perf_counter() - tp
-        pipelined = {"inflight": len(workers), "proofs": n_pipe, "ms_per_proof": dtp * 1e3 / n_pipe,
+        for p in proofs:
+            p.free()
+        pipelined = {"inflight": args.pipelined, "proofs": n_pipe, "api": "cm_prove_many", "ms_per_proof": dtp * 1e3 / n_pipe,
                      "value": n_pipe * cells / dtp, "unit": "M31 trace cells/s",
                      "note": "throughput with several independent segment proofs in flight on the GPU (not the headline value)"}
 

@@ -15,6 +15,9 @@
 #include "point_eval.hpp"
 #include "host_adapter.hpp"
 #include <chrono>
+#include <deque>
+#include <condition_variable>
+#include <thread>
 #include <memory>
 #include <mutex>
 #include <map>
@@ -1027,6 +1030,44 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
 
 }  // namespace cm
 
+// ---- segment pipeline: several independent segment proofs in flight on one GPU ---------------
+// Continuation segments are independent proofs (runner/src/vm/mod.rs:184-240).  Every worker is a persistent
+// host thread with its own main stream, side streams, device pool and upload ring (all thread-local), so the
+// launch gaps, host round trips and latency-bound kernels of one proof overlap with the others' work.
+namespace cm {
+namespace {
+struct ProveWorkers {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> jobs;
+  std::vector<std::thread> threads;
+  void ensure(unsigned n) {
+    std::lock_guard<std::mutex> lk(mu);
+    while (threads.size() < n) {
+      threads.emplace_back([this] {
+        for (;;) {
+          std::function<void()> job;
+          {
+            std::unique_lock<std::mutex> lk2(mu);
+            cv.wait(lk2, [this] { return !jobs.empty(); });
+            job = std::move(jobs.front());
+            jobs.pop_front();
+          }
+          job();
+        }
+      });
+      threads.back().detach();
+    }
+  }
+  void submit(std::function<void()> f) {
+    { std::lock_guard<std::mutex> lk(mu); jobs.push_back(std::move(f)); }
+    cv.notify_one();
+  }
+};
+ProveWorkers& prove_workers() { static ProveWorkers* w = new ProveWorkers(); return *w; }
+}  // namespace
+}  // namespace cm
+
 // ================================================================= C ABI
 struct cm_proof { cm::ProofData* d; std::string json; std::vector<uint32_t> words; };
 struct cm_device_input { cm::DeviceInput* d; };
@@ -1072,6 +1113,45 @@ int32_t cm_prove_segment(const cm_prover_input* input, const cm_pcs_config* conf
   rc = cm_prove_device(di, config, out);
   cm_input_free(di);
   return rc;
+}
+int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
+                      cm_proof** outs) {
+  if (!n) return 0;
+  if (inflight < 1) inflight = 1;
+  if (inflight > 8) inflight = 8;
+  cm_pcs_config cfg = config ? *config : default_cfg();
+  cm::ProveWorkers& w = cm::prove_workers();
+  w.ensure(inflight);
+  struct Shared { std::mutex mu; std::condition_variable cv; uint32_t done = 0, next = 0; int32_t rc = 0; std::string err; } sh;
+  for (uint32_t i = 0; i < n; i++) outs[i] = nullptr;
+  const uint32_t runners = inflight < n ? inflight : n;
+  // `runners` jobs, each pulling segment indices until none is left: exactly that many proofs are in flight
+  for (uint32_t r = 0; r < runners; r++) {
+    w.submit([&] {
+      for (;;) {
+        uint32_t i;
+        { std::lock_guard<std::mutex> lk(sh.mu); i = sh.next++; }
+        if (i >= n) break;
+        int32_t rc = 0;
+        std::string err;
+        try {
+          std::unique_ptr<cm_proof> p(new cm_proof());
+          p->d = cm::prove(*inputs[i]->d, cfg);
+          outs[i] = p.release();
+        } catch (const cm::CmError& e) { rc = e.code ? e.code : 1; err = e.what(); }
+        catch (const std::exception& e) { rc = 1; err = e.what(); }
+        if (rc) { std::lock_guard<std::mutex> lk(sh.mu); if (!sh.rc) { sh.rc = rc; sh.err = err; } }
+      }
+      std::lock_guard<std::mutex> lk(sh.mu);
+      sh.done++;
+      sh.cv.notify_all();
+    });
+  }
+  std::unique_lock<std::mutex> lk(sh.mu);
+  sh.cv.wait(lk, [&] { return sh.done == runners; });
+  lk.unlock();
+  if (sh.rc) { cm_set_last_error(sh.err.c_str()); return sh.rc; }
+  return 0;
 }
 int32_t cm_proof_free(cm_proof* p) { if (p) { delete p->d; delete p; } return 0; }
 int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out) {

@@ -368,3 +368,15 @@ def _backend_download_input(self, dev_input):
 
 Backend.adapt_segment = _backend_adapt_segment
 Backend.download_input = _backend_download_input
+
+
+def _backend_prove_many(self, dev_inputs, inflight=3, cfg=None):
+    """Segment pipeline (cm_prove_many): independent segment proofs, up to `inflight` on the GPU at once."""
+    n = len(dev_inputs)
+    ins = (C.c_void_p * n)(*[d.value if isinstance(d, C.c_void_p) else d for d in dev_inputs])
+    outs = (C.c_void_p * n)()
+    self._ck(self.L.cm_prove_many(ins, C.c_uint32(n), _cfg(cfg), C.c_uint32(inflight), outs))
+    return [Proof(self.L, C.c_void_p(outs[i])) for i in range(n)]
+
+
+Backend.prove_many = _backend_prove_many

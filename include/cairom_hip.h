@@ -205,6 +205,11 @@ typedef struct cm_device_input cm_device_input;
 int32_t cm_input_upload(const cm_prover_input* input, cm_device_input** out);
 int32_t cm_input_free(cm_device_input* h);
 int32_t cm_prove_device(const cm_device_input* input, const cm_pcs_config* config, cm_proof** out);
+/* Segment pipeline: prove n independent segments with up to `inflight` (1..8) proofs in flight on the
+ * GPU (persistent worker threads inside the library, one stream set / device pool each).  outs[i] = proof of
+ * inputs[i]; on error the first failure is returned and the proofs already built stay in outs (free them). */
+int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
+                      cm_proof** outs);
 /* Flat u32 serialisation of the proof (format: cairo_m_amd/csrc/proof.hpp), used by the parity tests. */
 int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* n_out);
 /* JSON text of the proof; *len_out = length without the terminating NUL; the buffer is owned by

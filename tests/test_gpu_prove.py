@@ -134,3 +134,24 @@ def test_2pow24_rows_segment_verifies(backend, oracle):
     p.free()
     backend.free_input(dev)
     inp.free()
+
+
+def test_prove_many_pipeline(backend, oracle):
+    """cm_prove_many (segment pipeline): 5 proofs with 3 in flight, each identical to the proof made alone."""
+    inps = [synth_fibonacci(n) for n in (3, 50, 100)]
+    devs = [backend.upload_input(i) for i in inps]
+    alone = []
+    for d in devs:
+        p = backend.prove_device(d)
+        alone.append(p.words().copy())
+        p.free()
+    order = [0, 1, 2, 1, 0]
+    proofs = backend.prove_many([devs[k] for k in order], inflight=3)
+    for k, p in zip(order, proofs):
+        assert np.array_equal(p.words(), alone[k])
+        p.free()
+    assert oracle.verify(alone[2])[0] == 0
+    for d in devs:
+        backend.free_input(d)
+    for i in inps:
+        i.free()
