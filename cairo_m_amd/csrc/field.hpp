@@ -33,19 +33,34 @@ struct M31 {
   }
   CM_HD bool is_zero() const { return v == 0; }
 };
-CM_HD M31 operator+(M31 a, M31 b) {
-  uint32_t s = a.v + b.v;
-  return M31(s >= P ? s - P : s);
+// Conditional subtraction of P.  On gfx950 `min(s, s - P)` costs a 4-cycle VOP3 v_min_u32 after the subtract;
+// subtract-with-borrow + select is two 2-cycle VOP2 ops (v_sub_co_u32, v_cndmask_b32) — tools/valu_lab.hip.
+CM_HD uint32_t m31_csub(uint32_t s) {  // s < 2P  ->  s mod P
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  const bool borrow = __builtin_usub_overflow(s, P, &r);
+  return borrow ? s : r;
+#else
+  return s >= P ? s - P : s;
+#endif
 }
+CM_HD M31 operator+(M31 a, M31 b) { return M31(m31_csub(a.v + b.v)); }
 CM_HD M31 operator-(M31 a, M31 b) {
   uint32_t s = a.v - b.v;
   return M31(a.v < b.v ? s + P : s);
 }
 CM_HD M31 operator-(M31 a) { return M31(a.v ? P - a.v : 0); }
 CM_HD M31 operator*(M31 a, M31 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (2a) * b = 2t: the high word of the 64-bit product IS t >> 31 and (low word >> 1) IS t & P — a shift, the
+  // multiply-add and a shift instead of multiply, and, 4-cycle v_alignbit (t = a*b < 2^62, so 2t < 2^63)
+  uint64_t t2 = (uint64_t)(a.v << 1) * b.v;
+  uint32_t s = ((uint32_t)t2 >> 1) + (uint32_t)(t2 >> 32);
+#else
   uint64_t t = (uint64_t)a.v * b.v;
   uint32_t s = (uint32_t)(t & P) + (uint32_t)(t >> 31);
-  return M31(s >= P ? s - P : s);
+#endif
+  return M31(m31_csub(s));
 }
 CM_HD M31& operator+=(M31& a, M31 b) { a = a + b; return a; }
 CM_HD M31& operator-=(M31& a, M31 b) { a = a - b; return a; }
