@@ -81,7 +81,7 @@ def main():
                     help="independent segment proofs in flight per GPU (one host thread + stream set each)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: gloo lets 2 ranks share one GPU (with --force-device 0)")
     ap.add_argument("--force-device", type=int, default=-1, help="debug: every rank uses this device")
-    ap.add_argument("--pipelined", type=int, default=3,
+    ap.add_argument("--pipelined", type=int, default=4,
                     help="after the timed region, also measure throughput with this many segment proofs in flight "
                          "(reported as the extra `pipelined` object, N=1 only; 0 = skip)")
     args = ap.parse_args()
