@@ -1068,6 +1068,11 @@ ProveWorkers& prove_workers() { static ProveWorkers* w = new ProveWorkers(); ret
 }  // namespace
 }  // namespace cm
 
+namespace cm {
+std::string verify_proof(const ProofData& pf);                                                // verifier.hip
+bool proof_from_words(const uint32_t* w, uint64_t n, ProofData& p, std::string& err);
+}  // namespace cm
+
 // ================================================================= C ABI
 struct cm_proof { cm::ProofData* d; std::string json; std::vector<uint32_t> words; };
 struct cm_device_input { cm::DeviceInput* d; };
@@ -1152,6 +1157,22 @@ int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm
   lk.unlock();
   if (sh.rc) { cm_set_last_error(sh.err.c_str()); return sh.rc; }
   return 0;
+}
+// verify_cairo_m (crates/prover/src/verifier.rs:17-95): 0 = accepted; status 11 + cm_last_error() = name of the failed check
+int32_t cm_verify_proof(const cm_proof* p) {
+  return pguard([&] {
+    std::string e = cm::verify_proof(*p->d);
+    if (!e.empty()) throw cm::CmError(11, "verification failed: " + e);
+  });
+}
+int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words) {
+  return pguard([&] {
+    cm::ProofData pd;
+    std::string e;
+    if (!cm::proof_from_words(words, n_words, pd, e)) throw cm::CmError(11, "verification failed: " + e);
+    e = cm::verify_proof(pd);
+    if (!e.empty()) throw cm::CmError(11, "verification failed: " + e);
+  });
 }
 int32_t cm_proof_free(cm_proof* p) { if (p) { delete p->d; delete p; } return 0; }
 int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out) {

@@ -235,6 +235,13 @@ class Proof:
         return {"cells": cells.value, "steps": steps.value,
                 "phase_ms": dict(zip(self.PHASES, [ph[i] for i in range(min(n, 32))]))}
 
+    def verify(self):
+        """verify_cairo_m on this proof (product-side verifier, host code): (status, message)."""
+        rc = self.L.cm_verify_proof(self.h)
+        buf = C.create_string_buffer(512)
+        self.L.cm_last_error(buf, C.c_size_t(512))
+        return rc, buf.value.decode(errors="replace") if rc else ""
+
     def free(self):
         if self.h:
             self.L.cm_proof_free(self.h)

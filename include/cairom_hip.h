@@ -205,6 +205,11 @@ typedef struct cm_device_input cm_device_input;
 int32_t cm_input_upload(const cm_prover_input* input, cm_device_input** out);
 int32_t cm_input_free(cm_device_input* h);
 int32_t cm_prove_device(const cm_device_input* input, const cm_pcs_config* config, cm_proof** out);
+/* verify_cairo_m (crates/prover/src/verifier.rs:17-95 + Stwo verify): host code, works without a GPU.
+ * 0 = the proof is accepted; otherwise status 11 and cm_last_error() names the failed check
+ * (InvalidLogupSum, OodsNotMatching, Merkle(...), Fri(...), ProofOfWork, ...).  `words` = cm_proof_words format. */
+int32_t cm_verify_proof(const cm_proof* p);
+int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words);
 /* Segment pipeline: prove n independent segments with up to `inflight` (1..8) proofs in flight on the
  * GPU (persistent worker threads inside the library, one stream set / device pool each).  outs[i] = proof of
  * inputs[i]; on error the first failure is returned and the proofs already built stay in outs (free them). */

@@ -23,6 +23,8 @@ def test_fibonacci_proof_bit_exact(backend, oracle, n):
     assert diff.size == 0, f"first differing word {diff[:5]}"
     rc, err = oracle.verify(got)
     assert rc == 0, err
+    rc, err = proof.verify()       # product-side verifier agrees
+    assert rc == 0, err
     # tampering is rejected
     bad = got.copy()
     bad[bad.size // 2] ^= 1
@@ -102,6 +104,8 @@ def test_metric_config_proof_verifies(backend, oracle):
     w0 = p0.words().copy()
     assert p0.stats()["cells"] == 200_152_208
     rc, err = oracle.verify(w0)
+    assert rc == 0, err
+    rc, err = p0.verify()          # product-side verifier (cm_verify_proof)
     assert rc == 0, err
     p0.free()
     out = [None, None]
