@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--fib-n", type=int, default=FIB_N)
-    ap.add_argument("--cpu-sample-n", type=int, default=150000)
+    ap.add_argument("--cpu-sample-n", type=int, default=250000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kprof", action="store_true", help="debug: no in-library HIP-event kernel timing")
     ap.add_argument("--inflight", type=int, default=1,

@@ -188,6 +188,7 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
   CM_CHECK(seg.n_trace >= 2, "adapter: empty trace");
   const uint32_t n_steps = (uint32_t)(seg.n_trace - 1), n_mem = (uint32_t)seg.n_memory_trace, n_init = (uint32_t)seg.n_initial_memory;
   CM_CHECK(seg.n_memory_trace < (1ull << 32) && seg.n_trace < (1ull << 32), "adapter: segment too large");
+  CM_CHECK(seg.n_memory_trace >= 1, "adapter: empty memory trace");
   // ---- upload the runner output ----
   DevBuf d_trace(seg.n_trace * 8), d_mem((size_t)n_mem * 20 + 4), d_init((size_t)n_init * 16 + 4), d_err(4);
   CM_HIP(hipMemcpyAsync(d_trace.p, seg.trace, seg.n_trace * 8, hipMemcpyHostToDevice, st));
