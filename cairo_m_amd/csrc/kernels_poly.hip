@@ -187,20 +187,26 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const uint32_t* partial
 // A proof samples ~20 (log size, point) groups; as separate launches (4 each) the small groups are pure
 // launch latency.  Job descriptors + the per-bit point factors travel in ONE upload; blocks find their job
 // with a scalar scan over the (<= 64) block-range prefix.
+// value = sum_i coeff[i] * low[i_lo] * high[i_hi].  A thread owns 4 low indices and walks EAP2_GROUP chunks
+// (= high indices): coeff * high[chunk] — a wave-uniform QM31 from scalar loads — is accumulated as raw 64-bit
+// products, and the low factor is applied ONCE per thread at the end.  The inner loop is one coalesced
+// coefficient load + 4 multiply-adds: no per-coefficient table traffic (the first version re-read a 16-byte
+// table entry from L2 for every 4-byte coefficient and ran at ~2 TB/s).
+constexpr uint32_t EAP2_LOW_BITS = 10, EAP2_GROUP = 32;
 struct EapJobDev {
   uint32_t log_n, ncols;
   const uint32_t* const* coeffs;
   uint32_t* out;                 // 4 * ncols words
   uint32_t low_off, high_off;    // word offsets of the two tables in the scratch buffer
-  uint32_t partial_off;          // word offset of partial[ncols][nchunks][4]
+  uint32_t partial_off;          // word offset of partial[ncols][ngroups][4]
   uint32_t block_begin;          // first block of this job in k_eval_partial_multi
   uint32_t col_begin;            // first (job, column) index of this job in k_reduce_partials_multi
-  uint32_t pad;
+  uint32_t ngroups;              // chunk groups per column
   uint32_t maps[32 * 4];         // QM31 factor of index bit k
 };
 __global__ void __launch_bounds__(256) k_point_tables_multi(const EapJobDev* __restrict__ jobs, uint32_t* __restrict__ scratch) {
   const EapJobDev& jb = jobs[blockIdx.y];
-  const uint32_t low = jb.log_n < EAP_LOW_BITS ? jb.log_n : EAP_LOW_BITS;
+  const uint32_t low = jb.log_n < EAP2_LOW_BITS ? jb.log_n : EAP2_LOW_BITS;
   const uint32_t high = jb.log_n - low;
   const bool hi_tab = blockIdx.z == 1;
   const uint32_t nbits = hi_tab ? high : low, first_bit = hi_tab ? low : 0;
@@ -215,51 +221,88 @@ __device__ __forceinline__ unsigned long long fold31x2(unsigned long long x) {
   x = (x & P) + (x >> 31);
   return (x & P) + (x >> 31);
 }
-__global__ void __launch_bounds__(256) k_eval_partial_multi(const EapJobDev* __restrict__ jobs, uint32_t njobs,
+// first block / first column of every job, passed BY VALUE (kernel arguments sit in scalar registers): finding a
+// block's job by walking the 560-byte descriptors in memory cost ~20 dependent scalar loads per block
+struct EapStarts { uint32_t v[64]; };
+__global__ void __launch_bounds__(256) k_eval_partial_multi(const EapJobDev* __restrict__ jobs, uint32_t njobs, EapStarts starts,
                                                             uint32_t* __restrict__ scratch) {
   uint32_t j = 0;
-  while (j + 1 < njobs && jobs[j + 1].block_begin <= blockIdx.x) j++;
+#pragma unroll 8
+  for (uint32_t k = 1; k < 64; k++) j += (k < njobs && starts.v[k] <= blockIdx.x) ? 1u : 0u;
   const EapJobDev& jb = jobs[j];
-  const uint32_t low_bits = jb.log_n < EAP_LOW_BITS ? jb.log_n : EAP_LOW_BITS;
+  const uint32_t low_bits = jb.log_n < EAP2_LOW_BITS ? jb.log_n : EAP2_LOW_BITS;
   const uint32_t nchunks = 1u << (jb.log_n - low_bits);
   const uint32_t b = blockIdx.x - jb.block_begin;
-  const uint32_t col = b / nchunks, chunk = b - col * nchunks;
-  const uint32_t* __restrict__ c = jb.coeffs[col] + ((size_t)chunk << low_bits);
-  const uint32_t* __restrict__ lowtab = scratch + jb.low_off;
-  // 16 coefficients per thread: raw 64-bit products, 4 per coordinate fit a u64 (4 * (2^31-1)^2 + 2^32 < 2^64),
-  // folded back below 2^32 after every group of 4
-  unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+  const uint32_t col = b / jb.ngroups, grp = b - col * jb.ngroups;
+  const uint32_t c0 = grp * EAP2_GROUP, c1 = min(c0 + EAP2_GROUP, nchunks);
+  const uint32_t* __restrict__ coef = jb.coeffs[col];
+  const uint32_t* __restrict__ high = scratch + jb.high_off;
+  constexpr uint32_t PER = (1u << EAP2_LOW_BITS) / 256;  // low indices per thread
+  unsigned long long q[PER][4];
 #pragma unroll
-  for (uint32_t g = 0; g < (1u << EAP_LOW_BITS) / 1024; g++) {
+  for (uint32_t k = 0; k < PER; k++) q[k][0] = q[k][1] = q[k][2] = q[k][3] = 0;
+  const bool full_low = low_bits == EAP2_LOW_BITS;
+  for (uint32_t cb = c0; cb < c1; cb += 4) {
+    if (full_low && cb + 4 <= c1) {
+      // common case: no bounds tests, so the 16 coefficient loads of this step issue back to back
+      uint32_t x[4][PER];
 #pragma unroll
-    for (uint32_t it = 0; it < 4; it++) {
-      const uint32_t i = threadIdx.x + (g * 4 + it) * 256;
-      if (i < (1u << low_bits)) {
-        const unsigned long long x = c[i];
-        const uint4 t = *reinterpret_cast<const uint4*>(lowtab + 4 * i);
-        q0 += x * t.x; q1 += x * t.y; q2 += x * t.z; q3 += x * t.w;
+      for (uint32_t cc = 0; cc < 4; cc++)
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) x[cc][k] = coef[((size_t)(cb + cc) << EAP2_LOW_BITS) + threadIdx.x + k * 256];
+#pragma unroll
+      for (uint32_t cc = 0; cc < 4; cc++) {
+        const uint32_t c = cb + cc;
+        const uint32_t h0 = high[4 * c], h1 = high[4 * c + 1], h2 = high[4 * c + 2], h3 = high[4 * c + 3];  // wave-uniform
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+          const unsigned long long xv = x[cc][k];
+          q[k][0] += xv * h0; q[k][1] += xv * h1; q[k][2] += xv * h2; q[k][3] += xv * h3;
+        }
+      }
+    } else {
+#pragma unroll
+      for (uint32_t cc = 0; cc < 4; cc++) {
+        const uint32_t c = cb + cc;
+        if (c < c1) {
+          const uint32_t h0 = high[4 * c], h1 = high[4 * c + 1], h2 = high[4 * c + 2], h3 = high[4 * c + 3];
+#pragma unroll
+          for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t i = threadIdx.x + k * 256;
+            if (i < (1u << low_bits)) {
+              const unsigned long long xv = coef[((size_t)c << low_bits) + i];
+              q[k][0] += xv * h0; q[k][1] += xv * h1; q[k][2] += xv * h2; q[k][3] += xv * h3;
+            }
+          }
+        }
       }
     }
-    q0 = fold31x2(q0); q1 = fold31x2(q1); q2 = fold31x2(q2); q3 = fold31x2(q3);
+    // 4 raw products per coordinate fit a u64 on top of a folded remainder (4 * (2^31-1)^2 + 2^32 < 2^64)
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) { q[k][0] = fold31x2(q[k][0]); q[k][1] = fold31x2(q[k][1]); q[k][2] = fold31x2(q[k][2]); q[k][3] = fold31x2(q[k][3]); }
   }
-  QM31 acc(M31::reduce(q0), M31::reduce(q1), M31::reduce(q2), M31::reduce(q3));
+  QM31 acc;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    const uint32_t i = threadIdx.x + k * 256;
+    if (i < (1u << low_bits)) {
+      QM31 s(M31::reduce(q[k][0]), M31::reduce(q[k][1]), M31::reduce(q[k][2]), M31::reduce(q[k][3]));
+      acc += s * QM31::from_u32(scratch + jb.low_off + 4 * i);
+    }
+  }
   acc = block_reduce_qm31(acc);
-  if (threadIdx.x == 0) {
-    acc = acc * QM31::from_u32(scratch + jb.high_off + 4 * chunk);
-    acc.to_u32(scratch + jb.partial_off + 4 * ((size_t)col * nchunks + chunk));
-  }
+  if (threadIdx.x == 0) acc.to_u32(scratch + jb.partial_off + 4 * ((size_t)col * jb.ngroups + grp));
 }
-__global__ void __launch_bounds__(256) k_reduce_partials_multi(const EapJobDev* __restrict__ jobs, uint32_t njobs,
+__global__ void __launch_bounds__(256) k_reduce_partials_multi(const EapJobDev* __restrict__ jobs, uint32_t njobs, EapStarts starts,
                                                                const uint32_t* __restrict__ scratch) {
   uint32_t j = 0;
-  while (j + 1 < njobs && jobs[j + 1].col_begin <= blockIdx.x) j++;
+#pragma unroll 8
+  for (uint32_t k = 1; k < 64; k++) j += (k < njobs && starts.v[k] <= blockIdx.x) ? 1u : 0u;
   const EapJobDev& jb = jobs[j];
-  const uint32_t low_bits = jb.log_n < EAP_LOW_BITS ? jb.log_n : EAP_LOW_BITS;
-  const uint32_t nchunks = 1u << (jb.log_n - low_bits);
   const uint32_t col = blockIdx.x - jb.col_begin;
-  const uint32_t* p = scratch + jb.partial_off + 4 * (size_t)col * nchunks;
+  const uint32_t* p = scratch + jb.partial_off + 4 * (size_t)col * jb.ngroups;
   QM31 acc;
-  for (uint32_t i = threadIdx.x; i < nchunks; i += blockDim.x) acc += QM31::from_u32(p + 4 * i);
+  for (uint32_t i = threadIdx.x; i < jb.ngroups; i += blockDim.x) acc += QM31::from_u32(p + 4 * i);
   acc = block_reduce_qm31(acc);
   if (threadIdx.x == 0) acc.to_u32(jb.out + 4 * col);
 }
@@ -405,13 +448,14 @@ void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st) {
     CM_CHECK(j.ncols > 0 && j.log_n < 32, "eval_at_point_multi: bad job");
     EapJobDev& d = dj[k];
     memset(&d, 0, sizeof(d));
-    const uint32_t low = j.log_n < EAP_LOW_BITS ? j.log_n : EAP_LOW_BITS, high = j.log_n - low;
-    d.log_n = j.log_n; d.ncols = j.ncols; d.coeffs = j.d_coeffs; d.out = j.d_out;
+    const uint32_t low = j.log_n < EAP2_LOW_BITS ? j.log_n : EAP2_LOW_BITS, high = j.log_n - low;
+    const uint32_t ngroups = ((1u << high) + EAP2_GROUP - 1) / EAP2_GROUP;
+    d.log_n = j.log_n; d.ncols = j.ncols; d.coeffs = j.d_coeffs; d.out = j.d_out; d.ngroups = ngroups;
     d.low_off = (uint32_t)words; words += (size_t)4 << low;
     d.high_off = (uint32_t)words; words += (size_t)4 << high;
-    d.partial_off = (uint32_t)words; words += ((size_t)4 * j.ncols) << high;
+    d.partial_off = (uint32_t)words; words += (size_t)4 * j.ncols * ngroups;
     CM_CHECK(words < ((size_t)1 << 32), "eval_at_point_multi: scratch too large");
-    d.block_begin = blocks; blocks += j.ncols << high;
+    d.block_begin = blocks; blocks += j.ncols * ngroups;
     d.col_begin = cols; cols += j.ncols;
     j.py.to_u32(d.maps);
     QM31 x = j.px;
@@ -424,8 +468,11 @@ void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st) {
   const uint32_t nj = (uint32_t)jobs.size();
   KProfScope kp("k_eval_at_point", bytes, st);
   hipLaunchKernelGGL(k_point_tables_multi, dim3(max_tab_blocks, nj, 2), dim3(256), 0, st, djp, scratch.u32());
-  hipLaunchKernelGGL(k_eval_partial_multi, dim3(blocks), dim3(256), 0, st, djp, nj, scratch.u32());
-  hipLaunchKernelGGL(k_reduce_partials_multi, dim3(cols), dim3(256), 0, st, djp, nj, scratch.u32());
+  CM_CHECK(nj <= 64, "eval_at_point_multi: more than 64 sampling groups");
+  EapStarts bstart, cstart;
+  for (uint32_t k = 0; k < 64; k++) { bstart.v[k] = k < nj ? dj[k].block_begin : 0xffffffffu; cstart.v[k] = k < nj ? dj[k].col_begin : 0xffffffffu; }
+  hipLaunchKernelGGL(k_eval_partial_multi, dim3(blocks), dim3(256), 0, st, djp, nj, bstart, scratch.u32());
+  hipLaunchKernelGGL(k_reduce_partials_multi, dim3(cols), dim3(256), 0, st, djp, nj, cstart, scratch.u32());
   CM_HIP(hipGetLastError());
 }
 
