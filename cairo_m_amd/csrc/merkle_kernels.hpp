@@ -48,7 +48,13 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
     }
   }
   if (i < n) {
-    for (uint32_t c0 = 0; c0 < n_cols; c0 += 16) {
+    uint32_t c0 = 0;
+    for (; c0 + 16 <= n_cols; c0 += 16) {  // full chunks: 16 loads issue back to back, no per-column bounds branches
+#pragma unroll
+      for (uint32_t k = 0; k < 16; k++) m[k] = cols[c0 + k][i];
+      b2s_compress(h, m);
+    }
+    if (c0 < n_cols) {
 #pragma unroll
       for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? cols[c0 + k][i] : 0u;
       b2s_compress(h, m);
