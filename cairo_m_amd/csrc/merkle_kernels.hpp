@@ -103,7 +103,13 @@ __global__ void __launch_bounds__(256) k_merkle_multi(MerkleMultiArgs a) {
         b2s_compress(h, m);
       }
       const uint32_t c_begin = a.col_begin[lv], c_end = a.col_end[lv];
-      for (uint32_t c0 = c_begin; c0 < c_end; c0 += 16) {
+      uint32_t c0 = c_begin;
+      for (; c0 + 16 <= c_end; c0 += 16) {
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) m[k] = a.cols[c0 + k][i];
+        b2s_compress(h, m);
+      }
+      if (c0 < c_end) {
 #pragma unroll
         for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? a.cols[c0 + k][i] : 0u;
         b2s_compress(h, m);
@@ -147,7 +153,13 @@ __global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
         b2s_compress_quad(h0, h1, m, q);
       }
       const uint32_t c_begin = a.col_begin[l], c_end = a.col_end[l];
-      for (uint32_t c0 = c_begin; c0 < c_end; c0 += 16) {
+      uint32_t c0 = c_begin;
+      for (; c0 + 16 <= c_end; c0 += 16) {
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) m[k] = a.cols[c0 + k][node];
+        b2s_compress_quad(h0, h1, m, q);
+      }
+      if (c0 < c_end) {
 #pragma unroll
         for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? a.cols[c0 + k][node] : 0u;
         b2s_compress_quad(h0, h1, m, q);
@@ -178,7 +190,13 @@ __global__ void __launch_bounds__(256) k_merkle_layer_quad(uint32_t log_size, co
     m[8] = x2.x; m[9] = x2.y; m[10] = x2.z; m[11] = x2.w; m[12] = x3.x; m[13] = x3.y; m[14] = x3.z; m[15] = x3.w;
     b2s_compress_quad(h0, h1, m, q);
   }
-  for (uint32_t c0 = 0; c0 < n_cols; c0 += 16) {
+  uint32_t c0 = 0;
+  for (; c0 + 16 <= n_cols; c0 += 16) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = cols[c0 + k][i];
+    b2s_compress_quad(h0, h1, m, q);
+  }
+  if (c0 < n_cols) {
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? cols[c0 + k][i] : 0u;
     b2s_compress_quad(h0, h1, m, q);
