@@ -60,10 +60,14 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
     const bool staged_in = (rr == 0) && INVERSE && M == 0;
     if (rr == 0 && !staged_in) {
       if (padded) {
+        // zero-extension without exec-masked loads: out-of-range lanes read element 0 (one cached line) and the
+        // value is replaced by a select, so the 8 loads still issue back to back
 #pragma unroll
         for (uint32_t e = 0; e < 8; e++) {
-          uint32_t gi = gidx(li[e]);
-          v[e] = M31(gi < a.in_len ? src[gi] : 0u);
+          const uint32_t gi = gidx(li[e]);
+          const bool in = gi < a.in_len;
+          const uint32_t x = src[in ? gi : 0u];
+          v[e] = M31(in ? x : 0u);
         }
       } else {  // no per-element bounds test: 8 loads issue back to back instead of 8 exec-masked branches
 #pragma unroll
