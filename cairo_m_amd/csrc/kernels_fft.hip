@@ -105,8 +105,12 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
         const uint32_t e1 = e | (1u << s);
         const uint32_t g0 = e & ~((1u << k) - 1);  // j = 0 element of this group
         const uint32_t j = e & ((1u << k) - 1);
-        const uint32_t h = (gidx(li[g0]) >> (layer + 1)) + (j >> (s + 1));
+        uint32_t h = (gidx(li[g0]) >> (layer + 1)) + (j >> (s + 1));
         __builtin_assume(h < (1u << 29));  // byte offset fits 32 bits: saddr + 32-bit voffset addressing
+        // The 64 lanes of a wave differ in 6 consecutive bits of rho = (t << (3-k)) | g, i.e. local index bits below
+        // 9 - k; a round on bits [b, b+k) with 9 - k <= b therefore pairs elements whose twiddle index is the same
+        // in every lane: fetch it with a scalar load (no per-lane address arithmetic, no vector memory op).
+        if (9 - k <= b) h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
         M31 w(twp[h]);
         M31 x = v[e], y = v[e1];
         if (INVERSE) { v[e] = x + y; v[e1] = (x - y) * w; }
