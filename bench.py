@@ -71,8 +71,8 @@ def cpu_baseline(sample_n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--fib-n", type=int, default=FIB_N)
     ap.add_argument("--cpu-sample-n", type=int, default=250000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
