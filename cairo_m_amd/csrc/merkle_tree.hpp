@@ -40,29 +40,29 @@ struct GatherBatch {
     return off;
   }
   void run(hipStream_t st) {
+    // one upload (all address tables), three gather launches into one output buffer, ONE device->host copy
     words.resize(word_addrs.size());
     hashes.resize(hash_addrs.size() * 8);
     run_out.resize(run_words);
-    DevBuf dw, dh, dr, ow, oh, orr;
-    if (!word_addrs.empty()) {
-      dw = upload(word_addrs, st);
-      ow.alloc(words.size() * 4);
-      gather_words(dw.as<const uint32_t*>(), (uint32_t)word_addrs.size(), 1, ow.u32(), st);
-      CM_HIP(hipMemcpyAsync(words.data(), ow.p, words.size() * 4, hipMemcpyDeviceToHost, st));
-    }
-    if (!hash_addrs.empty()) {
-      dh = upload(hash_addrs, st);
-      oh.alloc(hashes.size() * 4);
-      gather_words(dh.as<const uint32_t*>(), (uint32_t)hash_addrs.size(), 8, oh.u32(), st);
-      CM_HIP(hipMemcpyAsync(hashes.data(), oh.p, hashes.size() * 4, hipMemcpyDeviceToHost, st));
-    }
-    if (!runs.empty()) {
-      dr = upload(runs, st);
-      orr.alloc(run_words * 4 + 4);
-      gather_runs(dr.as<RowRun>(), (uint32_t)runs.size(), orr.u32(), st);
-      CM_HIP(hipMemcpyAsync(run_out.data(), orr.p, run_words * 4, hipMemcpyDeviceToHost, st));
-    }
+    const size_t nw = words.size(), nh = hashes.size(), nr = run_out.size(), total = nw + nh + nr;
+    if (!total) return;
+    UploadBatch ub;
+    const uint32_t** d_w = nullptr;
+    const uint32_t** d_h = nullptr;
+    RowRun* d_r = nullptr;
+    if (nw) ub.add(word_addrs, &d_w);
+    if (nh) ub.add(hash_addrs, &d_h);
+    if (nr) ub.add(runs, &d_r);
+    DevBuf tables = ub.flush(st), out(total * 4);
+    if (nw) gather_words(d_w, (uint32_t)word_addrs.size(), 1, out.u32(), st);
+    if (nh) gather_words(d_h, (uint32_t)hash_addrs.size(), 8, out.u32() + nw, st);
+    if (nr) gather_runs(d_r, (uint32_t)runs.size(), out.u32() + nw + nh, st);
+    std::vector<uint32_t> host(total);
+    CM_HIP(hipMemcpyAsync(host.data(), out.p, total * 4, hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
+    std::copy(host.begin(), host.begin() + nw, words.begin());
+    std::copy(host.begin() + nw, host.begin() + nw + nh, hashes.begin());
+    std::copy(host.begin() + nw + nh, host.end(), run_out.begin());
   }
 };
 
