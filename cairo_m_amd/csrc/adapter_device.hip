@@ -18,12 +18,13 @@
 #include "engine.hpp"
 #include "host_adapter.hpp"
 #include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 
 namespace cm {
 
 struct DeviceInput;  // prover.hip
 DeviceInput* make_device_input(const cm_prover_input& meta_host_small, DevBuf (&bundles)[CM_N_OPCODE_COMPONENTS], DevBuf& data_accesses,
-                               DevBuf& clock_updates);
+                               DevBuf& clock_updates, DevBuf* init_tree_dev, DevBuf* fin_tree_dev);
 
 namespace {
 
@@ -179,6 +180,85 @@ void with_temp(F&& f) {  // hipCUB two-phase calls
 }
 inline dim3 grid1(uint32_t n) { return dim3((n + 255) / 256); }
 
+// ---- partial Merkle tree over the boundary memory, on the GPU (adapter/merkle.rs:183-295) ---------------------
+// The host builder hashes O(cells * 30) Poseidon2 nodes sequentially: fine for fibonacci (tens of cells), minutes
+// for a program that touches 10^6 cells.  Level by level, without host round trips: entries (index, value, mult)
+// sorted by index; an entry is the first of its sibling pair iff its parent differs from its predecessor's; an
+// exclusive scan of those flags gives every parent its slot; one thread per pair hashes it (absent sibling =
+// default hash of that depth) and emits the NodeData row + the parent entry.  Node order = depth 30..1,
+// ascending index, exactly like the host builder.
+struct TreeState { uint32_t n, node_off; };   // device: entries at the current depth, nodes written so far
+__global__ void k_tree_flags(const uint32_t* __restrict__ idx, const TreeState* __restrict__ stt, uint32_t cap, uint32_t* __restrict__ first) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  first[i] = (i < stt->n && (i == 0 || (idx[i] >> 1) != (idx[i - 1] >> 1))) ? 1u : 0u;
+}
+__global__ void k_tree_level(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val, const uint32_t* __restrict__ mult,
+                             const uint32_t* __restrict__ first, const uint32_t* __restrict__ ppos, const TreeState* __restrict__ stt,
+                             uint32_t cap, uint32_t depth, uint32_t dflt, cm_merkle_node* __restrict__ nodes,
+                             uint32_t* __restrict__ nidx, uint32_t* __restrict__ nval, uint32_t* __restrict__ nmult) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap || i >= stt->n || !first[i]) return;
+  const uint32_t index = idx[i];
+  uint32_t lv = dflt, lm = 0, rv = dflt, rm = 0;
+  if ((index & 1u) == 0) {
+    lv = val[i]; lm = mult[i];
+    if (i + 1 < stt->n && idx[i + 1] == index + 1) { rv = val[i + 1]; rm = mult[i + 1]; }
+  } else {
+    rv = val[i]; rm = mult[i];
+  }
+  const uint32_t ph = host::poseidon2_hash(lv, rv);
+  cm_merkle_node nd;
+  nd.index = index & ~1u; nd.depth = depth; nd.left_value = lv; nd.right_value = rv; nd.parent_value = ph;
+  nd.left_mult = lm; nd.right_mult = rm; nd.parent_mult = 1u;
+  const uint32_t slot = ppos[i];
+  nodes[stt->node_off + slot] = nd;
+  nidx[slot] = index >> 1; nval[slot] = ph; nmult[slot] = 1u;
+}
+__global__ void k_tree_advance(TreeState* stt, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ppos) {
+  if (threadIdx.x || blockIdx.x) return;
+  const uint32_t n = stt->n;
+  const uint32_t parents = n ? ppos[n - 1] + first[n - 1] : 0u;
+  stt->node_off += parents;
+  stt->n = parents;
+}
+// leaves: (address << 2 | i, value_i, mult) sorted by address; returns the root; nodes + count stay on the device
+uint32_t build_partial_merkle_tree_device(const std::vector<uint32_t>& idx_h, const std::vector<uint32_t>& val_h,
+                                          const std::vector<uint32_t>& mult_h, DevBuf& nodes_out, uint64_t& n_nodes, hipStream_t st) {
+  const uint32_t cap = (uint32_t)idx_h.size();
+  CM_CHECK(cap > 0, "partial merkle tree: no leaves");
+  const std::vector<uint32_t>& dflt = host::poseidon2_default_hashes();
+  DevBuf a_idx = upload(idx_h, st), a_val = upload(val_h, st), a_mult = upload(mult_h, st);
+  DevBuf b_idx((size_t)cap * 4), b_val((size_t)cap * 4), b_mult((size_t)cap * 4), d_first((size_t)cap * 4), d_ppos((size_t)cap * 4), d_st(sizeof(TreeState));
+  // every level has at most as many nodes as the one below: cap * TREE_HEIGHT bounds the total
+  nodes_out.alloc((size_t)cap * air::TREE_HEIGHT * sizeof(cm_merkle_node));
+  TreeState s0{cap, 0};
+  stage_upload(d_st.p, &s0, sizeof(s0), st);
+  DevBuf* cur[3] = {&a_idx, &a_val, &a_mult};
+  DevBuf* nxt[3] = {&b_idx, &b_val, &b_mult};
+  size_t tmp_bytes = 0;
+  CM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_first.u32(), d_ppos.u32(), (int)cap, st));
+  DevBuf tmp(tmp_bytes ? tmp_bytes : 4);
+  for (uint32_t depth = air::TREE_HEIGHT; depth >= 1; depth--) {
+    hipLaunchKernelGGL(k_tree_flags, grid1(cap), dim3(256), 0, st, cur[0]->u32(), d_st.as<TreeState>(), cap, d_first.u32());
+    CM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, d_first.u32(), d_ppos.u32(), (int)cap, st));
+    hipLaunchKernelGGL(k_tree_level, grid1(cap), dim3(256), 0, st, cur[0]->u32(), cur[1]->u32(), cur[2]->u32(), d_first.u32(), d_ppos.u32(),
+                       d_st.as<TreeState>(), cap, depth, dflt[depth], nodes_out.as<cm_merkle_node>(), nxt[0]->u32(), nxt[1]->u32(), nxt[2]->u32());
+    hipLaunchKernelGGL(k_tree_advance, dim3(1), dim3(64), 0, st, d_st.as<TreeState>(), d_first.u32(), d_ppos.u32());
+    for (int k = 0; k < 3; k++) std::swap(cur[k], nxt[k]);
+  }
+  TreeState fin;
+  uint32_t root = 0;
+  CM_HIP(hipMemcpyAsync(&fin, d_st.p, sizeof(fin), hipMemcpyDeviceToHost, st));
+  CM_HIP(hipMemcpyAsync(&root, cur[1]->p, 4, hipMemcpyDeviceToHost, st));
+  CM_HIP(hipGetLastError());
+  CM_HIP(hipStreamSynchronize(st));
+  CM_CHECK(fin.n == 1, "partial merkle tree: did not converge to one root");
+  n_nodes = fin.node_off;
+  return root;
+}
+
+
 }  // namespace
 
 // host tail shared with the host adapter: boundary memory rows, public multiplicities, partial Merkle trees
@@ -314,7 +394,21 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
   }
   host::ProverInputOwned tail;
   for (int i = 0; i < 2; i++) { tail.program_range[i] = seg.program_range[i]; tail.input_range[i] = seg.input_range[i]; tail.output_range[i] = seg.output_range[i]; }
-  host::finish_boundary_memory(initial_memory, final_memory, tail);
+  // small boundary memories: trees on the host (a few hundred Poseidon2 hashes); large ones: on the GPU
+  size_t tree_min = 2048;
+  if (const char* e = getenv("CM_ADAPTER_DEVICE_TREE_MIN")) tree_min = (size_t)strtoull(e, nullptr, 10);
+  const bool device_trees = initial_memory.size() >= tree_min;
+  host::finish_boundary_memory(initial_memory, final_memory, tail, !device_trees);
+  DevBuf init_tree_dev, fin_tree_dev;
+  uint64_t n_init_tree = 0, n_fin_tree = 0;
+  if (device_trees) {
+    for (int half = 0; half < 2; half++) {
+      std::vector<uint32_t> li, lv, lm;
+      host::partial_tree_leaves(half ? final_memory : initial_memory, half == 0, tail.program_range, tail.input_range, tail.output_range, li, lv, lm);
+      uint32_t root = build_partial_merkle_tree_device(li, lv, lm, half ? fin_tree_dev : init_tree_dev, half ? n_fin_tree : n_init_tree, st);
+      (half ? tail.final_root : tail.initial_root) = root;
+    }
+  }
   // ---- assemble the device-resident ProverInput ----
   cm_prover_input meta = tail.view();
   meta.initial_pc = seg.trace[0]; meta.initial_fp = seg.trace[1];
@@ -322,7 +416,8 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
   for (int c = 0; c < CM_N_OPCODE_COMPONENTS; c++) { meta.bundles[c] = nullptr; meta.n_bundles[c] = counts[c]; }
   meta.data_accesses = nullptr; meta.n_data_accesses = n_acc;
   meta.clock_updates = nullptr; meta.n_clock_updates = n_cu;
-  return make_device_input(meta, bundles, d_acc, d_cu);
+  if (device_trees) { meta.n_initial_tree = n_init_tree; meta.n_final_tree = n_fin_tree; }
+  return make_device_input(meta, bundles, d_acc, d_cu, device_trees ? &init_tree_dev : nullptr, device_trees ? &fin_tree_dev : nullptr);
 }
 
 }  // namespace cm

@@ -28,7 +28,7 @@ struct CmOps {
 };
 
 // ---- Poseidon2-M31 hash (crates/prover/src/poseidon2.rs:25-54) ----------------------------------
-inline void poseidon2_permute(cm::M31* s) {
+CM_HD void poseidon2_permute(cm::M31* s) {
   using namespace air;
   auto mk = [](uint32_t v) { return cm::M31(v); };
   p2_external_matrix(s);
@@ -49,7 +49,7 @@ inline void poseidon2_permute(cm::M31* s) {
     }
   }
 }
-inline uint32_t poseidon2_hash(uint32_t l, uint32_t r) {
+CM_HD uint32_t poseidon2_hash(uint32_t l, uint32_t r) {
   cm::M31 s[16];
   s[0] = cm::M31(l);
   s[1] = cm::M31(r);
@@ -351,7 +351,7 @@ struct MemoryTracker {
 // (adapter/memory.rs:427-461), boundary memory rows in ascending address order, the two partial Merkle trees.
 // out.program_range / input_range / output_range must be set.
 inline void finish_boundary_memory(std::map<uint32_t, MemState>& initial_memory, std::map<uint32_t, MemState>& final_memory,
-                                   ProverInputOwned& out) {
+                                   ProverInputOwned& out, bool build_trees = true) {
   const uint32_t* prog = out.program_range;
   const uint32_t* inp = out.input_range;
   const uint32_t* outp = out.output_range;
@@ -372,8 +372,18 @@ inline void finish_boundary_memory(std::map<uint32_t, MemState>& initial_memory,
     out.initial_memory.push_back(cm_memory_cell{kv.first, {kv.second.value[0], kv.second.value[1], kv.second.value[2], kv.second.value[3]}, kv.second.clock, kv.second.mult});
   for (auto& kv : final_memory)
     out.final_memory.push_back(cm_memory_cell{kv.first, {kv.second.value[0], kv.second.value[1], kv.second.value[2], kv.second.value[3]}, kv.second.clock, kv.second.mult});
+  if (!build_trees) return;  // the device adapter hashes large trees on the GPU
   out.initial_root = build_partial_merkle_tree(initial_memory, true, prog, inp, outp, out.initial_tree);
   out.final_root = build_partial_merkle_tree(final_memory, false, prog, inp, outp, out.final_tree);
+}
+// leaves of a partial tree: (address << 2 | i, value_i, multiplicity 2 for public cells else 1), ascending
+inline void partial_tree_leaves(const std::map<uint32_t, MemState>& memory, bool initial, const uint32_t prog[2], const uint32_t inp[2],
+                                const uint32_t outp[2], std::vector<uint32_t>& idx, std::vector<uint32_t>& val, std::vector<uint32_t>& mult) {
+  for (auto& kv : memory) {
+    uint32_t addr = kv.first;
+    bool pub = initial ? ((addr >= prog[0] && addr < prog[1]) || (addr >= inp[0] && addr < inp[1])) : (addr >= outp[0] && addr < outp[1]);
+    for (uint32_t i = 0; i < 4; i++) { idx.push_back((addr << 2) + i); val.push_back(kv.second.value[i]); mult.push_back(pub ? 2u : 1u); }
+  }
 }
 
 // import_internal (adapter/mod.rs:97-193)

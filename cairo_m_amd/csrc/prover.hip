@@ -90,7 +90,7 @@ DeviceInput* upload_input(const cm_prover_input& in) {
 // device adapter (adapter_device.hip): bulk arrays already live in HBM, the small boundary-memory / Merkle-tree
 // arrays come from the host (pointers in `meta`, valid during the call)
 DeviceInput* make_device_input(const cm_prover_input& meta, DevBuf (&bundles)[CM_N_OPCODE_COMPONENTS], DevBuf& data_accesses,
-                               DevBuf& clock_updates) {
+                               DevBuf& clock_updates, DevBuf* init_tree_dev, DevBuf* fin_tree_dev) {
   DeviceInput* d = new DeviceInput();
   d->meta = meta;
   auto up = [](DevBuf& b, const void* p, size_t bytes) {
@@ -102,8 +102,10 @@ DeviceInput* make_device_input(const cm_prover_input& meta, DevBuf (&bundles)[CM
   d->clock_updates = std::move(clock_updates);
   up(d->init_mem, meta.initial_memory, meta.n_initial_memory * sizeof(cm_memory_cell));
   up(d->fin_mem, meta.final_memory, meta.n_final_memory * sizeof(cm_memory_cell));
-  up(d->init_tree, meta.initial_tree, meta.n_initial_tree * sizeof(cm_merkle_node));
-  up(d->fin_tree, meta.final_tree, meta.n_final_tree * sizeof(cm_merkle_node));
+  if (init_tree_dev) d->init_tree = std::move(*init_tree_dev);   // trees hashed on the GPU by the device adapter
+  else up(d->init_tree, meta.initial_tree, meta.n_initial_tree * sizeof(cm_merkle_node));
+  if (fin_tree_dev) d->fin_tree = std::move(*fin_tree_dev);
+  else up(d->fin_tree, meta.final_tree, meta.n_final_tree * sizeof(cm_merkle_node));
   d->public_data = make_public_data(meta);
   // the host pointers of `meta` die with the caller's temporaries
   for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) d->meta.bundles[i] = nullptr;

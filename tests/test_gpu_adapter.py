@@ -66,3 +66,48 @@ def test_metric_config_with_clock_updates(backend):
     assert a["clock_updates"].shape[0] > 0
     _check(backend, hi, hs)
     hi.free(); hs.free()
+
+
+def test_partial_merkle_trees_on_device(backend, monkeypatch):
+    """CM_ADAPTER_DEVICE_TREE_MIN=1 forces the GPU partial-Merkle-tree builder (Poseidon2, level by level; normally
+    used from 2048 boundary cells up): node lists, roots and proofs must still equal the host adapter's."""
+    from tests.test_oracle_air import felt_program, u32_loop_program
+    monkeypatch.setenv("CM_ADAPTER_DEVICE_TREE_MIN", "1")
+    hi, hs = synth_fibonacci(60), synth_fibonacci_segment(60)
+    _check(backend, hi, hs)
+    hi.free(); hs.free()
+    for prog, nret in ((felt_program(), 1), (u32_loop_program(20), 0)):
+        hi = vm_run(prog, entry_pc=0, args=(), n_returns=nret)
+        hs = vm_segment(prog, entry_pc=0, args=(), n_returns=nret)
+        _check(backend, hi, hs)
+        hi.free(); hs.free()
+
+
+def scatter_store_program(n):
+    """A loop that writes n distinct memory cells through a double dereference ([[fp+8] + [fp+11]] = [fp+12]):
+    the boundary memory grows to n cells, which takes the device adapter's GPU Merkle-tree path (>= 2048 cells)."""
+    P = 2**31 - 1
+    return [
+        [9, 0, 20],            # pc 0: i = 0
+        [43, 0, 8],            # pc 1: [fp+8] = fp
+        [9, 7, 12],            # pc 2: value = 7
+        [9, n, 30],            # pc 3: counter = n
+        [4, 20, 100, 11],      # pc 4: off = i + 100                      <- loop head
+        [45, 8, 11, 12],       # pc 5: [[fp+8] + off] = value  (cell fp + 100 + i)
+        [4, 20, 1, 21],        # pc 6: i' = i + 1
+        [4, 21, 0, 20],        # pc 7: i = i'
+        [4, 30, P - 1, 31],    # pc 8: c' = c - 1
+        [4, 31, 0, 30],        # pc 9: c = c'
+        [14, 30, P - 6],       # pc 10: jnz c -> pc 4
+        [11],                  # pc 11: ret
+    ]
+
+
+def test_large_boundary_memory_uses_device_trees(backend):
+    prog = scatter_store_program(3000)
+    hi = vm_run(prog, entry_pc=0, args=(), n_returns=0)
+    hs = vm_segment(prog, entry_pc=0, args=(), n_returns=0)
+    a = prover_input_arrays(hi.view)
+    assert a["initial_memory"].shape[0] >= 3000 and a["initial_tree"].shape[0] > 10_000
+    _check(backend, hi, hs)
+    hi.free(); hs.free()
