@@ -159,3 +159,22 @@ def test_prove_many_pipeline(backend, oracle):
         backend.free_input(d)
     for i in inps:
         i.free()
+
+
+def test_u32_loop_at_scale_verifies(backend, oracle):
+    """Looped u32 mix at 2^20 steps (BASELINE configs[2] stand-in at size): runner segment -> device adapter -> HIP prover;
+    the product verifier and the oracle verifier both accept (1.3e8 cells, every u32 / bitwise / range-check component live)."""
+    from cairo_m_amd.lib import vm_segment
+    from tests.test_oracle_air import u32_loop_program
+    hs = vm_segment(u32_loop_program(95_000), entry_pc=0, args=(), n_returns=0)
+    dev = backend.adapt_segment(hs)
+    p = backend.prove_device(dev)
+    st = p.stats()
+    assert st["steps"] == 3 + 11 * 95_000 + 1 and st["cells"] > 1.2e8
+    rc, err = p.verify()
+    assert rc == 0, err
+    rc, err = oracle.verify(p.words())
+    assert rc == 0, err
+    p.free()
+    backend.free_input(dev)
+    hs.free()
