@@ -148,8 +148,10 @@ AIR_HD void p2_internal_matrix(F* s, MK mk) {
 struct Poseidon2C {
   static constexpr int N_TRACE = 1 + P2_T * (1 + P2_FULL * 3) + 3 * P2_PARTIAL;  // 443
   // witness: poseidon2.rs:172-325.  `in` = 16-word initial state (zeros on padding rows)
-  template <class O>
-  static AIR_HD void witness(const uint32_t* in, uint32_t enabler, typename O::M* o) {
+  // `o` is anything indexable with `o[c] = M` (a plain array, or a writer that stores straight into the trace
+  // columns: 443 cells per row do not fit in registers, and a local array means 1.7 KiB of scratch per thread)
+  template <class O, class Out>
+  static AIR_HD void witness(const uint32_t* in, uint32_t enabler, Out o) {
     using M = typename O::M;
     auto mk = [](uint32_t v) { return O::mk(v); };
     int c = 0;
