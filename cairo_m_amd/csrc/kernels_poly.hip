@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials_multi(const EapJobDev* 
 
 // ================================================================= host wrappers
 Twiddles* twiddles_create(uint32_t R, hipStream_t st) {
-  CM_CHECK(R >= 2 && R <= 30, "twiddles: log size out of range");
+  CM_CHECK(R >= 2 && R <= 28, "twiddles: log size out of range (columns are limited to 2^26 rows)");
   Twiddles* t = new Twiddles();
   t->R = R;
   size_t nx = (size_t)1 << (R - 1), ny = (size_t)1 << R;
