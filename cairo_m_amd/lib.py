@@ -387,3 +387,57 @@ def _backend_prove_many(self, dev_inputs, inflight=3, cfg=None):
 
 
 Backend.prove_many = _backend_prove_many
+
+
+# ---- compiled-program JSON (crates/common/src/program.rs:143-170, instruction.rs:609-655) ----------------------
+def load_program_json(text):
+    """Compiled `Program` as the reference serialises it with serde_json: {"data": [{"Instruction": ["0x9", "0x1", ...]}
+    | {"Value": [[a, b], [c, d]]}, ...], "entrypoints": {name: {"pc": n, "params": [...], "returns": [...]}},
+    "metadata": {...}}.  Returns (cells, entrypoints): `cells` = one word list per program datum — instruction words
+    (opcode first, 1..6 words) or the 4 words of a raw QM31 value — in the form cm_vm_run / vm_run take."""
+    import json
+    doc = json.loads(text)
+    unknown = set(doc) - {"data", "entrypoints", "metadata"}
+    if unknown:
+        raise ValueError(f"unknown Program fields {sorted(unknown)} (the reference denies unknown fields)")
+    cells = []
+    for item in doc["data"]:
+        if "Instruction" in item:
+            words = [int(s, 16) for s in item["Instruction"]]
+            if not 1 <= len(words) <= 6:
+                raise ValueError("instruction must have 1..6 M31 words")
+        elif "Value" in item:
+            (a, b), (c, d) = item["Value"]
+            words = [int(a), int(b), int(c), int(d)]
+        else:
+            raise ValueError(f"unknown ProgramData variant {list(item)}")
+        if any(w >= 2**31 - 1 for w in words):
+            raise ValueError("program word is not a canonical M31")
+        cells.append(words)
+    entry = {name: {"pc": int(e["pc"]), "n_params": sum(_abi_slots(p["ty"]) for p in e.get("params", [])),
+                    "n_returns": sum(_abi_slots(r["ty"]) for r in e.get("returns", []))}
+             for name, e in doc.get("entrypoints", {}).items()}
+    return cells, entry
+
+
+def _abi_slots(ty):
+    """AbiType::size_in_slots (program.rs:30-42); serde externally-tagged enum: "Felt" | {"Pointer": {...}} | ..."""
+    if isinstance(ty, str):
+        return {"Felt": 1, "Bool": 1, "U32": 2, "Unit": 0}[ty]
+    (tag, body), = ty.items()
+    if tag == "Pointer":
+        return 1
+    if tag == "Tuple":
+        return sum(_abi_slots(t) for t in body)
+    if tag == "Struct":
+        return sum(_abi_slots(t) for _, t in body["fields"])
+    if tag == "FixedSizeArray":
+        return int(body["size"]) * _abi_slots(body["element"])
+    raise ValueError(f"unknown AbiType {tag}")
+
+
+def program_to_json(cells, entrypoints=None):
+    """Inverse of load_program_json for instruction-only programs (hex strings like `format!("0x{:x}")`)."""
+    import json
+    return json.dumps({"data": [{"Instruction": [f"0x{w:x}" for w in ins]} for ins in cells],
+                       "entrypoints": entrypoints or {}, "metadata": {}})

@@ -4,6 +4,7 @@ CPU only (host code of the library)."""
 import ctypes as C
 
 import numpy as np
+import pytest
 
 from cairo_m_amd.lib import load_library
 
@@ -147,3 +148,22 @@ def test_runner_artifact_wire_formats():
     assert L.cm_segment_from_artifacts(tb, C.c_uint64(len(tb) - 3), mb, C.c_uint64(len(mb)), 1, init.ctypes.data_as(C.POINTER(C.c_uint32)),
                                        C.c_uint64(init.size // 4), r, C.byref(h2)) != 0
     back.free(); hs.free()
+
+
+def test_compiled_program_json_roundtrip():
+    """Program JSON in the serde shape of crates/common/src/program.rs:143-170 (instructions as hex-string arrays,
+    instruction.rs:609-655): parse, run through the VM + adapter, same ProverInput as the word-list form."""
+    from cairo_m_amd.lib import load_program_json, program_to_json, prover_input_arrays, vm_run
+    from tests.test_oracle_air import felt_program
+    prog = felt_program()
+    text = program_to_json(prog, {"main": {"pc": 0, "returns": [{"name": "r", "ty": "Felt"}]},
+                                  "f": {"pc": 26, "params": [{"name": "a", "ty": "U32"}, {"name": "p", "ty": {"Pointer": {"element": "Felt", "len": None}}}]}})
+    assert '"0x9"' in text and '"Instruction"' in text
+    cells, entry = load_program_json(text)
+    assert cells == prog
+    assert entry["main"] == {"pc": 0, "n_params": 0, "n_returns": 1} and entry["f"]["n_params"] == 3
+    a = prover_input_arrays(vm_run(cells, entry_pc=entry["main"]["pc"], args=(), n_returns=entry["main"]["n_returns"]).view)
+    b = prover_input_arrays(vm_run(prog, entry_pc=0, args=(), n_returns=1).view)
+    assert all(np.array_equal(a[k], b[k]) if hasattr(a[k], "shape") else a[k] == b[k] for k in a)
+    with pytest.raises(ValueError):
+        load_program_json('{"data": [], "entrypoints": {}, "metadata": {}, "extra": 1}')
