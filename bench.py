@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--pipelined", type=int, default=4,
                     help="after the timed region, also measure throughput with this many segment proofs in flight "
                          "(reported as the extra `pipelined` object, N=1 only; 0 = skip)")
+    ap.add_argument("--preprocessed-cache", action="store_true",
+                    help="NOT the headline number: keep the committed preprocessed tree between proofs (SURVEY 8f-4); the "
+                         "default recomputes tree 0 in every proof like the reference does")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +108,7 @@ def main():
     from cairo_m_amd import Backend
     from cairo_m_amd.lib import synth_fibonacci
     be = Backend(local_rank)          # fails loudly without the .so / a GPU
+    be.set_preprocessed_cache(args.preprocessed_cache)
     inp = synth_fibonacci(args.fib_n)  # host: synthetic VM + adapter
     dev = be.upload_input(inp)         # ProverInput resident in HBM before the timed region
 
@@ -236,7 +240,9 @@ def main():
                "dtype": "u32", "data": "synthetic",
                "config": {"workload": f"fibonacci_loop n={args.fib_n} ({inp.steps} VM steps, one segment, "
                                       f"{cells} committed trace cells), REGULAR_96_BITS PCS config, "
-                                      "ProverInput resident in HBM", "cells_per_proof": cells,
+                                      "ProverInput resident in HBM"
+                                      + (", preprocessed tree cached between proofs" if args.preprocessed_cache else ""),
+                          "cells_per_proof": cells,
                           "vm_steps": inp.steps, "parallelism": f"{world} independent segment replica(s) x {len(workers)} proof(s) in flight per GPU"},
                "phase_ms": phases, "roofline": roofline, "pipelined": pipelined}
         if world == 1 and not args.no_cpu_baseline:

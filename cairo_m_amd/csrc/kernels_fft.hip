@@ -17,7 +17,10 @@
 namespace cm {
 
 constexpr uint32_t TILE_LOG = 11;
-// LDS padding: one extra word every 32 to break the power-of-two strides of the exchanges
+// LDS padding: one extra word every 32 to break the power-of-two strides of the exchanges; a thread's 8 accesses of one
+// exchange then share a base register and differ by immediate offsets.  (A conflict-free GF(2) swizzle
+// i ^ ((i>>5)&7) ^ (((i>>6)&3)<<3) was measured 5 % slower: it needs a v_xor per access, and the pass is VALU-bound —
+// tools/fft_lab.hip, tools/lds_lab.hip.)
 __device__ __forceinline__ constexpr uint32_t phys(uint32_t i) { return i + (i >> 5); }
 
 template <int W>
@@ -85,8 +88,10 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
         }
         __syncthreads();
       }
+#ifndef CM_FFT_ABL_NO_LDS
 #pragma unroll
       for (uint32_t e = 0; e < 8; e++) v[e] = M31(tile[phys(li[e])]);
+#endif
     }
     // butterflies: k layers on bits [b, b+k).  h(e) = h0 + (j >> (s+1)) with h0 from the j = 0 element of the group
 #pragma unroll
@@ -111,7 +116,11 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
         // 9 - k; a round on bits [b, b+k) with 9 - k <= b therefore pairs elements whose twiddle index is the same
         // in every lane: fetch it with a scalar load (no per-lane address arithmetic, no vector memory op).
         if (9 - k <= b) h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+#ifdef CM_FFT_ABL_NO_TW  /* tools/fft_lab: cost of the twiddle fetch (results are wrong) */
+        M31 w(h | 3u);
+#else
         M31 w(twp[h]);
+#endif
         M31 x = v[e], y = v[e1];
         if (INVERSE) { v[e] = x + y; v[e1] = (x - y) * w; }
         else { M31 yt = y * w; v[e] = x + yt; v[e1] = x - yt; }
@@ -127,10 +136,12 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
         dst[gidx(li[e])] = o.v;
       }
     } else {
+#ifndef CM_FFT_ABL_NO_LDS  /* tools/fft_lab: cost of the LDS exchanges (results are wrong) */
       __syncthreads();  // previous round's readers are done with the tile
 #pragma unroll
       for (uint32_t e = 0; e < 8; e++) tile[phys(li[e])] = v[e].v;
       __syncthreads();
+#endif
       if (staged_out) {
         // forward transform, last round holds 8 consecutive words per lane: store 16 B per lane from LDS
 #pragma unroll

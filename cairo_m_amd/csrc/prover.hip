@@ -14,6 +14,7 @@
 #include "kprof.hpp"
 #include "point_eval.hpp"
 #include "host_adapter.hpp"
+#include <atomic>
 #include <chrono>
 #include <deque>
 #include <condition_variable>
@@ -230,6 +231,28 @@ struct Prover {
   }
 };
 
+// Optional cache of tree 0.  The preprocessed columns are constants (preprocessed/mod.rs:75-82), so their
+// coefficients, LDE and Merkle tree are the same for every proof of one PCS config.  OFF by default — a proof then
+// recomputes them like the reference does (prover.rs:70-73) and bench.py times that; cm_set_preprocessed_cache(1) or
+// CM_PREPROCESSED_CACHE=1 keeps the committed tree per host thread (it lives in that thread's device pool).
+static std::atomic<int> g_pp_cache{-1};
+static bool pp_cache_enabled() {
+  int v = g_pp_cache.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("CM_PREPROCESSED_CACHE");
+    v = (e && *e && *e != '0') ? 1 : 0;
+    g_pp_cache.store(v, std::memory_order_relaxed);
+  }
+  return v == 1;
+}
+struct PreprocessedCache {
+  bool valid = false;
+  uint32_t log_blowup = 0;
+  ColumnSet evals;     // the tables on their trace domains: the LogUp pass of rc8/16/20 and bitwise reads them
+  CommittedTree tree;
+};
+static thread_local PreprocessedCache tl_pp_cache;
+
 // Twiddle tables depend only on the domain size: built once per size and kept (like the code objects).
 static Twiddles* cached_twiddles(uint32_t R, hipStream_t st) {
   static std::mutex mu;
@@ -348,7 +371,12 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
 
   // ---- tree 0: preprocessed trace (prover.rs:70-73) ----
   ColumnSet pp_evals;
-  {
+  if (pp_cache_enabled() && tl_pp_cache.valid && tl_pp_cache.log_blowup == cfg.log_blowup_factor) {
+    P.trees[0] = std::move(tl_pp_cache.tree);  // both handed back at the end of the proof
+    pp_evals = std::move(tl_pp_cache.evals);
+    tl_pp_cache.valid = false;
+    ch.mix_root(P.trees[0].root);
+  } else {
     std::vector<uint32_t> logs(air::PREPROC_LOG, air::PREPROC_LOG + air::N_PREPROC);
     pp_evals.alloc(logs, st);
     for (int i = 0; i < air::N_PREPROC; i++) launch_preproc(i, logs[i], pp_evals.ptrs[i], st);
@@ -939,12 +967,14 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
         }
       }
     }
+    // `vals` sits in bit-reversed evaluation order, so after the in-place transform position p holds the coefficient of
+    // the basis element of degree p (= LinePoly::into_ordered_coefficients); the proof keeps the first 2^bound of them
+    // in LinePoly's own bit-reversed order (from_ordered_coefficients).
     M31 ninv = inv(M31::from_u32(n));
-    std::vector<QM31> ordered(n);
-    for (uint32_t i = 0; i < n; i++) ordered[bit_reverse(i, last_log)] = vals[i] * ninv;
     uint32_t keep = 1u << cfg.log_last_layer_degree_bound;
-    for (uint32_t i = keep; i < n; i++) CM_CHECK(ordered[i].is_zero(), "fri: last layer has invalid degree");
-    pf.last_layer_poly.assign(ordered.begin(), ordered.begin() + keep);
+    for (uint32_t i = keep; i < n; i++) CM_CHECK(vals[i].is_zero(), "fri: last layer has invalid degree");
+    pf.last_layer_poly.assign(keep, QM31());
+    for (uint32_t i = 0; i < keep; i++) pf.last_layer_poly[bit_reverse(i, cfg.log_last_layer_degree_bound)] = vals[i] * ninv;
     pf.last_layer_log_size = cfg.log_last_layer_degree_bound;
     ch.mix_felts(pf.last_layer_poly.data(), pf.last_layer_poly.size());
   }
@@ -1027,6 +1057,14 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   pf.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   pf.steps = 0;
   for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) pf.steps += in.n_bundles[i];
+  if (pp_cache_enabled()) {
+    tl_pp_cache.tree = std::move(P.trees[0]);
+    tl_pp_cache.evals = std::move(pp_evals);
+    tl_pp_cache.log_blowup = cfg.log_blowup_factor;
+    tl_pp_cache.valid = true;
+  } else if (tl_pp_cache.valid) {
+    tl_pp_cache = PreprocessedCache();  // switched off: give the buffers back to the pool
+  }
   return out.release();
 }
 
@@ -1204,6 +1242,10 @@ int32_t cm_kprof_enable(int32_t on) {
   return 0;
 }
 // time only one kernel class (name as reported by cm_kprof_report); NULL / "" = all classes
+int32_t cm_set_preprocessed_cache(int32_t on) {
+  cm::g_pp_cache.store(on ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
 int32_t cm_kprof_filter(const char* name) {
   cm::KProf::get().only = name ? name : "";
   return 0;

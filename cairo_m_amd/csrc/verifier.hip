@@ -380,7 +380,8 @@ std::string verify_proof(const ProofData& pf) {
   if (q_logs[0] < last_log + 1 || pf.fri_inner.size() != (size_t)(q_logs[0] - 1 - last_log)) return "Fri(InvalidNumFriLayers)";
   std::vector<QM31> alphas;
   for (auto& l : pf.fri_inner) { ch.mix_root(l.commitment); alphas.push_back(ch.draw_felt()); }
-  if (pf.last_layer_poly.size() != ((size_t)1 << cfg.log_last_layer_degree_bound)) return "Fri(LastLayerDegreeInvalid)";
+  if (pf.last_layer_poly.size() != ((size_t)1 << cfg.log_last_layer_degree_bound) ||
+      pf.last_layer_log_size != cfg.log_last_layer_degree_bound) return "Fri(LastLayerDegreeInvalid)";
   ch.mix_felts(pf.last_layer_poly.data(), pf.last_layer_poly.size());
   ch.mix_u64(pf.proof_of_work);
   if (ch.trailing_zeros() < cfg.pow_bits) return "ProofOfWork";
@@ -504,7 +505,7 @@ std::string verify_proof(const ProofData& pf) {
       for (size_t j = 0; j < n; j++) {
         QM31 term = pf.last_layer_poly[j];
         M31 cur = x;
-        for (size_t b = 0; ((size_t)1 << b) < n; b++) { if ((j >> b) & 1) term = term * cur; cur = double_x(cur); }
+        for (uint32_t b = 0; b < pf.last_layer_log_size; b++) { if ((j >> (pf.last_layer_log_size - 1 - b)) & 1) term = term * cur; cur = double_x(cur); }
         v += term;
       }
       if (v != evals[i]) return "Fri(LastLayerEvaluationsInvalid)";

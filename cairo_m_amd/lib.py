@@ -389,6 +389,14 @@ def _backend_prove_many(self, dev_inputs, inflight=3, cfg=None):
 Backend.prove_many = _backend_prove_many
 
 
+def _backend_set_preprocessed_cache(self, on):
+    """cm_set_preprocessed_cache: keep the committed preprocessed tree (tree 0) between proofs; off by default."""
+    self._ck(self.L.cm_set_preprocessed_cache(C.c_int32(1 if on else 0)))
+
+
+Backend.set_preprocessed_cache = _backend_set_preprocessed_cache
+
+
 # ---- compiled-program JSON (crates/common/src/program.rs:143-170, instruction.rs:609-655) ----------------------
 def load_program_json(text):
     """Compiled `Program` as the reference serialises it with serde_json: {"data": [{"Instruction": ["0x9", "0x1", ...]}

@@ -215,6 +215,11 @@ int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words);
  * inputs[i]; on error the first failure is returned and the proofs already built stay in outs (free them). */
 int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
                       cm_proof** outs);
+/* Preprocessed-tree cache: tree 0 commits constant tables (crates/prover/src/preprocessed/mod.rs:75-82;
+ * verifier.rs:38 notes its root is a known constant).  Off by default (every proof recomputes it, as prover.rs:70-73
+ * does); on = each host thread keeps the committed tree (coefficients, LDE, Merkle layers) between proofs of one
+ * PCS config.  Env CM_PREPROCESSED_CACHE=1 sets the initial value.  Proof bytes are identical either way. */
+int32_t cm_set_preprocessed_cache(int32_t on);
 /* Flat u32 serialisation of the proof (format: cairo_m_amd/csrc/proof.hpp), used by the parity tests. */
 int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* n_out);
 /* JSON text of the proof; *len_out = length without the terminating NUL; the buffer is owned by

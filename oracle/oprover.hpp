@@ -665,11 +665,12 @@ inline ProveOutput prove_segment(const cm_prover_input& in, const PcsConfig& cfg
     M31 ninv = M31((uint32_t)n).inverse();
     for (auto& v : vals) v = v * ninv;
     size_t keep = (size_t)1 << cfg.log_last_layer;
-    // coefficients are in bit-reversed order of the monomial index; into_ordered_coefficients bit-reverses
-    std::vector<QM31> ordered(n);
-    for (size_t i = 0; i < n; i++) ordered[bit_reverse_index(i, lg)] = vals[i];
-    for (size_t i = keep; i < n; i++) if (!ordered[i].is_zero()) throw std::runtime_error("fri: invalid last layer degree");
-    pf.last_layer_poly.assign(ordered.begin(), ordered.begin() + keep);
+    // Stwo: bit_reverse(values); line_ifft (natural order) -> LinePoly coefficients in ITS bit-reversed order;
+    // into_ordered_coefficients() bit-reverses again.  Working in place on the bit-reversed evaluations, position p of
+    // `vals` therefore already is ordered coefficient p (degree p).  The proof keeps from_ordered_coefficients(first keep).
+    for (size_t i = keep; i < n; i++) if (!vals[i].is_zero()) throw std::runtime_error("fri: invalid last layer degree");
+    pf.last_layer_poly.assign(keep, QM31());
+    for (size_t i = 0; i < keep; i++) pf.last_layer_poly[bit_reverse_index(i, cfg.log_last_layer)] = vals[i];
     pf.last_layer_log_size = cfg.log_last_layer;
     ch.mix_felts(pf.last_layer_poly);
   }

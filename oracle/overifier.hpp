@@ -171,7 +171,8 @@ inline std::string verify_proof(const Proof& pf) {
   if (q_logs[0] < last_log + 1 || pf.fri_inner.size() != (size_t)(q_logs[0] - 1 - last_log)) return "FRI: InvalidNumFriLayers";
   std::vector<QM31> alphas;
   for (auto& l : pf.fri_inner) { ch.mix_root(l.commitment); alphas.push_back(ch.draw_felt()); }
-  if (pf.last_layer_poly.size() != ((size_t)1 << cfg.log_last_layer)) return "FRI: LastLayerDegreeInvalid";
+  if (pf.last_layer_poly.size() != ((size_t)1 << cfg.log_last_layer) || pf.last_layer_log_size != cfg.log_last_layer)
+    return "FRI: LastLayerDegreeInvalid";
   ch.mix_felts(pf.last_layer_poly);
   ch.mix_u64(pf.proof_of_work);
   if (ch.trailing_zeros() < cfg.pow_bits) return "ProofOfWork";
@@ -282,14 +283,13 @@ inline std::string verify_proof(const Proof& pf) {
     Coset lc = Coset::half_odds(layer_log);
     for (size_t i = 0; i < lq.positions.size(); i++) {
       M31 x = lc.at(bit_reverse_index(lq.positions[i], layer_log)).x;
-      // LinePoly::eval_at_point with ordered coefficients: sum c_j * prod basis
+      // LinePoly::eval_at_point = fold(coeffs, [x, pi(x), pi^2(x), ...]): the top index bit pairs with x
       QM31 v;
-      // coefficients ordered as 1, x, pi(x), x*pi(x), ...
       size_t n = pf.last_layer_poly.size();
       for (size_t j = 0; j < n; j++) {
         QM31 term = pf.last_layer_poly[j];
         M31 cur = x;
-        for (size_t b = 0; ((size_t)1 << b) < n; b++) { if ((j >> b) & 1) term = term * cur; cur = double_x(cur); }
+        for (uint32_t b = 0; b < pf.last_layer_log_size; b++) { if ((j >> (pf.last_layer_log_size - 1 - b)) & 1) term = term * cur; cur = double_x(cur); }
         v += term;
       }
       if (v != evals[i]) return "FRI: LastLayerEvaluationsInvalid";

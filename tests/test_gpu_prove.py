@@ -161,6 +161,47 @@ def test_prove_many_pipeline(backend, oracle):
         i.free()
 
 
+def test_preprocessed_cache_keeps_proof_bytes(backend, oracle):
+    """cm_set_preprocessed_cache: with tree 0 kept between proofs the proof words stay identical to the
+    uncached proof (and to the oracle's), across different inputs, another PCS config, and the segment pipeline."""
+    inps = [synth_fibonacci(n) for n in (40, 7)]
+    devs = [backend.upload_input(i) for i in inps]
+    want = []
+    for d in devs:
+        p = backend.prove_device(d)
+        want.append(p.words().copy())
+        p.free()
+    assert np.array_equal(want[0], oracle.prove(inps[0].view)[0])
+    backend.set_preprocessed_cache(True)
+    try:
+        for rep in range(2):                      # first pass fills the cache, second one uses it
+            for d, w in zip(devs, want):
+                p = backend.prove_device(d)
+                assert np.array_equal(p.words(), w)
+                p.free()
+        cfg2 = (5, 1, 2, 20)                      # other pow bits / last-layer bound / query count: tree 0 is the same
+        p = backend.prove_device(devs[1], cfg=cfg2)
+        w2 = p.words().copy()
+        p.free()
+        assert np.array_equal(w2, oracle.prove(inps[1].view, cfg=cfg2)[0])
+        p = backend.prove_device(devs[1], cfg=cfg2)
+        assert np.array_equal(p.words(), w2)
+        p.free()
+        proofs = backend.prove_many([devs[0], devs[1], devs[0], devs[1]], inflight=2)
+        for k, p in enumerate(proofs):
+            assert np.array_equal(p.words(), want[k % 2])
+            p.free()
+    finally:
+        backend.set_preprocessed_cache(False)
+    p = backend.prove_device(devs[0])             # switched off again: buffers returned, proof unchanged
+    assert np.array_equal(p.words(), want[0])
+    p.free()
+    for d in devs:
+        backend.free_input(d)
+    for i in inps:
+        i.free()
+
+
 def test_u32_loop_at_scale_verifies(backend, oracle):
     """Looped u32 mix at 2^20 steps (BASELINE configs[2] stand-in at size): runner segment -> device adapter -> HIP prover;
     the product verifier and the oracle verifier both accept (1.3e8 cells, every u32 / bitwise / range-check component live)."""

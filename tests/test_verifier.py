@@ -46,3 +46,28 @@ def test_product_verifier_on_u32_program(oracle):
     rc, err = _verify(L, words)
     assert rc == 0, err
     inp.free()
+
+
+@pytest.mark.parametrize("bound", [1, 2])
+def test_nonzero_last_layer_degree_bound(oracle, bound):
+    """PcsConfig with log_last_layer_degree_bound > 0 (prove_cairo_m takes any Option<PcsConfig>, prover.rs:23-29): FRI
+    stops 2^(bound+1) points early, the last layer is interpolated (Stwo LineEvaluation::interpolate) and 2^bound
+    coefficients go into the proof in LinePoly's bit-reversed order.  Both verifiers accept, and evaluate that polynomial
+    at the folded queries, so any flip in it is rejected."""
+    L = load_library()
+    inp = synth_fibonacci(7)
+    cfg = (5, 1, bound, 20)
+    words, _ = oracle.prove(inp.view, cfg=cfg)
+    assert oracle.verify(words)[0] == 0
+    rc, err = _verify(L, words)
+    assert rc == 0, err
+    # locate the last-layer polynomial: its (count, 4*count words, log_size) record is unique in the stream
+    n = 1 << bound
+    hits = [i for i in range(words.size - 4 * n - 1) if words[i] == n and words[i + 1 + 4 * n] == bound
+            and all(w < 2**31 - 1 for w in words[i + 1:i + 1 + 4 * n]) and np.count_nonzero(words[i + 1:i + 1 + 4 * n]) >= 3 * n]
+    assert hits, "last-layer record not found"
+    for k in range(4 * n):
+        bad = words.copy()
+        bad[hits[-1] + 1 + k] ^= 1
+        assert _verify(L, bad)[0] != 0 and oracle.verify(bad)[0] != 0
+    inp.free()
