@@ -43,6 +43,62 @@ constexpr int N_ITER = 256;
 #define L_FMA(a) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
 #define L_CNDMASK(a) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : );
 
+#define L_XOR_SDWA(a) asm volatile("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(a) : "v"(b), "v"(c));
+#define L_XOR_SDWA_PAD(a) asm volatile("v_xor_b32_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(a) : "v"(b));
+#define L_OR_SDWA(a) asm volatile("v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(a) : "v"(b));
+#define L_AND_LIT(a) asm volatile("v_and_b32 %0, 0x7fffffff, %0" : "+v"(a));
+#define L_AND_SGPR(a) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a) : "s"(s0));
+#define L_ADD_LIT(a) asm volatile("v_add_u32 %0, 0x7fffffff, %0" : "+v"(a));
+#define L_ADD_INLINE(a) asm volatile("v_add_u32 %0, 17, %0" : "+v"(a));
+#define L_SUBREV_LIT(a) asm volatile("v_subrev_co_u32 %0, vcc, 0x7fffffff, %0" : "+v"(a) : : "vcc");
+#define L_SUBREV_SGPR(a) asm volatile("v_subrev_co_u32 %0, vcc, %1, %0" : "+v"(a) : "s"(s0) : "vcc");
+// v_cndmask with a live VCC (written once by a VALU compare before the loop) and the e64 form with an SGPR-pair mask
+__global__ void __launch_bounds__(256) k_cndmask_vcc(uint32_t* out, uint32_t s0, uint32_t s1) {
+  uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  uint32_t b = s0 ^ threadIdx.x, c = s1 + blockIdx.x;
+  asm volatile("v_cmp_gt_u32 vcc, %0, %1\n s_nop 4" : : "v"(b), "v"(c) : "vcc");
+#define L_CND_VCC(a) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : );
+  for (int it = 0; it < N_ITER; it++) {
+    REP8(L_CND_VCC(a0) L_CND_VCC(a1) L_CND_VCC(a2) L_CND_VCC(a3) L_CND_VCC(a4) L_CND_VCC(a5) L_CND_VCC(a6) L_CND_VCC(a7))
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+__global__ void __launch_bounds__(256) k_cndmask_e64(uint32_t* out, uint32_t s0, uint32_t s1) {
+  uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  uint32_t b = s0 ^ threadIdx.x;
+  unsigned long long m = ((unsigned long long)s0 << 32) | s1;
+#define L_CND_E64(a) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(m));
+  for (int it = 0; it < N_ITER; it++) {
+    REP8(L_CND_E64(a0) L_CND_E64(a1) L_CND_E64(a2) L_CND_E64(a3) L_CND_E64(a4) L_CND_E64(a5) L_CND_E64(a6) L_CND_E64(a7))
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+// the two conditional-subtract forms of M31 arithmetic, as dependent pairs on 8 accumulators
+#define L_CSUB_MIN(a) asm volatile("v_subrev_u32 %1, 0x7fffffff, %0\n v_min_u32 %0, %0, %1" : "+v"(a), "=&v"(tmp));
+#define L_CSUB_CND(a) asm volatile("v_subrev_co_u32 %1, vcc, 0x7fffffff, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(a), "=&v"(tmp) : : "vcc");
+__global__ void __launch_bounds__(256) k_csub_min(uint32_t* out, uint32_t s0, uint32_t s1) {
+  uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7, tmp;
+  for (int it = 0; it < N_ITER / 2; it++) {
+    REP8(L_CSUB_MIN(a0) L_CSUB_MIN(a1) L_CSUB_MIN(a2) L_CSUB_MIN(a3) L_CSUB_MIN(a4) L_CSUB_MIN(a5) L_CSUB_MIN(a6) L_CSUB_MIN(a7))
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+__global__ void __launch_bounds__(256) k_csub_cnd(uint32_t* out, uint32_t s0, uint32_t s1) {
+  uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7, tmp;
+  for (int it = 0; it < N_ITER / 2; it++) {
+    REP8(L_CSUB_CND(a0) L_CSUB_CND(a1) L_CSUB_CND(a2) L_CSUB_CND(a3) L_CSUB_CND(a4) L_CSUB_CND(a5) L_CSUB_CND(a6) L_CSUB_CND(a7))
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+DEFKERNEL(k_and_lit, L_AND_LIT)
+DEFKERNEL(k_and_sgpr, L_AND_SGPR)
+DEFKERNEL(k_add_lit, L_ADD_LIT)
+DEFKERNEL(k_add_inline, L_ADD_INLINE)
+DEFKERNEL(k_subrev_lit, L_SUBREV_LIT)
+DEFKERNEL(k_subrev_sgpr, L_SUBREV_SGPR)
+DEFKERNEL(k_xor_sdwa, L_XOR_SDWA)
+DEFKERNEL(k_xor_sdwa_pad, L_XOR_SDWA_PAD)
+DEFKERNEL(k_or_sdwa, L_OR_SDWA)
 DEFKERNEL(k_xor, L_XOR)
 DEFKERNEL(k_add, L_ADD)
 DEFKERNEL(k_add3, L_ADD3)
@@ -78,7 +134,12 @@ typedef void (*kern_t)(uint32_t*, uint32_t, uint32_t);
 struct K { const char* name; kern_t fn; };
 
 int main() {
-  K ks[] = {{"v_xor_b32", k_xor}, {"v_add_u32", k_add}, {"v_add3_u32", k_add3}, {"v_alignbit_b32", k_alignbit},
+  K ks[] = {{"v_cndmask_b32 (vcc set by v_cmp)", k_cndmask_vcc}, {"v_cndmask_b32_e64 (sgpr mask)", k_cndmask_e64},
+            {"csub: sub + min (pair = 1 op)", k_csub_min}, {"csub: sub_co + cndmask (pair = 1 op)", k_csub_cnd},
+            {"v_and_b32 literal", k_and_lit}, {"v_and_b32 sgpr", k_and_sgpr}, {"v_add_u32 literal", k_add_lit}, {"v_add_u32 inline const", k_add_inline},
+            {"v_subrev_co_u32 literal", k_subrev_lit}, {"v_subrev_co_u32 sgpr", k_subrev_sgpr},
+            {"v_xor_b32_sdwa dst WORD_1 preserve", k_xor_sdwa}, {"v_xor_b32_sdwa dst WORD_1 pad", k_xor_sdwa_pad},
+            {"v_or_b32_sdwa src0 WORD_1", k_or_sdwa}, {"v_xor_b32", k_xor}, {"v_add_u32", k_add}, {"v_add3_u32", k_add3}, {"v_alignbit_b32", k_alignbit},
             {"v_alignbyte_b32", k_alignbyte}, {"v_perm_b32", k_perm}, {"v_lshrrev_b32", k_lshr}, {"v_lshl_or_b32", k_lshlor},
             {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_u32", k_mulhi}, {"v_mul_u32_u24", k_mul24},
             {"v_mad_u32_u24", k_mad24}, {"v_min_u32", k_min}, {"v_and_b32", k_and}, {"v_sub_u32", k_sub},
@@ -102,7 +163,7 @@ int main() {
     double tops = lane_ops / (ms * 1e-3) / 1e12;
     // cycles per wave-instruction per SIMD at 2.4 GHz: 1024 SIMDs, 64 lanes per wave instruction
     double cyc = (2.4e9 * 1024.0) / (tops * 1e12 / 64.0);
-    printf("%-18s %7.2f T lane-ops/s   %5.2f cycles / wave-instruction / SIMD (at 2.4 GHz)\n", k.name, tops, cyc);
+    printf("%-36s %7.2f T lane-ops/s   %5.2f cycles / wave-instruction / SIMD (at 2.4 GHz)\n", k.name, tops, cyc);
   }
   return 0;
 }
