@@ -6,7 +6,7 @@ import json
 import numpy as np
 import pytest
 
-from cairo_m_amd.lib import synth_fibonacci
+from cairo_m_amd.lib import prover_input_arrays, synth_fibonacci
 
 pytestmark = pytest.mark.gpu
 
@@ -159,6 +159,30 @@ def test_prove_many_pipeline(backend, oracle):
         backend.free_input(d)
     for i in inps:
         i.free()
+
+
+def test_continuation_segments_bit_exact(backend, oracle):
+    """Continuation (crates/prover/tests/prover.rs:203-243): fibonacci_loop(30) = 312 steps cut every 100 steps into 4
+    segments.  Each segment — it starts from the memory / clocks the previous one left — goes runner segment -> device
+    adapter -> HIP prover and must equal the oracle's proof of the host-adapted input; the public roots and registers chain."""
+    from cairo_m_amd.lib import synth_fibonacci_segment
+    pub = []
+    for s in range(4):
+        hi = synth_fibonacci(30, max_steps=100, segment=s)
+        assert hi.steps == (100 if s < 3 else 12)
+        hs = synth_fibonacci_segment(30, max_steps=100, segment=s)
+        dev = backend.adapt_segment(hs)
+        p = backend.prove_device(dev)
+        want, _ = oracle.prove(hi.view)
+        assert np.array_equal(p.words(), want), f"segment {s}"
+        assert p.verify()[0] == 0
+        a = prover_input_arrays(hi.view)
+        pub.append(a)
+        p.free()
+        backend.free_input(dev)
+        hs.free(); hi.free()
+    for a, b in zip(pub, pub[1:]):
+        assert a["roots"][1] == b["roots"][0] and a["regs"][2:] == b["regs"][:2]   # (initial, final) root; (pc, fp) x 2
 
 
 def test_preprocessed_cache_keeps_proof_bytes(backend, oracle):
