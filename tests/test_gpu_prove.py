@@ -161,6 +161,32 @@ def test_prove_many_pipeline(backend, oracle):
         i.free()
 
 
+def test_invalid_witness_is_rejected_with_status_10(backend, oracle):
+    """Error behaviour of the boundary: the reference surfaces exactly one Stwo error, ProvingError::Stwo(
+    ConstraintsNotSatisfied) (crates/prover/src/errors.rs:14-18) — the composition polynomial does not match the
+    constraints at the OODS point.  A ProverInput whose logged memory values break the opcode constraints must come back
+    as status 10 from cm_prove_segment (the oracle prover refuses it too), and the library must keep working afterwards."""
+    import ctypes as C
+    from cairo_m_amd.lib import CmError, ProverInputView
+    inp = synth_fibonacci(20)
+    p = backend.prove(inp)
+    good = p.words().copy()
+    p.free()
+    v = C.cast(inp.view, C.POINTER(ProverInputView)).contents
+    acc = np.ctypeslib.as_array(C.cast(v.data_accesses, C.POINTER(C.c_uint32)), shape=(int(v.n_data_accesses), 4))
+    acc[20:40, 3] ^= 1                                    # the `value` of twenty logged accesses
+    with pytest.raises(CmError) as e:
+        backend.prove(inp)
+    assert "status 10" in str(e.value) and "ConstraintsNotSatisfied" in str(e.value)
+    with pytest.raises(RuntimeError):
+        oracle.prove(inp.view)
+    acc[20:40, 3] ^= 1
+    p = backend.prove(inp)
+    assert np.array_equal(p.words(), good)
+    p.free()
+    inp.free()
+
+
 def test_continuation_segments_bit_exact(backend, oracle):
     """Continuation (crates/prover/tests/prover.rs:203-243): fibonacci_loop(30) = 312 steps cut every 100 steps into 4
     segments.  Each segment — it starts from the memory / clocks the previous one left — goes runner segment -> device
