@@ -72,10 +72,11 @@ __device__ __forceinline__ uint32_t b2s_sel4(uint32_t q, uint32_t x0, uint32_t x
   CM_QG(b2s_sel4(q, m[s8], m[s10], m[s12], m[s14]), b2s_sel4(q, m[s9], m[s11], m[s13], m[s15]))                   \
   b = CM_QUAD_ROT(b, CM_QP(3, 0, 1, 2)); c = CM_QUAD_ROT(c, CM_QP(2, 3, 0, 1)); d = CM_QUAD_ROT(d, CM_QP(1, 2, 3, 0));
 // h0 = h[q], h1 = h[4 + q] of the node's chaining value; q = lane & 3; all 4 lanes of the quad must be active
-__device__ __forceinline__ void b2s_compress_quad(uint32_t& h0, uint32_t& h1, const uint32_t (&m)[16], uint32_t q) {
+__device__ __forceinline__ void b2s_compress_quad(uint32_t& h0, uint32_t& h1, const uint32_t (&m)[16], uint32_t q, uint32_t t = 0,
+                                                  uint32_t f0 = 0) {
   uint32_t a = h0, b = h1;
   uint32_t c = b2s_sel4(q, 0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au);
-  uint32_t d = b2s_sel4(q, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u);
+  uint32_t d = b2s_sel4(q, 0x510E527Fu ^ t, 0x9B05688Cu, 0x1F83D9ABu ^ f0, 0x5BE0CD19u);
   CM_QROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
   CM_QROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
   CM_QROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
@@ -92,43 +93,43 @@ __device__ __forceinline__ void b2s_compress_quad(uint32_t& h0, uint32_t& h1, co
 
 // ---- device-side Fiat-Shamir steps for the FRI commit phase -----------------------------------------------
 // Between two FRI layers the transcript only does mix_root(layer root) and draw_felt() (the folding
-// challenge).  Doing those two hashes in a 1-thread kernel keeps the whole commit phase on the stream:
+// challenge).  Doing those two hashes on the device keeps the whole commit phase on the stream:
 // no device->host root copy, host hash, and relaunch per layer.  The host replays the same steps on its own
 // channel afterwards (from the recorded roots) and checks the challenges agree.
-// RFC 7693 compression with explicit counter / finalisation flag (one out-of-line copy of the unrolled form)
-static __device__ __noinline__ void b2s_compress_tf(uint32_t (&h)[8], const uint32_t (&m)[16], uint32_t t, uint32_t f0) {
-  b2s_compress(h, m, t, f0);
-}
-static __device__ __forceinline__ void b2s256_init(uint32_t (&h)[8]) {
-  for (int i = 0; i < 8; i++) h[i] = B2S_IV_D[i];
-  h[0] ^= 0x01010020u;
-}
-// chan = {digest[8], n_sent}.  Blake2sChannel::mix_root then draw_felt (host twin: host_channel.hpp).
-// Called by ONE thread.
-static __device__ __noinline__ void chan_mix_root_draw_dev(uint32_t* chan, const uint32_t* root, uint32_t* felt_out, uint32_t* root_log) {
-  uint32_t h[8], m[16];
-  // mix_root: digest = Blake2s256(digest || root)  (64 bytes = one final block, t = 64)
-  for (int i = 0; i < 8; i++) { m[i] = chan[i]; m[8 + i] = root[i]; root_log[i] = root[i]; }
-  b2s256_init(h);
-  b2s_compress_tf(h, m, 64, 0xFFFFFFFFu);
-  for (int i = 0; i < 8; i++) chan[i] = h[i];
+// chan = {digest[8], n_sent}.  Blake2sChannel::mix_root then draw_felt (host twin: host_channel.hpp):
+//   mix_root: digest = Blake2s256(digest || root)  (64 bytes = one final block, t = 64)
+//   draw_felt: Blake2s256(digest || le32(n_sent) || 0^28 || 0x00) (65 bytes), retried until all 8 words < 2P.
+// Runs on ONE QUAD of lanes (lanes 0..3 of a wave, all four active, q = lane): half the latency of a one-thread form.
+// `root` may live in LDS; `x8` is an 8-word LDS scratch; the challenge also lands in lds_felt[0..4).
+static __device__ __noinline__ void chan_mix_root_draw_quad(uint32_t q, uint32_t* chan, const uint32_t* root, uint32_t* felt_out,
+                                                            uint32_t* root_log, volatile uint32_t* x8, volatile uint32_t* lds_felt) {
+  uint32_t m[16];
+  for (int i = 0; i < 8; i++) { m[i] = chan[i]; m[8 + i] = root[i]; }
+  root_log[q] = root[q]; root_log[4 + q] = root[4 + q];
+  const uint32_t iv0 = b2s_sel4(q, 0x6A09E667u ^ 0x01010020u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au);
+  const uint32_t iv1 = b2s_sel4(q, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u);
+  uint32_t h0 = iv0, h1 = iv1;
+  b2s_compress_quad(h0, h1, m, q, 64, 0xFFFFFFFFu);      // mix_root
+  chan[q] = h0; chan[4 + q] = h1;
+  x8[q] = h0; x8[4 + q] = h1;                              // the 4 lanes run in lockstep; LDS ops of a wave stay in order
+  for (int i = 0; i < 8; i++) m[i] = x8[i];
   uint32_t n_sent = 0;
-  // draw_felt: Blake2s256(digest || le32(n_sent) || 0^28 || 0x00) (65 bytes), retry until all 8 words < 2P
-  for (;;) {
-    uint32_t d[8];
-    for (int i = 0; i < 8; i++) { m[i] = h[i]; m[8 + i] = 0; }
+  for (;;) {                                               // draw_felt
+    for (int i = 8; i < 16; i++) m[i] = 0;
     m[8] = n_sent++;
-    b2s256_init(d);
-    b2s_compress_tf(d, m, 64, 0);
-    for (int i = 0; i < 16; i++) m[i] = 0;
-    b2s_compress_tf(d, m, 65, 0xFFFFFFFFu);
-    bool ok = true;
-    for (int i = 0; i < 8; i++) ok = ok && d[i] < 2u * P;
-    if (!ok) continue;
-    for (int i = 0; i < 4; i++) felt_out[i] = M31::from_u32(d[i]).v;
+    uint32_t d0 = iv0, d1 = iv1;
+    b2s_compress_quad(d0, d1, m, q, 64, 0);
+    uint32_t z[16];
+    for (int i = 0; i < 16; i++) z[i] = 0;
+    b2s_compress_quad(d0, d1, z, q, 65, 0xFFFFFFFFu);
+    const bool ok = d0 < 2u * P && d1 < 2u * P;
+    if ((__ballot(ok) & 0xFull) != 0xFull) continue;
+    const uint32_t f = M31::from_u32(d0).v;
+    felt_out[q] = f;
+    lds_felt[q] = f;
     break;
   }
-  chan[8] = n_sent;
+  if (q == 0) chan[8] = n_sent;
 }
 
 }  // namespace cm

@@ -39,6 +39,7 @@ void fold_line(uint32_t* const out[4], const uint32_t* const src[4], uint32_t lo
 // tree, do the transcript step (mix_root, draw the folding challenge) and fold to the next layer.  These
 // layers are pure launch/dependency latency as separate kernels (~6 launches each).
 constexpr uint32_t FRI_TAIL_MAX_LOG = 13;
+constexpr uint32_t FRI_TAIL_DEFAULT_LOG = 10;  // env CM_FRI_TAIL_LOG overrides (tuning)
 struct FriTailLayer {
   uint32_t* cols[4];                        // line evaluation of the layer (4 coordinates x 2^log)
   const uint32_t* circle[4];                // quotient columns of log + 1 to fold in first, or null

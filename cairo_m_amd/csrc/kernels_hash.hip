@@ -41,8 +41,9 @@ __global__ void __launch_bounds__(256) k_grind(const uint32_t* __restrict__ dige
 
 // chan = {digest[8], n_sent}.  Blake2sChannel::mix_root then draw_felt (host twin: host_channel.hpp).
 __global__ void k_chan_mix_root_draw(uint32_t* chan, const uint32_t* root, uint32_t* felt_out, uint32_t* root_log) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  chan_mix_root_draw_dev(chan, root, felt_out, root_log);
+  __shared__ uint32_t x8[8], felt[4];
+  if (threadIdx.x >= 4 || blockIdx.x != 0) return;   // one quad of lanes: half the latency of one thread
+  chan_mix_root_draw_quad(threadIdx.x, chan, root, felt_out, root_log, x8, felt);
 }
 
 // Decommitment gather: out[q * width + w] = addrs[q][w]  (width 1 = column values, 8 = 32-byte hashes).

@@ -253,6 +253,16 @@ struct PreprocessedCache {
 };
 static thread_local PreprocessedCache tl_pp_cache;
 
+// FRI layers of at most 2^fri_tail_log() points are all handled by one single-block launch (k_fri_tail).
+static uint32_t fri_tail_log() {
+  static const uint32_t v = [] {
+    const char* e = getenv("CM_FRI_TAIL_LOG");
+    uint32_t x = e ? (uint32_t)atoi(e) : FRI_TAIL_DEFAULT_LOG;
+    return std::min(std::max(x, 1u), FRI_TAIL_MAX_LOG);
+  }();
+  return v;
+}
+
 // Twiddle tables depend only on the domain size: built once per size and kept (like the code objects).
 static Twiddles* cached_twiddles(uint32_t R, hipStream_t st) {
   static std::mutex mu;
@@ -818,7 +828,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     for (size_t k = 0; k < quotients.size(); k++) for (int c = 0; c < 4; c++) { cols.push_back(quotients[k].ptrs[c]); logs.push_back(q_logs[k]); }
     first_tree.prepare(cols, logs);
     ub.add(first_tree.cols, &first_tree.d_cols_view);
-    for (uint32_t l = layer_log; l > last_log && l > FRI_TAIL_MAX_LOG; l--) {
+    for (uint32_t l = layer_log; l > last_log && l > fri_tail_log(); l--) {
       std::unique_ptr<InnerLayer> il(new InnerLayer());
       il->log = l;
       il->eval.alloc(std::vector<uint32_t>(4, l), st, false);
@@ -842,7 +852,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   size_t qi = 0, pi = 0;
   const QM31 unused_alpha;
   while (layer_log > last_log) {
-    if (layer_log <= FRI_TAIL_MAX_LOG) {
+    if (layer_log <= fri_tail_log()) {
       // every remaining layer in one launch (k_fri_tail); buffers are laid out here so that the decommitment
       // code sees ordinary InnerLayer objects afterwards
       FriTailArgs ta;
