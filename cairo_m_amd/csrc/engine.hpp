@@ -139,6 +139,9 @@ struct DevBuf {
   uint32_t* u32() const { return (uint32_t*)p; }
   template <class T> T* as() const { return (T*)p; }
 };
+// Device->host results land in a per-thread pinned buffer: truly asynchronous (pool.hip).  Valid after the stream is
+// synchronised and until the next call on this thread.
+const void* stage_download_async(const void* src, size_t bytes, hipStream_t st);
 // Small host->device uploads (pointer arrays, coefficients, positions) go through a pinned staging ring
 // and hipMemcpyAsync on the launch stream: no host sync, no pageable-copy stall.
 template <class T>

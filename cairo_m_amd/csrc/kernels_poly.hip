@@ -439,6 +439,7 @@ void eval_at_point_batch(const uint32_t* const* d_coeffs, uint32_t ncols, uint32
 
 void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st) {
   if (jobs.empty()) return;
+
   std::vector<EapJobDev> dj(jobs.size());
   size_t words = 0;
   uint32_t blocks = 0, cols = 0, max_tab_blocks = 1;

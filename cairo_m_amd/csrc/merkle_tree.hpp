@@ -57,12 +57,11 @@ struct GatherBatch {
     if (nw) gather_words(d_w, (uint32_t)word_addrs.size(), 1, out.u32(), st);
     if (nh) gather_words(d_h, (uint32_t)hash_addrs.size(), 8, out.u32() + nw, st);
     if (nr) gather_runs(d_r, (uint32_t)runs.size(), out.u32() + nw + nh, st);
-    std::vector<uint32_t> host(total);
-    CM_HIP(hipMemcpyAsync(host.data(), out.p, total * 4, hipMemcpyDeviceToHost, st));
+    const uint32_t* host = (const uint32_t*)stage_download_async(out.p, total * 4, st);
     CM_HIP(hipStreamSynchronize(st));
-    std::copy(host.begin(), host.begin() + nw, words.begin());
-    std::copy(host.begin() + nw, host.begin() + nw + nh, hashes.begin());
-    std::copy(host.begin() + nw + nh, host.end(), run_out.begin());
+    std::copy(host, host + nw, words.begin());
+    std::copy(host + nw, host + nw + nh, hashes.begin());
+    std::copy(host + nw + nh, host + total, run_out.begin());
   }
 };
 
@@ -177,7 +176,12 @@ struct MerkleTree {
     DecommitPlan plan;
     plan.hash0 = gb.hash_addrs.size();
     size_t ci = 0;
-    std::vector<uint32_t> last;
+    size_t max_q = 0;
+    for (auto& kv : queries_per_log_size) max_q = std::max(max_q, kv.second.size());
+    std::vector<uint32_t> last, total;   // scratch reused across the layers (no per-layer allocation)
+    last.reserve(max_q);
+    total.reserve(max_q);
+    plan.segs.reserve(max_q * layers.size());
     for (int layer_log = (int)layers.size() - 1; layer_log >= 0; layer_log--) {
       size_t c0 = ci;
       while (ci < cols.size() && col_logs[ci] == (uint32_t)layer_log) ci++;
@@ -185,7 +189,7 @@ struct MerkleTree {
       static const std::vector<uint32_t> empty;
       auto it = queries_per_log_size.find((uint32_t)layer_log);
       const std::vector<uint32_t>& colq = it == queries_per_log_size.end() ? empty : it->second;
-      std::vector<uint32_t> total;
+      total.clear();
       size_t pi = 0, qi = 0;
       while (pi < last.size() || qi < colq.size()) {
         uint32_t node;

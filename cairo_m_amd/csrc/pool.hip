@@ -1,6 +1,7 @@
 // Device-memory caching pool + pinned upload ring.  Sized for a 288 GB part: freed blocks are kept
 // (never returned to the driver on the hot path) and reused best-fit, so a steady-state proof performs
 // zero hipMalloc/hipFree calls; cm_shutdown()/pool_trim() hands everything back.
+#include <algorithm>
 #include "engine.hpp"
 #include <map>
 #include <mutex>
@@ -89,6 +90,27 @@ void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
   memcpy(s.base + s.off, src, bytes);
   CM_HIP(hipMemcpyAsync(dst, s.base + s.off, bytes, hipMemcpyHostToDevice, st));
   s.off += need;
+}
+
+// Pinned landing buffer for device->host results (one per host thread, grown on demand): a hipMemcpyAsync into
+// pageable memory blocks the caller until the stream has drained, so host work meant to overlap the producing
+// kernels never overlapped.  The returned pointer is valid once `st` is synchronised, until the next call.
+namespace {
+struct Landing {
+  uint8_t* base = nullptr;
+  size_t cap = 0;
+};
+Landing& landing() { static thread_local Landing* l = new Landing(); return *l; }
+}  // namespace
+const void* stage_download_async(const void* src, size_t bytes, hipStream_t st) {
+  Landing& l = landing();
+  if (bytes > l.cap) {
+    if (l.base) { CM_HIP(hipStreamSynchronize(st)); CM_HIP(hipHostFree(l.base)); l.base = nullptr; }
+    l.cap = std::max(bytes * 2, (size_t)1 << 20);
+    CM_HIP(hipHostMalloc((void**)&l.base, l.cap, hipHostMallocDefault));
+  }
+  if (bytes) CM_HIP(hipMemcpyAsync(l.base, src, bytes, hipMemcpyDeviceToHost, st));
+  return l.base;
 }
 
 // ---- fork/join side streams ---------------------------------------------------------------------------

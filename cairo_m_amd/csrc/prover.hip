@@ -184,9 +184,14 @@ struct Prover {
   std::vector<double> phase_ms;
   std::chrono::steady_clock::time_point t0;
 
-  void tick(const char*) {
+  void tick(const char* name) {
+    static const bool trace = getenv("CM_HOST_TRACE") != nullptr;
+    auto te = std::chrono::steady_clock::now();
     CM_HIP(hipStreamSynchronize(st));
     auto t1 = std::chrono::steady_clock::now();
+    if (trace)
+      fprintf(stderr, "[phase] %-20s host %8.1f us, then waited %8.1f us for the GPU\n", name,
+              std::chrono::duration<double, std::micro>(te - t0).count(), std::chrono::duration<double, std::micro>(t1 - te).count());
     phase_ms.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
     t0 = t1;
   }
@@ -329,7 +334,19 @@ static QGather plan_fri_positions(const uint32_t* const col4[4], const std::vect
 }
 
 // =========================================================================================================
+// CM_HOST_TRACE=1: host-side time between marks on stderr (where the GPU sits idle waiting for the host)
+struct HostTrace {
+  bool on = getenv("CM_HOST_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[host] %-40s %8.1f us\n", what, std::chrono::duration<double, std::micro>(n - t).count());
+    t = n;
+  }
+};
 ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
+  HostTrace ht;
   const cm_prover_input& in = din.meta;
   std::unique_ptr<ProofData> out(new ProofData());
   ProofData& pf = *out;
@@ -377,6 +394,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       ch.mix_u32s(words.data(), words.size());
     }
   }
+  ht.mark("setup");
   P.tick("setup");
 
   // ---- tree 0: preprocessed trace (prover.rs:70-73) ----
@@ -392,7 +410,9 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     for (int i = 0; i < air::N_PREPROC; i++) launch_preproc(i, logs[i], pp_evals.ptrs[i], st);
     P.commit(P.trees[0], &pp_evals, false);
   }
+  ht.mark("preprocessed enqueued");
   P.tick("preprocessed");
+  ht.mark("preprocessed gpu done");
 
   // ---- tree 1: execution trace (prover.rs:77-82; Claim::write_trace) ----
   std::vector<size_t> tr0(air::N_COMPONENTS), it0(air::N_COMPONENTS);
@@ -637,6 +657,23 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   }
   P.tick("composition_commit");
 
+  // host side of compute_fri_quotients for every size group, packed into ONE upload:
+  // [column pointers | out pointers | col_index | coef_c | batches] per group, 16-byte aligned
+  struct QRef { int t; uint32_t c; };
+  struct QEntry { uint32_t col; const QM31* value; };
+  struct QBatch { CPoint<QM31> pt; std::vector<QEntry> entries; };
+  struct QGroup { uint32_t log = 0; std::vector<const uint32_t*> cols; std::vector<QBatch> batches; ColumnSet out;
+                  size_t o_cols = 0, o_out = 0, o_ci = 0, o_cc = 0, o_qb = 0; };
+  std::vector<QGroup> qg;
+  std::vector<uint8_t> qblob;
+  auto qput = [&](const void* ptr, size_t bytes) {
+    size_t o = (qblob.size() + 15) & ~(size_t)15;
+    qblob.resize(o + bytes);
+    if (bytes && ptr) memcpy(qblob.data() + o, ptr, bytes);
+    return o;
+  };
+
+  ht.mark("(composition commit done)");
   // ---- OODS sampling ----
   CPoint<QM31> oods;
   {
@@ -646,8 +683,10 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     oods.x = (QM31(M31(1)) - t2) * iv;
     oods.y = (t + t) * iv;
   }
+  ht.mark("oods: point drawn");
   pf.sampled_values.resize(4);
   for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
+  ht.mark("oods: sampled_values resized");
   // Sampling jobs = (log size, point): every column at the OODS point, plus the previous-row mask
   // (oods - trace_step(log)) of each component's last LogUp column group.  All jobs share one pointer-table
   // upload, one scratch buffer and ONE device->host copy of the results.
@@ -674,6 +713,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
         jobs.push_back(Job{kv.first, pt, kv.second});
       }
     }
+    ht.mark("oods: jobs built");
     std::vector<const uint32_t*> table;
     size_t n_out = 0;
     for (auto& j : jobs) {
@@ -683,6 +723,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       n_out += j.refs.size();
     }
     DevBuf d_table = upload(table, st), dout(n_out * 16);
+    ht.mark("oods: table uploaded");
     {
       std::vector<EapJob> ej;
       for (auto& j : jobs)
@@ -690,114 +731,112 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
                             dout.u32() + 4 * j.out_off});
       eval_at_point_multi(ej, st);
     }
-    std::vector<uint32_t> w(n_out * 4);
-    CM_HIP(hipMemcpyAsync(w.data(), dout.p, w.size() * 4, hipMemcpyDeviceToHost, st));
+    const uint32_t* w = (const uint32_t*)stage_download_async(dout.p, n_out * 16, st);   // read after the sync below
+    ht.mark("oods: enqueued");
+    // ---- while the evaluation kernels run: everything about the sampled values and the DEEP quotients
+    // (compute_fri_quotients) that does not depend on the values themselves ----
+    for (auto& j : jobs)
+      for (auto& r : j.refs) pf.sampled_values[r.t][r.c].push_back(QM31());   // mask order [-1, 0]: sized now, filled below
+    size_t n_samples = 0;
+    for (auto& t : pf.sampled_values) for (auto& c : t) n_samples += c.size();
+    std::map<uint32_t, std::vector<QRef>, std::greater<uint32_t>> qgroups;  // LDE log -> columns (tree-major order)
+    for (int t = 0; t < 4; t++)
+      for (uint32_t c = 0; c < P.trees[t].lde.size(); c++) qgroups[P.trees[t].lde.logs[c]].push_back({t, c});
+    for (auto& kv : qgroups) {
+      QGroup g;
+      g.log = kv.first;
+      for (uint32_t i = 0; i < kv.second.size(); i++) {
+        const QRef& r = kv.second[i];
+        g.cols.push_back(P.trees[r.t].lde.ptrs[r.c]);
+        const size_t ns = pf.sampled_values[r.t][r.c].size();
+        for (size_t k = 0; k < ns; k++) {
+          // sample points: [oods] or [prev, oods]
+          CPoint<QM31> pt = (ns == 2 && k == 0) ? prev_points[P.trees[r.t].coeffs.logs[r.c]] : oods;
+          size_t bi = 0;
+          for (; bi < g.batches.size(); bi++) if (g.batches[bi].pt.x == pt.x && g.batches[bi].pt.y == pt.y) break;
+          if (bi == g.batches.size()) g.batches.push_back(QBatch{pt, {}});
+          g.batches[bi].entries.push_back(QEntry{i, &pf.sampled_values[r.t][r.c][k]});
+        }
+      }
+      size_t n_entries = 0;
+      for (auto& bt : g.batches) n_entries += bt.entries.size();
+      g.out.alloc(std::vector<uint32_t>(4, g.log), st, false);
+      g.o_cols = qput(g.cols.data(), g.cols.size() * sizeof(void*));
+      g.o_out = qput(g.out.ptrs.data(), 4 * sizeof(void*));
+      g.o_ci = qput(nullptr, n_entries * 4);
+      g.o_cc = qput(nullptr, n_entries * 16);
+      g.o_qb = qput(nullptr, g.batches.size() * sizeof(QuotientBatch));
+      qg.push_back(std::move(g));
+    }
+    ht.mark("oods: overlapped quotient planning");
     CM_HIP(hipStreamSynchronize(st));
+    ht.mark("oods: waited for gpu");
     for (auto& j : jobs)
       for (size_t i = 0; i < j.refs.size(); i++) {
         auto& sv = pf.sampled_values[j.refs[i].t][j.refs[i].c];
-        QM31 v = QM31::from_u32(&w[4 * (j.out_off + i)]);
-        if (j.refs[i].prev) sv.insert(sv.begin(), v);  // mask order [-1, 0]
-        else sv.push_back(v);
+        (j.refs[i].prev ? sv.front() : sv.back()) = QM31::from_u32(&w[4 * (j.out_off + i)]);
       }
-  }
-  {
     std::vector<QM31> flat;
-    for (auto& t : pf.sampled_values) for (auto& c : t) for (auto& s : c) flat.push_back(s);
+    flat.reserve(n_samples);
+    for (auto& t : pf.sampled_values) for (auto& c : t) for (auto& sm : c) flat.push_back(sm);
+    ht.mark("oods: fill + flatten");
     ch.mix_felts(flat.data(), flat.size());
+    ht.mark("oods: mix_felts");
   }
   P.tick("oods_sampling");
-  // ---- DEEP quotients (compute_fri_quotients) ----
+  // ---- DEEP quotients (compute_fri_quotients): the value-dependent coefficients, one upload, the launches ----
   QM31 qcoeff = ch.draw_felt();
-  struct Ref { int t; uint32_t c; };
-  std::map<uint32_t, std::vector<Ref>, std::greater<uint32_t>> qgroups;  // LDE log -> columns (tree-major order)
-  for (int t = 0; t < 4; t++)
-    for (uint32_t c = 0; c < P.trees[t].lde.size(); c++) qgroups[P.trees[t].lde.logs[c]].push_back({t, c});
   std::vector<uint32_t> q_logs;
   std::vector<ColumnSet> quotients;
   {
-    // host side of compute_fri_quotients for every size group, packed into ONE upload:
-    // [column pointers | out pointers | col_index | coef_c | batches] per group, 16-byte aligned
-    struct GroupOff { size_t cols, out, ci, cc, qb; uint32_t n_batches, n_cols; };
-    std::vector<GroupOff> offs;
-    std::vector<uint8_t> blob;
-    auto put = [&](const void* p, size_t bytes) {
-      size_t o = (blob.size() + 15) & ~(size_t)15;
-      blob.resize(o + bytes);
-      if (bytes) memcpy(blob.data() + o, p, bytes);
-      return o;
-    };
-    for (auto& kv : qgroups) {
-      uint32_t l = kv.first;
-      std::vector<const uint32_t*> cols;
-      struct Batch { CPoint<QM31> pt; std::vector<std::pair<uint32_t, QM31>> entries; };
-      std::vector<Batch> batches;
-      for (uint32_t i = 0; i < kv.second.size(); i++) {
-        const Ref& r = kv.second[i];
-        cols.push_back(P.trees[r.t].lde.ptrs[r.c]);
-        const auto& sv = pf.sampled_values[r.t][r.c];
-        for (size_t k = 0; k < sv.size(); k++) {
-          // sample points: [oods] or [prev, oods]
-          CPoint<QM31> pt = (sv.size() == 2 && k == 0) ? prev_points[P.trees[r.t].coeffs.logs[r.c]] : oods;
-          size_t b = 0;
-          for (; b < batches.size(); b++) if (batches[b].pt.x == pt.x && batches[b].pt.y == pt.y) break;
-          if (b == batches.size()) batches.push_back(Batch{pt, {}});
-          batches[b].entries.push_back({i, sv[k]});
-        }
-      }
-      std::vector<QuotientBatch> qb(batches.size());
-      std::vector<uint32_t> col_index, coef_c;
-      for (size_t b = 0; b < batches.size(); b++) {
-        qb[b].begin = (uint32_t)col_index.size();
+    for (auto& g : qg) {
+      uint32_t* col_index = (uint32_t*)(qblob.data() + g.o_ci);
+      uint32_t* coef_c = (uint32_t*)(qblob.data() + g.o_cc);
+      QuotientBatch* qb = (QuotientBatch*)(qblob.data() + g.o_qb);
+      uint32_t e = 0;
+      for (size_t bi = 0; bi < g.batches.size(); bi++) {
+        const QBatch& bt = g.batches[bi];
+        qb[bi].begin = e;
         QM31 alpha(M31(1)), sum_a, sum_b;
-        QM31 cdiff = conj_u(batches[b].pt.y) - batches[b].pt.y;
-        for (auto& e : batches[b].entries) {
+        const QM31 cdiff = conj_u(bt.pt.y) - bt.pt.y;
+        for (auto& en : bt.entries) {
+          const QM31 v = *en.value;
           alpha = alpha * qcoeff;
-          QM31 a = conj_u(e.second) - e.second;
-          QM31 bb = e.second * cdiff - a * batches[b].pt.y;
-          sum_a += alpha * a;
+          QM31 av = conj_u(v) - v;
+          QM31 bb = v * cdiff - av * bt.pt.y;
+          sum_a += alpha * av;
           sum_b += alpha * bb;
-          col_index.push_back(e.first);
-          uint32_t w[4];
-          (alpha * cdiff).to_u32(w);
-          coef_c.insert(coef_c.end(), w, w + 4);
+          col_index[e] = en.col;
+          (alpha * cdiff).to_u32(coef_c + 4 * e);
+          e++;
         }
-        qb[b].end = (uint32_t)col_index.size();
-        batches[b].pt.x.to_u32(qb[b].point);   // words = (Pr.x, Pi.x): QM31 = (a.a, a.b, b.a, b.b)
-        batches[b].pt.y.to_u32(qb[b].point + 4);
-        sum_a.to_u32(qb[b].sum_a);
-        sum_b.to_u32(qb[b].sum_b);
-        qpow(qcoeff, batches[b].entries.size()).to_u32(qb[b].batch_coeff);
+        qb[bi].end = e;
+        bt.pt.x.to_u32(qb[bi].point);   // words = (Pr.x, Pi.x): QM31 = (a.a, a.b, b.a, b.b)
+        bt.pt.y.to_u32(qb[bi].point + 4);
+        sum_a.to_u32(qb[bi].sum_a);
+        sum_b.to_u32(qb[bi].sum_b);
+        alpha.to_u32(qb[bi].batch_coeff);   // qcoeff^(entries of the batch)
       }
-      ColumnSet q;
-      q.alloc(std::vector<uint32_t>(4, l), st, false);
-      GroupOff g;
-      g.cols = put(cols.data(), cols.size() * sizeof(void*));
-      g.out = put(q.ptrs.data(), 4 * sizeof(void*));
-      g.ci = put(col_index.data(), col_index.size() * 4);
-      g.cc = put(coef_c.data(), coef_c.size() * 4);
-      g.qb = put(qb.data(), qb.size() * sizeof(QuotientBatch));
-      g.n_batches = (uint32_t)qb.size();
-      g.n_cols = (uint32_t)cols.size();
-      offs.push_back(g);
-      q_logs.push_back(l);
-      quotients.push_back(std::move(q));
     }
-    DevBuf d_blob = upload(blob, st);
+    ht.mark("quotients: coefficient math");
+    DevBuf d_blob = upload(qblob, st);
     const uint8_t* base = d_blob.as<uint8_t>();
-    for (size_t k = 0; k < offs.size(); k++) {
+    for (auto& g : qg) {
       QuotientArgs a;
-      a.tw = view(*P.tw); a.log_size = q_logs[k];
-      a.cols = (const uint32_t* const*)(base + offs[k].cols);
-      a.out = (uint32_t* const*)(base + offs[k].out);
-      a.col_index = (const uint32_t*)(base + offs[k].ci);
-      a.coef_c = (const uint32_t*)(base + offs[k].cc);
-      a.batches = (const QuotientBatch*)(base + offs[k].qb);
-      a.n_batches = offs[k].n_batches;
-      launch_quotients(a, (double)offs[k].n_cols, st);
+      a.tw = view(*P.tw); a.log_size = g.log;
+      a.cols = (const uint32_t* const*)(base + g.o_cols);
+      a.out = (uint32_t* const*)(base + g.o_out);
+      a.col_index = (const uint32_t*)(base + g.o_ci);
+      a.coef_c = (const uint32_t*)(base + g.o_cc);
+      a.batches = (const QuotientBatch*)(base + g.o_qb);
+      a.n_batches = (uint32_t)g.batches.size();
+      launch_quotients(a, (double)g.cols.size(), st);
+      q_logs.push_back(g.log);
+      quotients.push_back(std::move(g.out));
     }
   }
   P.tick("quotients");
+  ht.mark("quotients: gpu done");
 
   // ---- FRI commit ----
   // The whole commit phase is enqueued without a host round trip: after each layer's Merkle tree a 1-thread
@@ -946,7 +985,8 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     CM_HIP(hipMemcpyAsync(h_alphas.data(), d_alphas.p, h_alphas.size() * 4, hipMemcpyDeviceToHost, st));
     CM_HIP(hipMemcpyAsync(h_roots.data(), d_roots.p, h_roots.size() * 4, hipMemcpyDeviceToHost, st));
     {
-      GatherBatch gb;
+      ht.mark("decommit: queries drawn");
+    GatherBatch gb;
       QGather g = plan_gather_q(c4, pos, gb);
       gb.run(st);  // synchronises the stream: roots / challenges are on the host now
       finish_gather_q(g, gb, vals);
@@ -992,6 +1032,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   pf.proof_of_work = grind_gpu(ch.digest.data(), cfg.pow_bits, st);
   ch.mix_u64(pf.proof_of_work);
   P.tick("pow");
+  ht.mark("pow done");
 
   // ---- queries + decommitment ----
   Queries queries;
@@ -1016,6 +1057,12 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   {
     // One batched gather for every tree of the proof: FRI first layer, inner layers, the 4 commitment trees.
     GatherBatch gb;
+    {  // ~ n_queries x tree depth x (2 siblings) per tree; growing these vectors dominated the planning time
+      const size_t per_tree = (size_t)cfg.n_queries * 2 * (q_logs[0] + 2);
+      gb.hash_addrs.reserve(per_tree * (inner.size() + 5));
+      gb.word_addrs.reserve((size_t)cfg.n_queries * 8 * (inner.size() + 1));
+      gb.runs.reserve((size_t)cfg.n_queries * 4 * (q_logs[0] + 2));
+    }
     std::vector<QGather> first_w;
     std::map<uint32_t, std::vector<uint32_t>> first_dpos;
     for (size_t k = 0; k < quotients.size(); k++) {
@@ -1040,8 +1087,11 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       }
     }
     DecommitPlan tree_plan[4];
+    ht.mark("decommit: fri plans");
     for (int t = 0; t < 4; t++) tree_plan[t] = P.trees[t].merkle.plan_decommit(qpos, gb);
+    ht.mark("decommit: tree plans");
     gb.run(st);
+    ht.mark("decommit: gather run (upload+kernel+d2h)");
     for (auto& g : first_w) finish_gather_q(g, gb, pf.fri_first.fri_witness);
     {
       std::vector<uint32_t> qv;
@@ -1062,6 +1112,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       pf.commitments.push_back(P.trees[t].root);
     }
   }
+  ht.mark("decommit: finish");
   P.tick("decommit");
   pf.phase_ms = P.phase_ms;
   pf.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
