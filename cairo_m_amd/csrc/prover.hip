@@ -373,6 +373,12 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   uint32_t max_log = 0;
   for (int c = 0; c < air::N_COMPONENTS; c++) max_log = std::max(max_log, clog[c]);
   for (int c = 0; c < air::N_COMPONENTS; c++) CM_CHECK(clog[c] <= 26, "component too large");
+  // launch orders: components by descending size (stable)
+  std::vector<int> by_size, by_size_all;
+  for (int c = 0; c < air::N_COMPONENTS; c++) { by_size_all.push_back(c); if (c < air::N_OPCODE_COMPONENTS) by_size.push_back(c); }
+  auto bigger = [&](int x, int y) { return clog[x] > clog[y]; };
+  std::stable_sort(by_size.begin(), by_size.end(), bigger);
+  std::stable_sort(by_size_all.begin(), by_size_all.end(), bigger);
   const uint32_t comp_log = max_log + 1;
   P.tw = cached_twiddles(comp_log + cfg.log_blowup_factor, st);
 
@@ -445,8 +451,11 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     // components are independent: fork over side streams (trace then histogram of one component stay ordered)
     KProfRegion kreg("k_trace_gen(region)", st);
     Fork fk(st);
-    for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++) {
-      hipStream_t sc = fk.stream(c);
+    // large components first: their kernels keep the GPU busy while the host issues the ~40 launches of the idle
+    // ones (the host launch rate, not the GPU, bounds this region otherwise); histogram adds commute
+    for (int pos = 0; pos < air::N_OPCODE_COMPONENTS; pos++) {
+      const int c = by_size[pos];
+      hipStream_t sc = fk.stream(pos);
       launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
       launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, sc);
     }
@@ -502,10 +511,11 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     std::vector<LogupTailJob> jobs(air::N_COMPONENTS);
     KProfRegion kreg("k_logup(region)", st);
     Fork fk(st);
-    for (int c = 0; c < air::N_COMPONENTS; c++) {
+    for (int pos = 0; pos < air::N_COMPONENTS; pos++) {   // large components first (see trace generation)
+      const int c = by_size_all[pos];
       const air::ComponentInfo& info = air::component_info(c);
       launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
-                   drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(c));
+                   drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(pos));
       for (int k = 0; k < 4; k++) jobs[c].col[k] = it_evals.ptrs[it0[c] + info.n_interaction - 4 + k];
       jobs[c].log_size = clog[c];
     }
