@@ -382,8 +382,15 @@ def _backend_prove_many(self, dev_inputs, inflight=3, cfg=None):
     n = len(dev_inputs)
     ins = (C.c_void_p * n)(*[d.value if isinstance(d, C.c_void_p) else d for d in dev_inputs])
     outs = (C.c_void_p * n)()
-    self._ck(self.L.cm_prove_many(ins, C.c_uint32(n), _cfg(cfg), C.c_uint32(inflight), outs))
-    return [Proof(self.L, C.c_void_p(outs[i])) for i in range(n)]
+    rc = self.L.cm_prove_many(ins, C.c_uint32(n), _cfg(cfg), C.c_uint32(inflight), outs)
+    proofs = [Proof(self.L, C.c_void_p(outs[i])) if outs[i] else None for i in range(n)]
+    if rc != 0:
+        try:
+            self._ck(rc)                       # raises CmError with the first failure's message
+        except CmError as e:
+            e.partial = proofs                 # the proofs that were built (None where a segment failed): caller frees them
+            raise
+    return proofs
 
 
 Backend.prove_many = _backend_prove_many

@@ -187,6 +187,38 @@ def test_invalid_witness_is_rejected_with_status_10(backend, oracle):
     inp.free()
 
 
+def test_prove_many_reports_first_failure_and_keeps_the_rest(backend):
+    """cm_prove_many error contract (include/cairom_hip.h): the first failure is returned, the proofs already built stay
+    in outs.  One bad segment among three: status 10, the two good proofs are there and equal their solo proofs."""
+    import ctypes as C
+    from cairo_m_amd.lib import CmError, ProverInputView
+    inps = [synth_fibonacci(n) for n in (9, 30, 12)]
+    solo = []
+    for i in inps:
+        p = backend.prove(i)
+        solo.append(p.words().copy())
+        p.free()
+    v = C.cast(inps[1].view, C.POINTER(ProverInputView)).contents
+    acc = np.ctypeslib.as_array(C.cast(v.data_accesses, C.POINTER(C.c_uint32)), shape=(int(v.n_data_accesses), 4))
+    acc[20:40, 3] ^= 1
+    devs = [backend.upload_input(i) for i in inps]
+    with pytest.raises(CmError) as e:
+        backend.prove_many(devs, inflight=3)
+    assert "status 10" in str(e.value)
+    part = e.value.partial
+    assert part[1] is None and part[0] is not None and part[2] is not None
+    assert np.array_equal(part[0].words(), solo[0]) and np.array_equal(part[2].words(), solo[2])
+    part[0].free(); part[2].free()
+    good = backend.prove_many([devs[0], devs[2]], inflight=2)          # the pipeline keeps working
+    assert np.array_equal(good[0].words(), solo[0]) and np.array_equal(good[1].words(), solo[2])
+    for p in good:
+        p.free()
+    for d in devs:
+        backend.free_input(d)
+    for i in inps:
+        i.free()
+
+
 def test_continuation_segments_bit_exact(backend, oracle):
     """Continuation (crates/prover/tests/prover.rs:203-243): fibonacci_loop(30) = 312 steps cut every 100 steps into 4
     segments.  Each segment — it starts from the memory / clocks the previous one left — goes runner segment -> device
