@@ -142,6 +142,7 @@ struct DevBuf {
 // Device->host results land in a per-thread pinned buffer: truly asynchronous (pool.hip).  Valid after the stream is
 // synchronised and until the next call on this thread.
 const void* stage_download_async(const void* src, size_t bytes, hipStream_t st);
+uint32_t* pinned_words();   // 64 pinned words per host thread (deferred single-word checks)
 // Small host->device uploads (pointer arrays, coefficients, positions) go through a pinned staging ring
 // and hipMemcpyAsync on the launch stream: no host sync, no pageable-copy stall.
 template <class T>

@@ -113,6 +113,13 @@ const void* stage_download_async(const void* src, size_t bytes, hipStream_t st) 
   return l.base;
 }
 
+// 64 pinned words per host thread for single-word results whose check is deferred to the next natural sync
+uint32_t* pinned_words() {
+  static thread_local uint32_t* p = nullptr;
+  if (!p) CM_HIP(hipHostMalloc((void**)&p, 256, hipHostMallocDefault));
+  return p;
+}
+
 // ---- fork/join side streams ---------------------------------------------------------------------------
 namespace {
 struct SideStreams {

@@ -184,16 +184,39 @@ struct Prover {
   std::vector<double> phase_ms;
   std::chrono::steady_clock::time_point t0;
 
+  // Phase boundaries are HIP events on the prover stream, read back at the end of the proof: a host-side
+  // hipStreamSynchronize per phase drained the GPU at boundaries that need no host round trip (constraints ->
+  // composition commit, quotients -> FRI).  CM_HOST_TRACE=1 restores the synchronising form and prints host / wait times.
+  std::vector<hipEvent_t> evs;
+  static std::vector<hipEvent_t>& event_cache() { static thread_local std::vector<hipEvent_t> c; return c; }
+  hipEvent_t next_event() {
+    auto& c = event_cache();
+    if (evs.size() == c.size()) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); c.push_back(e); }
+    evs.push_back(c[evs.size()]);
+    return evs.back();
+  }
+  void start() {
+    t0 = std::chrono::steady_clock::now();
+    CM_HIP(hipEventRecord(next_event(), st));
+  }
   void tick(const char* name) {
     static const bool trace = getenv("CM_HOST_TRACE") != nullptr;
+    CM_HIP(hipEventRecord(next_event(), st));
+    if (!trace) return;
     auto te = std::chrono::steady_clock::now();
     CM_HIP(hipStreamSynchronize(st));
     auto t1 = std::chrono::steady_clock::now();
-    if (trace)
-      fprintf(stderr, "[phase] %-20s host %8.1f us, then waited %8.1f us for the GPU\n", name,
-              std::chrono::duration<double, std::micro>(te - t0).count(), std::chrono::duration<double, std::micro>(t1 - te).count());
-    phase_ms.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+    fprintf(stderr, "[phase] %-20s host %8.1f us, then waited %8.1f us for the GPU\n", name,
+            std::chrono::duration<double, std::micro>(te - t0).count(), std::chrono::duration<double, std::micro>(t1 - te).count());
     t0 = t1;
+  }
+  void finish() {   // the stream is idle (the decommitment gather has been read back)
+    CM_HIP(hipEventSynchronize(evs.back()));
+    for (size_t k = 1; k < evs.size(); k++) {
+      float ms = 0;
+      CM_HIP(hipEventElapsedTime(&ms, evs[k - 1], evs[k]));
+      phase_ms.push_back(ms);
+    }
   }
 
   // IFFT src(evals, trace domain) -> tree.coeffs; LDE -> tree.lde; Merkle; mix root.
@@ -356,7 +379,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   P.cfg = cfg;
   P.st = thread_main_stream();
   hipStream_t st = P.st;
-  P.t0 = std::chrono::steady_clock::now();
+  P.start();
   auto t_start = P.t0;
   Channel& ch = P.ch;
 
@@ -431,9 +454,10 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     }
     tr_evals.alloc(logs, st);
   }
+  DevBuf flag(4);   // range-check / bitwise lookup out of range: read back with the tree-1 root (no round trip of its own)
+  uint32_t* flag_host = pinned_words();
   {
     // multiplicity columns = histograms over every lookup of every opcode component (components/mod.rs:139-160)
-    DevBuf flag(4);
     CM_HIP(hipMemsetAsync(flag.p, 0, 4, st));
     HistPtrs h;
     h.rc8 = tr_evals.ptrs[tr0[air::C_RC8]]; h.rc16 = tr_evals.ptrs[tr0[air::C_RC16]];
@@ -469,14 +493,13 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
                            clog[air::C_POSEIDON2], tr_evals.dev(tr0[air::C_POSEIDON2]), fk.stream(air::C_POSEIDON2));
     fk.join();
     kreg.close();
-    uint32_t f = 0;
-    CM_HIP(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipStreamSynchronize(st));
-    CM_CHECK(f == 0, "trace generation: a range-check / bitwise lookup value is out of range");
+    flag_host[0] = 0xffffffffu;
+    CM_HIP(hipMemcpyAsync(flag_host, flag.p, 4, hipMemcpyDeviceToHost, st));
   }
   P.tick("trace_gen");
   for (int c = 0; c < air::N_COMPONENTS; c++) { pf.claim_log_sizes.push_back(clog[c]); ch.mix_u64(clog[c]); }
-  P.commit(P.trees[1], &tr_evals, false);
+  P.commit(P.trees[1], &tr_evals, false);   // synchronises on the root
+  CM_CHECK(flag_host[0] == 0, "trace generation: a range-check / bitwise lookup value is out of range");
   P.tick("trace_commit");
 
   // ---- interaction PoW + relations (prover.rs:90-94) ----
@@ -1124,6 +1147,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   }
   ht.mark("decommit: finish");
   P.tick("decommit");
+  P.finish();
   pf.phase_ms = P.phase_ms;
   pf.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   pf.steps = 0;
