@@ -5,6 +5,7 @@
 #include "engine.hpp"
 #include "fri_kernels.hpp"
 #include <string>
+#include <algorithm>
 
 using namespace cm;
 extern "C" int32_t cm_set_last_error(const char* msg);
@@ -30,9 +31,60 @@ __global__ void k_inverse_qm31(CP4 in, P4 out, uint64_t n) {
   QM31 v = inv(QM31(M31(in.p[0][i]), M31(in.p[1][i]), M31(in.p[2][i]), M31(in.p[3][i])));
   out.p[0][i] = v.a.a.v; out.p[1][i] = v.a.b.v; out.p[2][i] = v.b.a.v; out.p[3][i] = v.b.b.v;
 }
+// FriOps::decompose helpers: per-block partial sums of (+f on the first half, -f on the second), then the shift
+__global__ void k_decompose_sum(CP4 f, uint32_t log_n, uint32_t* partial /*[gridDim.x][4]*/) {
+  __shared__ uint32_t red[4][256];
+  const uint64_t n = 1ull << log_n, half = n >> 1;
+  QM31 acc;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    QM31 v(M31(f.p[0][i]), M31(f.p[1][i]), M31(f.p[2][i]), M31(f.p[3][i]));
+    if (i < half) acc += v; else acc = acc - v;
+  }
+  red[0][threadIdx.x] = acc.a.a.v; red[1][threadIdx.x] = acc.a.b.v; red[2][threadIdx.x] = acc.b.a.v; red[3][threadIdx.x] = acc.b.b.v;
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+      for (int k = 0; k < 4; k++) red[k][threadIdx.x] = (M31(red[k][threadIdx.x]) + M31(red[k][threadIdx.x + s])).v;
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ void k_decompose_apply(P4 f, uint32_t log_n, const uint32_t* partial, uint32_t n_partial, uint32_t* lambda_out) {
+  const uint64_t n = 1ull << log_n, half = n >> 1;
+  M31 lam[4];
+  for (int k = 0; k < 4; k++) {
+    M31 t(0);
+    for (uint32_t b = 0; b < n_partial; b++) t = t + M31(partial[b * 4 + k]);
+    lam[k] = t * inv(M31::from_u32((uint32_t)n));
+  }
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) for (int k = 0; k < 4; k++) lambda_out[k] = lam[k].v;
+  if (i >= n) return;
+  for (int k = 0; k < 4; k++) f.p[k][i] = (i < half ? M31(f.p[k][i]) - lam[k] : M31(f.p[k][i]) + lam[k]).v;
+}
 }  // namespace
 
 extern "C" {
+
+// FriOps::decompose (Stwo core::fri; CPU backend: lambda = (sum first half - sum second half) / n on the bit-reversed
+// evaluation, g = f -/+ lambda).  Not on the prove_cairo_m path (every committed column is inside the FFT space), kept
+// for the Backend trait surface.
+int32_t cm_fri_decompose(const cm_handle f[4], uint32_t log_n, uint32_t lambda_out[4], cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(log_n >= 1 && log_n <= 30, "cm_fri_decompose: bad log size");
+    CP4 c; P4 m;
+    for (int k = 0; k < 4; k++) { m.p[k] = P32(f[k]); c.p[k] = m.p[k]; CM_CHECK(m.p[k], "cm_fri_decompose: null column"); }
+    const uint64_t n = 1ull << log_n;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 64);
+    DevBuf partial((size_t)blocks * 16), lam(16);
+    hipLaunchKernelGGL(k_decompose_sum, dim3(blocks), dim3(256), 0, S(s), c, log_n, partial.u32());
+    hipLaunchKernelGGL(k_decompose_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(s), m, log_n, partial.u32(), blocks,
+                       lam.u32());
+    CM_HIP(hipGetLastError());
+    CM_HIP(hipMemcpyAsync(lambda_out, lam.p, 16, hipMemcpyDeviceToHost, S(s)));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
 
 // FieldOps::batch_inverse: element-wise inverses (the Montgomery trick of the CPU backend is a
 // latency optimisation; one Fermat chain per lane is the GPU-native form and gives the same values).

@@ -1293,6 +1293,158 @@ int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm
   if (sh.rc) { cm_set_last_error(sh.err.c_str()); return sh.rc; }
   return 0;
 }
+// ---- per-component AIR ops (include/cairom_hip.h): the kernels of the whole-segment prover, one component
+// at a time on caller-owned columns --------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+inline hipStream_t S_(cm_stream_t s) { return (hipStream_t)(uintptr_t)s; }
+inline uint32_t* H_(cm_handle h) { return (uint32_t*)(uintptr_t)h; }
+uint32_t component_log_size(const cm_prover_input& in, int c) {
+  using namespace cm;
+  if (c < air::N_OPCODE_COMPONENTS) return log_size_for(in.n_bundles[c]);
+  switch (c) {
+    case air::C_MEMORY: return log_size_for(in.n_initial_memory + in.n_final_memory);
+    case air::C_MERKLE: case air::C_POSEIDON2: return log_size_for(in.n_initial_tree + in.n_final_tree);
+    case air::C_CLOCK_UPDATE: return log_size_for(in.n_clock_updates);
+    case air::C_RC8: return 8; case air::C_RC16: return 16; case air::C_RC20: return 20; case air::C_BITWISE: return 18;
+  }
+  throw CmError(1, "bad component id");
+}
+std::vector<uint32_t*> handles(const cm_handle* h, int n) {
+  std::vector<uint32_t*> v(n);
+  for (int i = 0; i < n; i++) { v[i] = H_(h[i]); if (!v[i]) throw cm::CmError(1, "null column handle"); }
+  return v;
+}
+void check_component(int32_t c) { if (c < 0 || c >= air::N_COMPONENTS) throw cm::CmError(1, "bad component id"); }
+}  // namespace
+}  // extern "C++"
+
+int32_t cm_component_info(int32_t component, uint32_t* n_trace_cols, uint32_t* n_interaction_cols, uint32_t* n_constraints) {
+  return pguard([&] {
+    check_component(component);
+    const air::ComponentInfo& i = air::component_info(component);
+    if (n_trace_cols) *n_trace_cols = (uint32_t)i.n_trace;
+    if (n_interaction_cols) *n_interaction_cols = (uint32_t)i.n_interaction;
+    if (n_constraints) *n_constraints = (uint32_t)i.n_constraints;
+  });
+}
+int32_t cm_component_log_size(const cm_device_input* input, int32_t component, uint32_t* log_size) {
+  return pguard([&] { check_component(component); *log_size = component_log_size(input->d->meta, component); });
+}
+int32_t cm_trace_write(const cm_device_input* input, int32_t c, const cm_handle* cols, cm_stream_t s) {
+  return pguard([&] {
+    using namespace cm;
+    check_component(c);
+    CM_CHECK(c <= air::C_POSEIDON2, "cm_trace_write: the lookup-table components' trace is their multiplicity column (cm_histogram)");
+    bind_thread_to_library_device();
+    const DeviceInput& d = *input->d;
+    const cm_prover_input& in = d.meta;
+    const uint32_t lg = component_log_size(in, c);
+    hipStream_t st = S_(s);
+    DevBuf tab = upload(handles(cols, air::component_info(c).n_trace), st);
+    uint32_t* const* dc = tab.as<uint32_t*>();
+    if (c < air::N_OPCODE_COMPONENTS) launch_opcode_trace(c, d.bundles[c].p, (uint32_t)in.n_bundles[c], d.data_accesses.p, lg, dc, st);
+    else if (c == air::C_MEMORY)
+      launch_memory_trace(d.init_mem.p, (uint32_t)in.n_initial_memory, d.fin_mem.p, (uint32_t)in.n_final_memory, in.initial_root,
+                          in.final_root, lg, dc, st);
+    else if (c == air::C_MERKLE)
+      launch_merkle_trace(d.init_tree.p, (uint32_t)in.n_initial_tree, d.fin_tree.p, (uint32_t)in.n_final_tree, in.initial_root,
+                          in.final_root, lg, dc, st);
+    else if (c == air::C_CLOCK_UPDATE) launch_clock_update_trace(d.clock_updates.p, (uint32_t)in.n_clock_updates, lg, dc, st);
+    else launch_poseidon2_trace(d.init_tree.p, (uint32_t)in.n_initial_tree, d.fin_tree.p, (uint32_t)in.n_final_tree, lg, dc, st);
+    CM_HIP(hipStreamSynchronize(st));
+  });
+}
+int32_t cm_histogram(int32_t c, const cm_handle* trace_cols, uint32_t log_size, cm_handle rc8, cm_handle rc16, cm_handle rc20,
+                     cm_handle bitwise, cm_stream_t s) {
+  return pguard([&] {
+    using namespace cm;
+    CM_CHECK(c >= 0 && c < air::N_OPCODE_COMPONENTS, "cm_histogram: opcode components only");
+    bind_thread_to_library_device();
+    hipStream_t st = S_(s);
+    DevBuf tab = upload(handles(trace_cols, air::component_info(c).n_trace), st), flag(4);
+    CM_HIP(hipMemsetAsync(flag.p, 0, 4, st));
+    HistPtrs h;
+    h.rc8 = H_(rc8); h.rc16 = H_(rc16); h.rc20 = H_(rc20); h.bitwise = H_(bitwise); h.error_flag = flag.u32();
+    CM_CHECK(h.rc8 && h.rc16 && h.rc20 && h.bitwise, "cm_histogram: null multiplicity column");
+    launch_hist(c, (const uint32_t* const*)tab.as<uint32_t*>(), log_size, h, st);
+    uint32_t f = 0;
+    CM_HIP(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    CM_CHECK(f == 0, "cm_histogram: a range-check / bitwise lookup value is out of range");
+  });
+}
+int32_t cm_preprocessed_column(int32_t id, cm_handle col, cm_stream_t s) {
+  return pguard([&] {
+    using namespace cm;
+    CM_CHECK(id >= 0 && id < air::N_PREPROC && col, "cm_preprocessed_column: bad id / null column");
+    bind_thread_to_library_device();
+    launch_preproc(id, air::PREPROC_LOG[id], H_(col), S_(s));
+    CM_HIP(hipStreamSynchronize(S_(s)));
+  });
+}
+int32_t cm_interaction_write(int32_t c, const cm_handle* trace_cols, const cm_handle* preprocessed, uint32_t log_size,
+                             const cm_relations* relations, const cm_handle* out, uint32_t claimed_sum[4], cm_stream_t s) {
+  return pguard([&] {
+    using namespace cm;
+    check_component(c);
+    static_assert(sizeof(cm_relations) == sizeof(DevRelations), "cm_relations must mirror DevRelations");
+    bind_thread_to_library_device();
+    hipStream_t st = S_(s);
+    const air::ComponentInfo& info = air::component_info(c);
+    std::vector<uint32_t*> oc = handles(out, info.n_interaction);
+    UploadBatch ub;
+    uint32_t** d_tr = nullptr; uint32_t** d_pp = nullptr; uint32_t** d_out = nullptr;
+    ub.add(handles(trace_cols, info.n_trace), &d_tr);
+    ub.add(handles(preprocessed, air::N_PREPROC), &d_pp);
+    ub.add(oc, &d_out);
+    DevBuf tabs = ub.flush(st), drel(sizeof(DevRelations)), d_sums(16);
+    stage_upload(drel.p, relations, sizeof(DevRelations), st);
+    launch_logup(c, (const uint32_t* const*)d_tr, (const uint32_t* const*)d_pp, log_size, drel.as<DevRelations>(), d_out, st);
+    std::vector<LogupTailJob> jobs(1);
+    for (int k = 0; k < 4; k++) jobs[0].col[k] = oc[info.n_interaction - 4 + k];
+    jobs[0].log_size = log_size;
+    logup_finalize_all(jobs, d_sums.u32(), st);
+    CM_HIP(hipMemcpyAsync(claimed_sum, d_sums.p, 16, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+  });
+}
+int32_t cm_constraints_accumulate(int32_t c, const cm_handle* trace_lde, const cm_handle* interaction_lde,
+                                  const cm_handle* preprocessed_lde, uint32_t log_size, const cm_relations* relations,
+                                  const uint32_t* coeff_powers, const uint32_t claimed_sum[4], const cm_handle acc[4],
+                                  cm_stream_t s) {
+  return pguard([&] {
+    using namespace cm;
+    check_component(c);
+    bind_thread_to_library_device();
+    hipStream_t st = S_(s);
+    const air::ComponentInfo& info = air::component_info(c);
+    UploadBatch ub;
+    uint32_t** d_tr = nullptr; uint32_t** d_it = nullptr; uint32_t** d_pp = nullptr; uint32_t** d_acc = nullptr;
+    uint32_t* d_coeff = nullptr;
+    ub.add(handles(trace_lde, info.n_trace), &d_tr);
+    ub.add(handles(interaction_lde, info.n_interaction), &d_it);
+    ub.add(handles(preprocessed_lde, air::N_PREPROC), &d_pp);
+    ub.add(handles(acc, 4), &d_acc);
+    ub.add(std::vector<uint32_t>(coeff_powers, coeff_powers + 4 * (size_t)info.n_constraints), &d_coeff);
+    DevBuf tabs = ub.flush(st), drel(sizeof(DevRelations));
+    stage_upload(drel.p, relations, sizeof(DevRelations), st);
+    ConstraintArgs a;
+    a.tr = (const uint32_t* const*)d_tr; a.it = (const uint32_t* const*)d_it; a.pp = (const uint32_t* const*)d_pp;
+    a.rels = drel.as<DevRelations>();
+    a.coeff = d_coeff;
+    a.acc = d_acc;
+    a.log_size = log_size;
+    a.n_base = info.n_base_constraints;
+    (QM31::from_u32(claimed_sum) * inv(M31::from_u32(1u << log_size))).to_u32(a.cumsum_shift);
+    for (uint32_t k = 0; k < 2; k++) {
+      CPoint<M31> pt = point_at_index(domain_index_at(log_size + 1, k));
+      a.denom_inv[k] = inv(coset_vanishing_canonic<M31>(log_size, pt)).v;
+    }
+    launch_constraints(c, a, st);
+    CM_HIP(hipStreamSynchronize(st));
+  });
+}
 // verify_cairo_m (crates/prover/src/verifier.rs:17-95): 0 = accepted; status 11 + cm_last_error() = name of the failed check
 int32_t cm_verify_proof(const cm_proof* p) {
   return pguard([&] {

@@ -456,3 +456,70 @@ def program_to_json(cells, entrypoints=None):
     import json
     return json.dumps({"data": [{"Instruction": [f"0x{w:x}" for w in ins]} for ins in cells],
                        "entrypoints": entrypoints or {}, "metadata": {}})
+
+
+# ---- per-component AIR ops (include/cairom_hip.h) -----------------------------------------------------
+N_COMPONENTS = 34
+N_PREPROCESSED = 7
+PREPROCESSED_LOG = (18, 18, 18, 18, 8, 16, 20)
+RELATION_WORDS = 8 * 4 + 8 * 16 * 4   # cm_relations: z[8][4], alpha_pow[8][16][4]
+
+
+def _b_component_info(self, cid):
+    a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    self._ck(self.L.cm_component_info(C.c_int32(cid), C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
+def _b_component_log_size(self, dev_input, cid):
+    lg = C.c_uint32(0)
+    self._ck(self.L.cm_component_log_size(dev_input, C.c_int32(cid), C.byref(lg)))
+    return lg.value
+
+
+def _b_trace_write(self, dev_input, cid, cols):
+    self._ck(self.L.cm_trace_write(dev_input, C.c_int32(cid), self._harr(cols), C.c_uint64(0)))
+
+
+def _b_histogram(self, cid, trace_cols, log_size, rc8, rc16, rc20, bitwise):
+    self._ck(self.L.cm_histogram(C.c_int32(cid), self._harr(trace_cols), C.c_uint32(log_size), C.c_uint64(rc8), C.c_uint64(rc16),
+                                 C.c_uint64(rc20), C.c_uint64(bitwise), C.c_uint64(0)))
+
+
+def _b_preprocessed_column(self, pp_id, col):
+    self._ck(self.L.cm_preprocessed_column(C.c_int32(pp_id), C.c_uint64(col), C.c_uint64(0)))
+
+
+def _b_interaction_write(self, cid, trace_cols, preprocessed, log_size, rel_words, out_cols):
+    r = np.ascontiguousarray(rel_words, dtype=np.uint32)
+    assert r.size == RELATION_WORDS
+    cs = np.zeros(4, dtype=np.uint32)
+    self._ck(self.L.cm_interaction_write(C.c_int32(cid), self._harr(trace_cols), self._harr(preprocessed), C.c_uint32(log_size),
+                                         _p(r), self._harr(out_cols), _p(cs), C.c_uint64(0)))
+    return cs
+
+
+def _b_constraints_accumulate(self, cid, trace_lde, interaction_lde, preprocessed_lde, log_size, rel_words, coeff_words,
+                              claimed_sum, acc4):
+    r = np.ascontiguousarray(rel_words, dtype=np.uint32)
+    co = np.ascontiguousarray(coeff_words, dtype=np.uint32)
+    cs = np.ascontiguousarray(claimed_sum, dtype=np.uint32)
+    self._ck(self.L.cm_constraints_accumulate(C.c_int32(cid), self._harr(trace_lde), self._harr(interaction_lde),
+                                              self._harr(preprocessed_lde), C.c_uint32(log_size), _p(r), _p(co), _p(cs),
+                                              self._harr(acc4), C.c_uint64(0)))
+
+
+def _b_fri_decompose(self, f4, log_n):
+    lam = np.zeros(4, dtype=np.uint32)
+    self._ck(self.L.cm_fri_decompose(self._harr(f4), C.c_uint32(log_n), _p(lam), C.c_uint64(0)))
+    return lam
+
+
+Backend.component_info = _b_component_info
+Backend.component_log_size = _b_component_log_size
+Backend.trace_write = _b_trace_write
+Backend.histogram = _b_histogram
+Backend.preprocessed_column = _b_preprocessed_column
+Backend.interaction_write = _b_interaction_write
+Backend.constraints_accumulate = _b_constraints_accumulate
+Backend.fri_decompose = _b_fri_decompose

@@ -263,6 +263,52 @@ int32_t cm_segment_from_artifacts(const uint8_t* trace, uint64_t trace_len, cons
                                   int32_t mem_has_header, const uint32_t* initial_memory, uint64_t n_initial_memory,
                                   const uint32_t ranges[6], cm_host_segment** out);
 int32_t cm_host_segment_free(cm_host_segment* h);
+/* ---- per-component AIR ops --------------------------------------------------------------------
+ * What the reference does per component through Rust generics that name SimdBackend — and therefore cannot be
+ * reached through Stwo's Backend traits — on caller-owned device columns (cm_handle = u32[2^log_size]):
+ *   cm_trace_write            = <component>::Claim::write_trace (e.g. opcodes/store_fp_imm.rs:147-296, memory.rs:93-195,
+ *                               merkle.rs:92-201, clock_update.rs:77-166, poseidon2.rs:172-325)
+ *   cm_histogram              = range_check_N / bitwise Claim::write_trace multiplicities
+ *                               (preprocessed/range_check/range_check_macro.rs:62-112, preprocessed/bitwise.rs:72-157)
+ *   cm_preprocessed_column    = PreProcessedTrace::gen_trace columns (preprocessed/mod.rs:36-38, bitwise.rs:283-319)
+ *   cm_interaction_write      = <component>::InteractionClaim::write_interaction_trace + LogupTraceGenerator::finalize_last
+ *   cm_constraints_accumulate = FrameworkComponent::evaluate_constraint_quotients_on_domain of <component>::Eval
+ * Component ids: 0..25 = opcode components in the order of define_opcodes! (opcodes/mod.rs:223-268), then memory 26,
+ * merkle 27, clock_update 28, poseidon2 29, range_check_8/16/20 30..32, bitwise 33.  The whole-segment prover runs the
+ * same kernels. */
+#define CM_N_RELATIONS 8
+#define CM_MAX_RELATION_SIZE 16
+#define CM_N_PREPROCESSED 7
+/* Relations::draw (components/mod.rs:311-323): z and the powers alpha^0.. of every relation, QM31 as 4 words */
+typedef struct {
+  uint32_t z[CM_N_RELATIONS][4];
+  uint32_t alpha_pow[CM_N_RELATIONS][CM_MAX_RELATION_SIZE][4];
+} cm_relations;
+int32_t cm_component_info(int32_t component, uint32_t* n_trace_cols, uint32_t* n_interaction_cols, uint32_t* n_constraints);
+/* log size of the component's trace for this input: max(4, ceil_log2(rows)) — fixed 8/16/20/18 for the lookup tables */
+int32_t cm_component_log_size(const cm_device_input* input, int32_t component, uint32_t* log_size);
+/* components 0..29; cols = n_trace_cols columns of 2^log_size (padding rows included) */
+int32_t cm_trace_write(const cm_device_input* input, int32_t component, const cm_handle* cols, cm_stream_t s);
+/* adds the lookups of one opcode component's trace (padding rows included) to the four multiplicity columns
+ * (2^8, 2^16, 2^20, 2^18 words, zeroed by the caller); an out-of-range value is status 1 */
+int32_t cm_histogram(int32_t component, const cm_handle* trace_cols, uint32_t log_size, cm_handle rc8, cm_handle rc16,
+                     cm_handle rc20, cm_handle bitwise, cm_stream_t s);
+/* preprocessed column id 0..6 (bitwise op / a / b / result, range_check_8, _16, _20) on its trace domain */
+int32_t cm_preprocessed_column(int32_t id, cm_handle col, cm_stream_t s);
+/* trace_cols / preprocessed: trace-domain columns (preprocessed = all CM_N_PREPROCESSED columns);
+ * out = n_interaction_cols columns; claimed_sum = the component's InteractionClaim */
+int32_t cm_interaction_write(int32_t component, const cm_handle* trace_cols, const cm_handle* preprocessed, uint32_t log_size,
+                             const cm_relations* relations, const cm_handle* out, uint32_t claimed_sum[4], cm_stream_t s);
+/* *_lde: the component's columns evaluated on CanonicCoset(log_size + 1) (cm_interpolate + cm_evaluate), preprocessed_lde
+ * likewise (column k on CanonicCoset(its log + 1)); coeff_powers = the random-coefficient powers of this component's
+ * n_constraints constraints, 4 words each, in constraint order; acc += sum_k coeff_k * C_k / vanishing */
+int32_t cm_constraints_accumulate(int32_t component, const cm_handle* trace_lde, const cm_handle* interaction_lde,
+                                  const cm_handle* preprocessed_lde, uint32_t log_size, const cm_relations* relations,
+                                  const uint32_t* coeff_powers, const uint32_t claimed_sum[4], const cm_handle acc[4],
+                                  cm_stream_t s);
+/* FriOps::decompose: lambda = (sum of the first half - sum of the second half) / 2^log_n of a bit-reversed secure
+ * evaluation; g = f - lambda on the first half, f + lambda on the second.  In place; lambda_out = 4 words. */
+int32_t cm_fri_decompose(const cm_handle f[4], uint32_t log_n, uint32_t lambda_out[4], cm_stream_t s);
 /* Optional HIP-event kernel timing on the launch stream (bench.py `roofline`). */
 int32_t cm_kprof_enable(int32_t on);
 int32_t cm_kprof_report(char* buf, size_t buf_len);

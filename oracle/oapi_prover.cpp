@@ -75,6 +75,75 @@ int orc_component_trace(const cm_prover_input* in, int cid, uint32_t* log_out, u
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return 4; }
 }
+// ---- per-component interaction trace / constraint accumulation (parity of cm_interaction_write / cm_constraints_accumulate) ----
+static Relations relations_from_words(const uint32_t* w) {   // layout of cm_relations: z[8][4], alpha_pow[8][16][4]
+  auto q = [](const uint32_t* x) { return QM31::from_m31s(M31(x[0]), M31(x[1]), M31(x[2]), M31(x[3])); };
+  Relations r;
+  for (int i = 0; i < air::N_RELATIONS; i++) r.z[i] = q(w + 4 * i);
+  const uint32_t* a = w + 4 * air::N_RELATIONS;
+  for (int i = 0; i < air::N_RELATIONS; i++)
+    for (int k = 0; k < air::MAX_REL_SIZE; k++) r.alpha_pow[i][k] = q(a + 4 * (i * air::MAX_REL_SIZE + k));
+  return r;
+}
+// interaction columns (n_interaction x 2^log words into dst) and claimed sum of one component
+int orc_component_interaction(const cm_prover_input* in, int cid, const uint32_t* rel_words, uint32_t* dst, uint64_t dst_cap,
+                              uint32_t* claimed_sum) {
+  try {
+    std::string err;
+    std::vector<ComponentTrace> cts = write_traces(*in, err);
+    if (!err.empty()) { g_err = err; return 1; }
+    ComponentTrace& ct = cts[cid];
+    std::vector<Col> pp = preprocessed_columns();
+    gen_interaction_dispatch(ct, relations_from_words(rel_words), pp);
+    uint64_t need = ct.interaction.size() << ct.log_size;
+    if (dst_cap < need) { g_err = "buffer too small"; return 2; }
+    for (size_t c = 0; c < ct.interaction.size(); c++) memcpy(dst + (c << ct.log_size), ct.interaction[c].data(), (size_t)4 << ct.log_size);
+    for (int k = 0; k < 4; k++) claimed_sum[k] = ct.claimed_sum.coord(k).v;
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 4; }
+}
+// acc (4 x 2^(log+1) words, zero-initialised here) = sum_k coeff_k * C_k / vanishing of one component on its evaluation domain
+int orc_component_constraints(const cm_prover_input* in, int cid, const uint32_t* rel_words, const uint32_t* coeff_words,
+                              uint32_t* acc_out) {
+  try {
+    std::string err;
+    std::vector<ComponentTrace> cts = write_traces(*in, err);
+    if (!err.empty()) { g_err = err; return 1; }
+    ComponentTrace& ct = cts[cid];
+    Relations rel = relations_from_words(rel_words);
+    std::vector<Col> pp = preprocessed_columns();
+    gen_interaction_dispatch(ct, rel, pp);
+    PcsProver pcs;
+    pcs.trees.resize(3);
+    auto lde = [](const Col& evals) { Col c = evals; uint32_t lg = ilog2(c.size()); return evaluate(interpolate(std::move(c)), lg + 1); };
+    for (auto& c : pp) pcs.trees[0].evals.push_back(lde(c));
+    for (auto& c : ct.trace) pcs.trees[1].evals.push_back(lde(c));
+    for (auto& c : ct.interaction) pcs.trees[2].evals.push_back(lde(c));
+    const air::ComponentInfo& info = air::component_info(cid);
+    std::vector<QM31> coeff(info.n_constraints);
+    for (int k = 0; k < info.n_constraints; k++)
+      coeff[k] = QM31::from_m31s(M31(coeff_words[4 * k]), M31(coeff_words[4 * k + 1]), M31(coeff_words[4 * k + 2]), M31(coeff_words[4 * k + 3]));
+    size_t N = (size_t)2 << ct.log_size;
+    std::vector<Col> acc(4, Col(N));
+    accumulate_constraints_dispatch(ct, TraceLocation{0, 0}, pcs, rel, coeff.data(), acc);
+    for (int k = 0; k < 4; k++) for (size_t i = 0; i < N; i++) acc_out[k * N + i] = acc[k][i].v;
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 4; }
+}
+// FriOps::decompose restated from the Stwo CPU backend: in place on 4 x 2^log words; lambda out
+void orc_fri_decompose(uint32_t* f, uint32_t log, uint32_t* lambda_out) {
+  size_t N = (size_t)1 << log, H = N / 2;
+  QM31 a, b;
+  auto at = [&](size_t i) { return QM31::from_m31s(M31(f[i]), M31(f[N + i]), M31(f[2 * N + i]), M31(f[3 * N + i])); };
+  for (size_t i = 0; i < H; i++) a += at(i);
+  for (size_t i = H; i < N; i++) b += at(i);
+  QM31 lambda = (a - b) * M31((uint32_t)N).inverse();
+  for (size_t i = 0; i < N; i++) {
+    QM31 v = i < H ? at(i) - lambda : at(i) + lambda;
+    for (int k = 0; k < 4; k++) f[k * N + i] = v.coord(k).v;
+  }
+  for (int k = 0; k < 4; k++) lambda_out[k] = lambda.coord(k).v;
+}
 // Poseidon2 permutation of 16 words (KAT: crates/prover/tests/poseidon2.rs:14-34)
 void orc_poseidon2_permute(uint32_t* state) {
   M31 s[16];

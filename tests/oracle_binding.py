@@ -135,6 +135,32 @@ def _attach_prover(cls):
             raise RuntimeError(err(self))
         return out.reshape(ncols.value, 1 << log.value)
 
+    def component_interaction(self, view, cid, rel_words, n_cols, log):
+        setup(self)
+        out = np.zeros(n_cols << log, dtype=np.uint32)
+        cs = np.zeros(4, dtype=np.uint32)
+        r = np.ascontiguousarray(rel_words, dtype=np.uint32)
+        rc = self.L.orc_component_interaction(view, C.c_int(cid), _p(r), _p(out), C.c_uint64(out.size), _p(cs))
+        if rc:
+            raise RuntimeError(err(self))
+        return out.reshape(n_cols, 1 << log), cs
+
+    def component_constraints(self, view, cid, rel_words, coeff_words, log):
+        setup(self)
+        out = np.zeros(4 << (log + 1), dtype=np.uint32)
+        r = np.ascontiguousarray(rel_words, dtype=np.uint32)
+        c = np.ascontiguousarray(coeff_words, dtype=np.uint32)
+        rc = self.L.orc_component_constraints(view, C.c_int(cid), _p(r), _p(c), _p(out))
+        if rc:
+            raise RuntimeError(err(self))
+        return out.reshape(4, -1)
+
+    def fri_decompose(self, f4, log):
+        f = np.ascontiguousarray(np.concatenate(f4), dtype=np.uint32).copy()
+        lam = np.zeros(4, dtype=np.uint32)
+        self.L.orc_fri_decompose(_p(f), C.c_uint32(log), _p(lam))
+        return f.reshape(4, -1), lam
+
     def fold_circle_into_line(self, dst4, src4, log, alpha):
         d = np.ascontiguousarray(np.concatenate(dst4), dtype=np.uint32).copy()
         s = np.ascontiguousarray(np.concatenate(src4), dtype=np.uint32)
@@ -168,6 +194,7 @@ def _attach_prover(cls):
 
     cls.prove, cls.verify, cls.assert_constraints = prove, verify, assert_constraints
     cls.component_trace, cls.poseidon2_permute = component_trace, poseidon2_permute
+    cls.component_interaction, cls.component_constraints, cls.fri_decompose = component_interaction, component_constraints, fri_decompose
     cls.fold_circle_into_line, cls.fold_line, cls.accumulate_quotients = fold_circle_into_line, fold_line, accumulate_quotients
 
 

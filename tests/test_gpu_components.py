@@ -1,0 +1,125 @@
+"""Per-component AIR ops of the C ABI (cm_trace_write, cm_histogram, cm_preprocessed_column,
+cm_interaction_write, cm_constraints_accumulate, cm_fri_decompose) against the oracle's per-component functions:
+trace columns, multiplicity columns, LogUp interaction columns + claimed sum, and the constraint-quotient accumulator
+must be bit-identical for every component of a program that exercises felt, u32, bitwise and range-check opcodes."""
+import numpy as np
+import pytest
+
+from cairo_m_amd.lib import N_COMPONENTS, N_PREPROCESSED, PREPROCESSED_LOG, RELATION_WORDS, synth_fibonacci, vm_run
+
+pytestmark = pytest.mark.gpu
+P = 2**31 - 1
+C_POSEIDON2, C_RC8, C_RC16, C_RC20, C_BITWISE = 29, 30, 31, 32, 33
+
+
+def _relations(rng):
+    """cm_relations words: z[8][4] then alpha_pow[8][16][4] (any field elements exercise the kernels)."""
+    return rng.integers(0, P, size=RELATION_WORDS, dtype=np.uint32)
+
+
+def _lde(backend, cols, log, tw):
+    """trace-domain columns -> columns on CanonicCoset(log + 1) through the PolyOps ABI; returns (coeff handles reused, lde)."""
+    hs = [backend.upload(c) for c in cols]
+    backend.interpolate(hs, log, tw)
+    out = [backend.col_alloc(2 << log) for _ in cols]
+    backend.evaluate(hs, log, log + 1, tw, out)
+    for h in hs:
+        backend.col_free(h)
+    return out
+
+
+def _inputs():
+    from tests.test_oracle_air import u32_program
+    return [("fibonacci", synth_fibonacci(37)), ("u32", vm_run(u32_program(), entry_pc=0, args=(), n_returns=0))]
+
+
+def test_trace_histogram_interaction_constraints_per_component(backend, oracle):
+    rng = np.random.default_rng(7)
+    tw = backend.twiddles(22)
+    pp_cols = []
+    for k in range(N_PREPROCESSED):
+        h = backend.col_alloc(1 << PREPROCESSED_LOG[k])
+        backend.preprocessed_column(k, h)
+        pp_cols.append(h)
+    pp_host = [backend.download(h, 1 << PREPROCESSED_LOG[k]) for k, h in enumerate(pp_cols)]
+    assert np.array_equal(pp_host[4], np.arange(256, dtype=np.uint32)) and np.array_equal(pp_host[6], np.arange(1 << 20, dtype=np.uint32))
+    a, b = (np.arange(1 << 16) >> 8).astype(np.uint32), (np.arange(1 << 16) & 255).astype(np.uint32)
+    assert np.array_equal(pp_host[3][:3 << 16], np.concatenate([a & b, a | b, a ^ b]))        # bitwise.rs:283-319
+    pp_lde = [_lde(backend, [c], PREPROCESSED_LOG[k], tw)[0] for k, c in enumerate(pp_host)]
+    for name, inp in _inputs():
+        dev = backend.upload_input(inp)
+        mult = [backend.upload(np.zeros(1 << lg, dtype=np.uint32)) for lg in (8, 16, 20, 18)]
+        rel = _relations(rng)
+        live = 0
+        for cid in range(N_COMPONENTS):
+            n_tr, n_it, n_cons = backend.component_info(cid)
+            log = backend.component_log_size(dev, cid)
+            if cid <= C_POSEIDON2:
+                cols = [backend.col_alloc(1 << log) for _ in range(n_tr)]
+                backend.trace_write(dev, cid, cols)
+                if cid < 26:
+                    backend.histogram(cid, cols, log, *mult)
+            else:   # the lookup tables' trace is the multiplicity column accumulated so far (all opcode components are done)
+                cols = [mult[cid - C_RC8]]
+            got = np.stack([backend.download(h, 1 << log) for h in cols])
+            want = oracle.component_trace(inp.view, cid)
+            assert got.shape == want.shape and np.array_equal(got, want), (name, cid, "trace")
+            live += int(got[0].sum() > 0)
+            # LogUp columns + claimed sum
+            out = [backend.col_alloc(1 << log) for _ in range(n_it)]
+            cs = backend.interaction_write(cid, cols, pp_cols, log, rel, out)
+            got_it = np.stack([backend.download(h, 1 << log) for h in out])
+            want_it, want_cs = oracle.component_interaction(inp.view, cid, rel, n_it, log)
+            assert np.array_equal(got_it, want_it), (name, cid, "interaction")
+            assert np.array_equal(cs, want_cs), (name, cid, "claimed sum")
+            # constraint quotients on the evaluation domain (skip poseidon2's 443 columns at the larger size: covered by proofs)
+            if log <= 12:
+                coeff = rng.integers(0, P, size=4 * n_cons, dtype=np.uint32)
+                tr_lde, it_lde = _lde(backend, list(got), log, tw), _lde(backend, list(got_it), log, tw)
+                acc = [backend.upload(np.zeros(2 << log, dtype=np.uint32)) for _ in range(4)]
+                backend.constraints_accumulate(cid, tr_lde, it_lde, pp_lde, log, rel, coeff, cs, acc)
+                got_acc = np.stack([backend.download(h, 2 << log) for h in acc])
+                want_acc = oracle.component_constraints(inp.view, cid, rel, coeff, log)
+                assert np.array_equal(got_acc, want_acc), (name, cid, "constraints")
+                for h in tr_lde + it_lde + acc:
+                    backend.col_free(h)
+            for h in out + (cols if cid <= C_POSEIDON2 else []):
+                backend.col_free(h)
+        assert live >= 8, (name, live)
+        for h in mult:
+            backend.col_free(h)
+        backend.free_input(dev)
+        inp.free()
+    for h in pp_cols + pp_lde:
+        backend.col_free(h)
+    backend.twiddles_free(tw)
+
+
+def test_trace_write_rejects_lookup_table_components(backend):
+    from cairo_m_amd.lib import CmError
+    inp = synth_fibonacci(3)
+    dev = backend.upload_input(inp)
+    h = backend.col_alloc(256)
+    with pytest.raises(CmError):
+        backend.trace_write(dev, C_RC8, [h])
+    with pytest.raises(CmError):
+        backend.component_info(34)
+    backend.col_free(h)
+    backend.free_input(dev)
+    inp.free()
+
+
+@pytest.mark.parametrize("log_n", [1, 5, 12, 17])
+def test_fri_decompose(backend, oracle, log_n):
+    rng = np.random.default_rng(log_n)
+    f = [rng.integers(0, P, size=1 << log_n, dtype=np.uint32) for _ in range(4)]
+    hs = [backend.upload(c) for c in f]
+    lam = backend.fri_decompose(hs, log_n)
+    got = np.stack([backend.download(h, 1 << log_n) for h in hs])
+    want, want_lam = oracle.fri_decompose(f, log_n)
+    assert np.array_equal(lam, want_lam) and np.array_equal(got, want)
+    # g = f - lambda * (+1 | -1): the alternating part of g vanishes (decomposing again gives lambda = 0)
+    lam2 = backend.fri_decompose(hs, log_n)
+    assert not lam2.any()
+    for h in hs:
+        backend.col_free(h)
