@@ -4,6 +4,8 @@
 #include "../../include/cairom_hip.h"
 #include "engine.hpp"
 #include "fri_kernels.hpp"
+#include "air_kernels.hpp"
+#include <vector>
 #include <string>
 #include <algorithm>
 
@@ -65,6 +67,32 @@ __global__ void k_decompose_apply(P4 f, uint32_t log_n, const uint32_t* partial,
 }  // namespace
 
 extern "C" {
+
+// AccumulationOps (Stwo core::air::accumulation): column += other, and the powers of the random coefficient
+int32_t cm_accumulate(const cm_handle dst[4], const cm_handle src[4], uint64_t n, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(n < (1ull << 32), "cm_accumulate: column too long");
+    std::vector<uint32_t*> d(4);
+    std::vector<const uint32_t*> c(4);
+    for (int k = 0; k < 4; k++) { d[k] = P32(dst[k]); c[k] = P32(src[k]); CM_CHECK(d[k] && c[k], "cm_accumulate: null column"); }
+    DevBuf dd = upload(d, S(s)), dc = upload(c, S(s));
+    add_columns(dd.as<uint32_t*>(), dc.as<const uint32_t*>(), 4, (uint32_t)n, S(s));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_generate_secure_powers(const uint32_t felt[4], uint64_t n, uint32_t* out) {
+  return guard([&] {
+    QM31 f = QM31::from_u32(felt), cur(M31(1));
+    for (uint64_t i = 0; i < n; i++) { cur.to_u32(out + 4 * i); cur = cur * f; }
+  });
+}
+int32_t cm_col_zero(cm_handle h, uint64_t n_u32, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(h, "cm_col_zero: null column");
+    CM_HIP(hipMemsetAsync(P32(h), 0, n_u32 * 4, S(s)));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
 
 // FriOps::decompose (Stwo core::fri; CPU backend: lambda = (sum first half - sum second half) / n on the bit-reversed
 // evaluation, g = f -/+ lambda).  Not on the prove_cairo_m path (every committed column is inside the FFT space), kept

@@ -523,3 +523,23 @@ Backend.preprocessed_column = _b_preprocessed_column
 Backend.interaction_write = _b_interaction_write
 Backend.constraints_accumulate = _b_constraints_accumulate
 Backend.fri_decompose = _b_fri_decompose
+
+
+def _b_accumulate(self, dst4, src4, n):
+    self._ck(self.L.cm_accumulate(self._harr(dst4), self._harr(src4), C.c_uint64(n), C.c_uint64(0)))
+
+
+def _b_secure_powers(self, felt, n):
+    f = np.ascontiguousarray(felt, dtype=np.uint32)
+    out = np.zeros(4 * n, dtype=np.uint32)
+    self._ck(self.L.cm_generate_secure_powers(_p(f), C.c_uint64(n), _p(out)))
+    return out.reshape(n, 4)
+
+
+def _b_col_zero(self, h, n):
+    self._ck(self.L.cm_col_zero(C.c_uint64(h), C.c_uint64(n), C.c_uint64(0)))
+
+
+Backend.accumulate = _b_accumulate
+Backend.secure_powers = _b_secure_powers
+Backend.col_zero = _b_col_zero

@@ -306,6 +306,11 @@ int32_t cm_constraints_accumulate(int32_t component, const cm_handle* trace_lde,
                                   const cm_handle* preprocessed_lde, uint32_t log_size, const cm_relations* relations,
                                   const uint32_t* coeff_powers, const uint32_t claimed_sum[4], const cm_handle acc[4],
                                   cm_stream_t s);
+/* AccumulationOps::accumulate: dst[k][i] += src[k][i] (4 coordinate columns of n words); generate_secure_powers:
+ * out[i] = felt^i for i < n (host array of 4 * n words).  Column::zeros = cm_col_alloc + cm_col_zero. */
+int32_t cm_accumulate(const cm_handle dst[4], const cm_handle src[4], uint64_t n, cm_stream_t s);
+int32_t cm_generate_secure_powers(const uint32_t felt[4], uint64_t n, uint32_t* out);
+int32_t cm_col_zero(cm_handle h, uint64_t n_u32, cm_stream_t s);
 /* FriOps::decompose: lambda = (sum of the first half - sum of the second half) / 2^log_n of a bit-reversed secure
  * evaluation; g = f - lambda on the first half, f + lambda on the second.  In place; lambda_out = 4 words. */
 int32_t cm_fri_decompose(const cm_handle f[4], uint32_t log_n, uint32_t lambda_out[4], cm_stream_t s);

@@ -123,3 +123,25 @@ def test_fri_decompose(backend, oracle, log_n):
     assert not lam2.any()
     for h in hs:
         backend.col_free(h)
+
+
+def test_accumulation_ops(backend, oracle):
+    """AccumulationOps::accumulate (column += other) and generate_secure_powers; Column::zeros."""
+    rng = np.random.default_rng(11)
+    n = 5000
+    a = [rng.integers(0, P, size=n, dtype=np.uint32) for _ in range(4)]
+    b = [rng.integers(0, P, size=n, dtype=np.uint32) for _ in range(4)]
+    ha, hb = [backend.upload(c) for c in a], [backend.upload(c) for c in b]
+    backend.accumulate(ha, hb, n)
+    for k in range(4):
+        want = ((a[k].astype(np.uint64) + b[k]) % P).astype(np.uint32)
+        assert np.array_equal(backend.download(ha[k], n), want)
+    backend.col_zero(ha[0], n)
+    assert not backend.download(ha[0], n).any()
+    felt = rng.integers(1, P, size=4, dtype=np.uint32)
+    pw = backend.secure_powers(felt, 9)
+    assert list(pw[0]) == [1, 0, 0, 0] and np.array_equal(pw[1], felt)
+    for i in range(2, 9):
+        assert np.array_equal(pw[i], oracle.qm31_mul(pw[i - 1], felt).reshape(-1)[:4])
+    for h in ha + hb:
+        backend.col_free(h)
