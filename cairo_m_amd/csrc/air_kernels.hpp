@@ -33,6 +33,12 @@ void launch_hist(int cid, const uint32_t* const* d_cols, uint32_t log_size, cons
 void launch_logup(int cid, const uint32_t* const* d_cols, const uint32_t* const* d_pp, uint32_t log_size,
                   const DevRelations* d_rels, uint32_t* const* d_out, hipStream_t st);
 void launch_constraints(int cid, const ConstraintArgs& a, hipStream_t st);
+// Every small component of a phase in ONE launch (blockIdx.y = job): see k_logup_small in kernels_air.inc
+struct SmallLogupJob { const uint32_t* const* cols; uint32_t* const* out; uint32_t log_size; int cid; };
+constexpr uint32_t SMALL_COMPONENT_MAX_LOG = 8;
+void launch_logup_small(const SmallLogupJob* d_jobs, uint32_t n_jobs, uint32_t max_log, const uint32_t* const* d_pp,
+                        const DevRelations* d_rels, hipStream_t st);
+void launch_constraints_small(const ConstraintArgs* d_jobs, const int* d_cids, uint32_t n_jobs, uint32_t max_log, hipStream_t st);
 // LogupTraceGenerator::finalize_last for every component at once
 struct LogupTailJob {
   uint32_t* col[4];     // last 4 interaction columns (trace domain, bit-reversed circle order)

@@ -291,6 +291,9 @@ static uint32_t fri_tail_log() {
   return v;
 }
 
+// CM_NO_SMALL_BATCH=1: one launch per small component again (A/B of the batched small-component kernels)
+static bool no_small_batch() { static const bool v = getenv("CM_NO_SMALL_BATCH") != nullptr; return v; }
+
 // Twiddle tables depend only on the domain size: built once per size and kept (like the code objects).
 static Twiddles* cached_twiddles(uint32_t R, hipStream_t st) {
   static std::mutex mu;
@@ -532,16 +535,29 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   {
     DevBuf d_sums(air::N_COMPONENTS * 16);
     std::vector<LogupTailJob> jobs(air::N_COMPONENTS);
+    // small components (idle opcode components = 16 padding rows, the tiny builtins): ONE launch for all of them
+    std::vector<SmallLogupJob> small_jobs;
+    uint32_t small_max_log = 0;
+    for (int c = 0; c < air::N_COMPONENTS; c++)
+      if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) {
+        small_jobs.push_back(SmallLogupJob{(const uint32_t* const*)tr_evals.dev(tr0[c]), it_evals.dev(it0[c]), clog[c], c});
+        small_max_log = std::max(small_max_log, clog[c]);
+      }
+    DevBuf d_small = upload(small_jobs, st);
     KProfRegion kreg("k_logup(region)", st);
     Fork fk(st);
+    int spos = 0;
     for (int pos = 0; pos < air::N_COMPONENTS; pos++) {   // large components first (see trace generation)
       const int c = by_size_all[pos];
       const air::ComponentInfo& info = air::component_info(c);
-      launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
-                   drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(pos));
       for (int k = 0; k < 4; k++) jobs[c].col[k] = it_evals.ptrs[it0[c] + info.n_interaction - 4 + k];
       jobs[c].log_size = clog[c];
+      if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
+      launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
+                   drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos++));
     }
+    launch_logup_small(d_small.as<SmallLogupJob>(), (uint32_t)small_jobs.size(), small_max_log, (const uint32_t* const*)pp_evals.dev(),
+                       drel.as<DevRelations>(), fk.stream(spos));
     fk.join();
     kreg.close();
     logup_finalize_all(jobs, d_sums.u32(), st);
@@ -634,27 +650,22 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
         for (uint32_t k = 0; k < 4 * g.n; k++) slot_tab[g.tab0 + k] = slots.u32() + g.off_words + ((size_t)k << g.el);
       d_slot_tab = upload(slot_tab, st);
     }
-    KProfRegion kreg("k_constraints(region)", st);
-    Fork fk(st);
-    int gi = 0, small_rr = 0;
-    // large groups first (descending size) so the long kernels start early
-    for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it, ++gi) {
+    // arguments of every component first: the small ones (<= 2^SMALL_COMPONENT_MAX_LOG rows) go to ONE batched launch
+    // whose argument array has to be uploaded before the fork
+    std::vector<ConstraintArgs> cargs(air::N_COMPONENTS);
+    std::vector<ConstraintArgs> small_args;
+    std::vector<int> small_cids;
+    uint32_t small_max_log = 0;
+    for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it) {
       for (int c : it->second) {
         const air::ComponentInfo& info = air::component_info(c);
-        ConstraintArgs a;
+        ConstraintArgs& a = cargs[c];
         a.tr = (const uint32_t* const*)P.trees[1].lde.dev(tr0[c]);
         a.it = (const uint32_t* const*)P.trees[2].lde.dev(it0[c]);
         a.pp = (const uint32_t* const*)P.trees[0].lde.dev();
         a.rels = drel.as<DevRelations>();
         a.coeff = d_powers.u32() + 4 * coff[c];
-        hipStream_t sc;
-        if (slot_of[c] >= 0) {
-          a.acc = d_slot_tab.as<uint32_t*>() + 4 * slot_of[c];
-          sc = fk.stream(4 + (small_rr++ % 4));
-        } else {
-          a.acc = accs.at(it->first).dev();
-          sc = fk.stream(gi % 4);
-        }
+        a.acc = slot_of[c] >= 0 ? d_slot_tab.as<uint32_t*>() + 4 * slot_of[c] : accs.at(it->first).dev();
         a.log_size = clog[c];
         a.n_base = info.n_base_constraints;
         (pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]))).to_u32(a.cumsum_shift);
@@ -662,9 +673,28 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
           CPoint<M31> p = point_at_index(domain_index_at(clog[c] + 1, k));
           a.denom_inv[k] = inv(coset_vanishing_canonic<M31>(clog[c], p)).v;
         }
-        launch_constraints(c, a, sc);
+        // a small component either owns a private slot or is alone in its size group: no accumulator is shared inside the batch
+        if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch() && (slot_of[c] >= 0 || it->second.size() == 1)) {
+          small_args.push_back(a);
+          small_cids.push_back(c);
+          small_max_log = std::max(small_max_log, clog[c]);
+        }
       }
     }
+    DevBuf d_small_args = upload(small_args, st), d_small_cids = upload(small_cids, st);
+    KProfRegion kreg("k_constraints(region)", st);
+    Fork fk(st);
+    int gi = 0, small_rr = 0;
+    // large groups first (descending size) so the long kernels start early
+    for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it, ++gi) {
+      for (int c : it->second) {
+        if (std::find(small_cids.begin(), small_cids.end(), c) != small_cids.end()) continue;
+        hipStream_t sc = slot_of[c] >= 0 ? fk.stream(4 + (small_rr++ % 3)) : fk.stream(gi % 4);
+        launch_constraints(c, cargs[c], sc);
+      }
+    }
+    launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
+                             fk.stream(7));
     fk.join();
     kreg.close();
     for (auto& g : sgroups) sum_slots(accs.at(g.el).dev(), slots.u32() + g.off_words, g.n, g.el, st);
