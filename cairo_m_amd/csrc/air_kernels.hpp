@@ -38,6 +38,9 @@ struct SmallLogupJob { const uint32_t* const* cols; uint32_t* const* out; uint32
 constexpr uint32_t SMALL_COMPONENT_MAX_LOG = 8;
 void launch_logup_small(const SmallLogupJob* d_jobs, uint32_t n_jobs, uint32_t max_log, const uint32_t* const* d_pp,
                         const DevRelations* d_rels, hipStream_t st);
+// trace rows + histogram of the small opcode components (<= 256 rows each), one block per job
+struct SmallTraceJob { const void* bundles; uint32_t n; uint32_t* const* cols; uint32_t log_size; int cid; };
+void launch_trace_hist_small(const SmallTraceJob* d_jobs, uint32_t n_jobs, const void* acc, const HistPtrs& h, hipStream_t st);
 void launch_constraints_small(const ConstraintArgs* d_jobs, const int* d_cids, uint32_t n_jobs, uint32_t max_log, hipStream_t st);
 // LogupTraceGenerator::finalize_last for every component at once
 struct LogupTailJob {

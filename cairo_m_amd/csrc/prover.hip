@@ -475,17 +475,26 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       CM_HIP(hipMemsetAsync(h.rc20, 0, 4u << 20, st));
       CM_HIP(hipMemsetAsync(h.bitwise, 0, 4u << 18, st));
     }
+    // small opcode components (idle ones are 16 padding rows): trace + histogram of all of them in ONE launch
+    std::vector<SmallTraceJob> small_trace;
+    for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++)
+      if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch())
+        small_trace.push_back(SmallTraceJob{din.bundles[c].p, (uint32_t)in.n_bundles[c], tr_evals.dev(tr0[c]), clog[c], c});
+    DevBuf d_small_trace = upload(small_trace, st);
     // components are independent: fork over side streams (trace then histogram of one component stay ordered)
     KProfRegion kreg("k_trace_gen(region)", st);
     Fork fk(st);
     // large components first: their kernels keep the GPU busy while the host issues the ~40 launches of the idle
     // ones (the host launch rate, not the GPU, bounds this region otherwise); histogram adds commute
+    int spos = 0;
     for (int pos = 0; pos < air::N_OPCODE_COMPONENTS; pos++) {
       const int c = by_size[pos];
-      hipStream_t sc = fk.stream(pos);
+      if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
+      hipStream_t sc = fk.stream(spos++);
       launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
       launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, sc);
     }
+    launch_trace_hist_small(d_small_trace.as<SmallTraceJob>(), (uint32_t)small_trace.size(), din.data_accesses.p, h, fk.stream(spos));
     launch_memory_trace(din.init_mem.p, (uint32_t)in.n_initial_memory, din.fin_mem.p, (uint32_t)in.n_final_memory, in.initial_root,
                         in.final_root, clog[air::C_MEMORY], tr_evals.dev(tr0[air::C_MEMORY]), fk.stream(air::C_MEMORY));
     launch_merkle_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree, in.initial_root,
