@@ -893,6 +893,9 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     ht.mark("quotients: coefficient math");
     DevBuf d_blob = upload(qblob, st);
     const uint8_t* base = d_blob.as<uint8_t>();
+    // one kernel per size group, independent outputs: the small groups (latency-bound, ~140 us in a row) overlap the large
+    Fork fkq(st);
+    int qk = 0;
     for (auto& g : qg) {
       QuotientArgs a;
       a.tw = view(*P.tw); a.log_size = g.log;
@@ -902,10 +905,11 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       a.coef_c = (const uint32_t*)(base + g.o_cc);
       a.batches = (const QuotientBatch*)(base + g.o_qb);
       a.n_batches = (uint32_t)g.batches.size();
-      launch_quotients(a, (double)g.cols.size(), st);
+      launch_quotients(a, (double)g.cols.size(), fkq.stream(qk++));
       q_logs.push_back(g.log);
       quotients.push_back(std::move(g.out));
     }
+    fkq.join();
   }
   P.tick("quotients");
   ht.mark("quotients: gpu done");
