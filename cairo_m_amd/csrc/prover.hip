@@ -222,12 +222,23 @@ struct Prover {
   // IFFT src(evals, trace domain) -> tree.coeffs; LDE -> tree.lde; Merkle; mix root.
   // If `in_place`, coeffs aliases src (src is consumed).
   void commit(CommittedTree& t, ColumnSet* evals, bool from_coeffs) {
+    commit_enqueue(t, evals, from_coeffs, st);
+    commit_finish(t);
+  }
+  // the root comes back on the prover stream (which has joined the stream the tree was built on) and goes into the transcript
+  void commit_finish(CommittedTree& t) {
+    t.merkle.root(t.root.data(), st);
+    ch.mix_root(t.root);
+  }
+  // everything of a commitment except the root read-back, on stream `s` (tree 0 is built on a side stream while the
+  // execution trace is generated: both are chains of small launches)
+  void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s) {
     const std::vector<uint32_t> logs = from_coeffs ? t.coeffs.logs : evals->logs;
     UploadBatch ub;
-    if (!from_coeffs) { t.coeffs.alloc(logs, st, false); ub.add(t.coeffs.ptrs, &t.coeffs.d_view); }
+    if (!from_coeffs) { t.coeffs.alloc(logs, s, false); ub.add(t.coeffs.ptrs, &t.coeffs.d_view); }
     std::vector<uint32_t> lde_logs(logs);
     for (auto& l : lde_logs) l += cfg.log_blowup_factor;
-    t.lde.alloc(lde_logs, st, false);
+    t.lde.alloc(lde_logs, s, false);
     ub.add(t.lde.ptrs, &t.lde.d_view);
     // pointer table of all size groups of the tree: [src | coeffs | lde] per group
     struct Grp { uint32_t log, n; size_t off; };
@@ -245,17 +256,15 @@ struct Prover {
     std::vector<const uint32_t*> cols(t.lde.ptrs.begin(), t.lde.ptrs.end());
     t.merkle.prepare(cols, t.lde.logs);
     ub.add(t.merkle.cols, &t.merkle.d_cols_view);
-    t.tables = ub.flush(st);   // ONE host->device copy for the whole tree
+    t.tables = ub.flush(s);   // ONE host->device copy for the whole tree
     for (auto& g : grps) {
       const uint32_t* const* dsrc = d_table + g.off;
       uint32_t* const* dco = (uint32_t* const*)(d_table + g.off + g.n);
       uint32_t* const* dld = (uint32_t* const*)(d_table + g.off + 2 * g.n);
-      if (!from_coeffs) interpolate_oop(dsrc, dco, g.n, g.log, *tw, st);
-      evaluate((const uint32_t* const*)dco, dld, g.n, g.log, g.log + cfg.log_blowup_factor, *tw, st);
+      if (!from_coeffs) interpolate_oop(dsrc, dco, g.n, g.log, *tw, s);
+      evaluate((const uint32_t* const*)dco, dld, g.n, g.log, g.log + cfg.log_blowup_factor, *tw, s);
     }
-    t.merkle.commit_prepared(st);
-    t.merkle.root(t.root.data(), st);
-    ch.mix_root(t.root);
+    t.merkle.commit_prepared(s);
   }
 };
 
@@ -431,6 +440,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
 
   // ---- tree 0: preprocessed trace (prover.rs:70-73) ----
   ColumnSet pp_evals;
+  std::unique_ptr<Fork> pp_fork;
   if (pp_cache_enabled() && tl_pp_cache.valid && tl_pp_cache.log_blowup == cfg.log_blowup_factor) {
     P.trees[0] = std::move(tl_pp_cache.tree);  // both handed back at the end of the proof
     pp_evals = std::move(tl_pp_cache.evals);
@@ -440,7 +450,10 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     std::vector<uint32_t> logs(air::PREPROC_LOG, air::PREPROC_LOG + air::N_PREPROC);
     pp_evals.alloc(logs, st);
     for (int i = 0; i < air::N_PREPROC; i++) launch_preproc(i, logs[i], pp_evals.ptrs[i], st);
-    P.commit(P.trees[0], &pp_evals, false);
+    // tree 0 is built on a side stream while the execution trace is generated (both are chains of small launches);
+    // its root comes back together with the root of tree 1
+    pp_fork.reset(new Fork(st));
+    P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
   }
   ht.mark("preprocessed enqueued");
   P.tick("preprocessed");
@@ -509,8 +522,14 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     CM_HIP(hipMemcpyAsync(flag_host, flag.p, 4, hipMemcpyDeviceToHost, st));
   }
   P.tick("trace_gen");
+  P.commit_enqueue(P.trees[1], &tr_evals, false, st);
+  if (pp_fork) pp_fork->join();   // tree 0 (a chain of ~30 small launches) has been running next to all of the above
+  // ONE round trip: root of tree 0 (when it was built in this proof), root of tree 1, the range-check flag
+  if (pp_fork) CM_HIP(hipMemcpyAsync(P.trees[0].root.data(), P.trees[0].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, st));
+  P.trees[1].merkle.root(P.trees[1].root.data(), st);
+  if (pp_fork) ch.mix_root(P.trees[0].root);   // transcript order (prover.rs:70-82): root 0, claim, root 1
   for (int c = 0; c < air::N_COMPONENTS; c++) { pf.claim_log_sizes.push_back(clog[c]); ch.mix_u64(clog[c]); }
-  P.commit(P.trees[1], &tr_evals, false);   // synchronises on the root
+  ch.mix_root(P.trees[1].root);
   CM_CHECK(flag_host[0] == 0, "trace generation: a range-check / bitwise lookup value is out of range");
   P.tick("trace_commit");
 
