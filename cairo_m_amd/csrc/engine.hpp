@@ -142,7 +142,11 @@ struct DevBuf {
 // Device->host results land in a per-thread pinned buffer: truly asynchronous (pool.hip).  Valid after the stream is
 // synchronised and until the next call on this thread.
 const void* stage_download_async(const void* src, size_t bytes, hipStream_t st);
-uint32_t* pinned_words();   // 64 pinned words per host thread (deferred single-word checks)
+// 1024 pinned words per host thread; fixed slots (words): 0 range-check flag, 2-3 grind nonce, 8-15 Merkle root,
+// 16-23 root of tree 0, 32-175 claimed sums, 256-351 FRI challenges, 384-575 FRI roots, 640-1023 last FRI layer
+uint32_t* pinned_words();
+enum PinnedSlot : uint32_t { PIN_FLAG = 0, PIN_NONCE = 2, PIN_ROOT = 8, PIN_ROOT0 = 16, PIN_SUMS = 32, PIN_ALPHAS = 256, PIN_ROOTS = 384,
+                            PIN_LAST_LAYER = 640, PIN_WORDS = 1024 };
 // Small host->device uploads (pointer arrays, coefficients, positions) go through a pinned staging ring
 // and hipMemcpyAsync on the launch stream: no host sync, no pageable-copy stall.
 template <class T>

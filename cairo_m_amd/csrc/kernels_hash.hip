@@ -8,6 +8,7 @@
 // cols[c][i], so a wave's 64 lanes read 256 contiguous bytes per column (coalesced); column
 // pointers are wave-uniform (scalar loads).  Hash framing: state = 0; optional F(state, left||right);
 // then one F per 16 column words (zero padded); t = f = 0 (see DESIGN.md "Merkle node framing").
+#include <string.h>
 #include "field.hpp"
 #include "device_common.hpp"
 #include "engine.hpp"
@@ -19,12 +20,12 @@ namespace cm {
 
 // Proof of work: smallest nonce in [base, base + n) with trailing_zeros(F(digest, [lo,hi,0..])[0..16B]) >= bits.
 // result initialised to ~0ull; atomicMin keeps the smallest hit.
-__global__ void __launch_bounds__(256) k_grind(const uint32_t* __restrict__ digest, uint32_t bits, uint64_t base,
-                                               unsigned long long* result) {
+struct GrindDigest { uint32_t w[8]; };   // the channel digest travels as a kernel argument: no host->device copy
+__global__ void __launch_bounds__(256) k_grind(GrindDigest digest, uint32_t bits, uint64_t base, unsigned long long* result) {
   const uint64_t nonce = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t h[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) h[k] = digest[k];
+  for (int k = 0; k < 8; k++) h[k] = digest.w[k];
   uint32_t m[16] = {0};
   m[0] = (uint32_t)nonce;
   m[1] = (uint32_t)(nonce >> 32);
@@ -97,20 +98,19 @@ void merkle_tail(const MerkleTailArgs& a, hipStream_t st) {
   CM_HIP(hipGetLastError());
 }
 uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st) {
-  DevBuf d_digest(32), d_res(8);
-  CM_HIP(hipMemcpyAsync(d_digest.p, digest, 32, hipMemcpyHostToDevice, st));
+  DevBuf d_res(8);
+  GrindDigest dg;
+  memcpy(dg.w, digest, 32);
+  unsigned long long* res = (unsigned long long*)(pinned_words() + PIN_NONCE);   // pinned: a truly asynchronous 8-byte read-back
   // expected nonce ~ 2^bits: start with 8x that and grow, instead of always hashing 2^22 candidates
   uint64_t batch = 1ull << (bits + 3 < 12 ? 12 : (bits + 3 > 22 ? 22 : bits + 3));
   for (uint64_t base = 0;; base += batch, batch = batch < (1ull << 22) ? batch * 2 : batch) {
-    unsigned long long init = ~0ull;
-    CM_HIP(hipMemcpyAsync(d_res.p, &init, 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_grind, dim3(batch / 256), dim3(256), 0, st, d_digest.u32(), bits, base,
-                       (unsigned long long*)d_res.p);
+    CM_HIP(hipMemsetAsync(d_res.p, 0xFF, 8, st));   // ~0ull: atomicMin keeps the smallest nonce
+    hipLaunchKernelGGL(k_grind, dim3(batch / 256), dim3(256), 0, st, dg, bits, base, (unsigned long long*)d_res.p);
     CM_HIP(hipGetLastError());
-    unsigned long long res;
-    CM_HIP(hipMemcpyAsync(&res, d_res.p, 8, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(res, d_res.p, 8, hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
-    if (res != ~0ull) return res;
+    if (*res != ~0ull) return *res;
     CM_CHECK(base < (1ull << 40), "grind: no nonce found");
   }
 }

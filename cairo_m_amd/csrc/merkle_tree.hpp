@@ -167,8 +167,10 @@ struct MerkleTree {
     }
   }
   void root(uint8_t out[32], hipStream_t st) const {
-    CM_HIP(hipMemcpyAsync(out, layers[0].p, 32, hipMemcpyDeviceToHost, st));
+    uint32_t* pin = pinned_words() + PIN_ROOT;
+    CM_HIP(hipMemcpyAsync(pin, layers[0].p, 32, hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
+    memcpy(out, pin, 32);
   }
 
   // Symbolic decommitment walk (Stwo MerkleProver::decommit).  queries_per_log_size: log -> sorted unique positions.

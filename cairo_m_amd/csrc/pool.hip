@@ -113,10 +113,11 @@ const void* stage_download_async(const void* src, size_t bytes, hipStream_t st) 
   return l.base;
 }
 
-// 64 pinned words per host thread for single-word results whose check is deferred to the next natural sync
+// 1024 pinned words per host thread for the small fixed-slot results of a proof (flag, nonce, roots, claimed sums,
+// FRI challenges): copies into pageable memory block the caller and cost 15-25 us each
 uint32_t* pinned_words() {
   static thread_local uint32_t* p = nullptr;
-  if (!p) CM_HIP(hipHostMalloc((void**)&p, 256, hipHostMallocDefault));
+  if (!p) CM_HIP(hipHostMalloc((void**)&p, 4096, hipHostMallocDefault));
   return p;
 }
 

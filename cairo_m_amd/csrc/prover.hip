@@ -525,8 +525,9 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   P.commit_enqueue(P.trees[1], &tr_evals, false, st);
   if (pp_fork) pp_fork->join();   // tree 0 (a chain of ~30 small launches) has been running next to all of the above
   // ONE round trip: root of tree 0 (when it was built in this proof), root of tree 1, the range-check flag
-  if (pp_fork) CM_HIP(hipMemcpyAsync(P.trees[0].root.data(), P.trees[0].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, st));
+  if (pp_fork) CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT0, P.trees[0].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, st));
   P.trees[1].merkle.root(P.trees[1].root.data(), st);
+  if (pp_fork) memcpy(P.trees[0].root.data(), pinned_words() + PIN_ROOT0, 32);
   if (pp_fork) ch.mix_root(P.trees[0].root);   // transcript order (prover.rs:70-82): root 0, claim, root 1
   for (int c = 0; c < air::N_COMPONENTS; c++) { pf.claim_log_sizes.push_back(clog[c]); ch.mix_u64(clog[c]); }
   ch.mix_root(P.trees[1].root);
@@ -589,8 +590,9 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     fk.join();
     kreg.close();
     logup_finalize_all(jobs, d_sums.u32(), st);
-    uint32_t sums[air::N_COMPONENTS * 4];
-    CM_HIP(hipMemcpyAsync(sums, d_sums.p, sizeof(sums), hipMemcpyDeviceToHost, st));
+    static_assert(PIN_SUMS + air::N_COMPONENTS * 4 <= PIN_ALPHAS, "pinned slot layout");
+    const uint32_t* sums = pinned_words() + PIN_SUMS;
+    CM_HIP(hipMemcpyAsync((void*)sums, d_sums.p, air::N_COMPONENTS * 16, hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
     for (int c = 0; c < air::N_COMPONENTS; c++) pf.claimed_sums.push_back(QM31::from_u32(sums + 4 * c));
   }
@@ -1076,12 +1078,23 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     std::vector<uint32_t> pos(n);
     for (uint32_t i = 0; i < n; i++) pos[i] = i;
     std::vector<QM31> vals;
-    std::vector<uint32_t> h_alphas((size_t)(n_inner + 1) * 4), h_roots((size_t)(n_inner + 1) * 8);
-    CM_HIP(hipMemcpyAsync(h_alphas.data(), d_alphas.p, h_alphas.size() * 4, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync(h_roots.data(), d_roots.p, h_roots.size() * 4, hipMemcpyDeviceToHost, st));
-    {
-      ht.mark("decommit: queries drawn");
-    GatherBatch gb;
+    // challenges, roots and the last layer come back in ONE round trip (pinned slots; a large last layer falls back to the
+    // batched gather)
+    CM_CHECK((n_inner + 1) * 4 <= PIN_ROOTS - PIN_ALPHAS && (n_inner + 1) * 8 <= PIN_LAST_LAYER - PIN_ROOTS, "fri: too many layers");
+    const uint32_t* h_alphas = pinned_words() + PIN_ALPHAS;
+    const uint32_t* h_roots = pinned_words() + PIN_ROOTS;
+    CM_HIP(hipMemcpyAsync((void*)h_alphas, d_alphas.p, (size_t)(n_inner + 1) * 16, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync((void*)h_roots, d_roots.p, (size_t)(n_inner + 1) * 32, hipMemcpyDeviceToHost, st));
+    if (4 * n <= PIN_WORDS - PIN_LAST_LAYER) {
+      uint32_t* ll = pinned_words() + PIN_LAST_LAYER;
+      for (int k = 0; k < 4; k++) CM_HIP(hipMemcpyAsync(ll + k * n, c4[k], n * 4, hipMemcpyDeviceToHost, st));
+      CM_HIP(hipStreamSynchronize(st));
+      for (uint32_t i = 0; i < n; i++) {
+        uint32_t w4[4] = {ll[i], ll[n + i], ll[2 * n + i], ll[3 * n + i]};
+        vals.push_back(QM31::from_u32(w4));
+      }
+    } else {
+      GatherBatch gb;
       QGather g = plan_gather_q(c4, pos, gb);
       gb.run(st);  // synchronises the stream: roots / challenges are on the host now
       finish_gather_q(g, gb, vals);
