@@ -499,15 +499,17 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     Fork fk(st);
     // large components first: their kernels keep the GPU busy while the host issues the ~40 launches of the idle
     // ones (the host launch rate, not the GPU, bounds this region otherwise); histogram adds commute
+    // the batched small components first: ~100 us of pure latency on a handful of CUs, hidden under the large kernels
+    // (launched last it ran alone at the end of the region)
+    launch_trace_hist_small(d_small_trace.as<SmallTraceJob>(), (uint32_t)small_trace.size(), din.data_accesses.p, h, fk.stream(Fork::N - 2));
     int spos = 0;
     for (int pos = 0; pos < air::N_OPCODE_COMPONENTS; pos++) {
       const int c = by_size[pos];
       if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
-      hipStream_t sc = fk.stream(spos++);
+      hipStream_t sc = fk.stream(spos++ % (Fork::N - 2));
       launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
       launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, sc);
     }
-    launch_trace_hist_small(d_small_trace.as<SmallTraceJob>(), (uint32_t)small_trace.size(), din.data_accesses.p, h, fk.stream(spos));
     launch_memory_trace(din.init_mem.p, (uint32_t)in.n_initial_memory, din.fin_mem.p, (uint32_t)in.n_final_memory, in.initial_root,
                         in.final_root, clog[air::C_MEMORY], tr_evals.dev(tr0[air::C_MEMORY]), fk.stream(air::C_MEMORY));
     launch_merkle_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree, in.initial_root,
@@ -575,6 +577,8 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     DevBuf d_small = upload(small_jobs, st);
     KProfRegion kreg("k_logup(region)", st);
     Fork fk(st);
+    launch_logup_small(d_small.as<SmallLogupJob>(), (uint32_t)small_jobs.size(), small_max_log, (const uint32_t* const*)pp_evals.dev(),
+                       drel.as<DevRelations>(), fk.stream(Fork::N - 1));   // first: latency-bound, hidden under the large kernels
     int spos = 0;
     for (int pos = 0; pos < air::N_COMPONENTS; pos++) {   // large components first (see trace generation)
       const int c = by_size_all[pos];
@@ -583,10 +587,8 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       jobs[c].log_size = clog[c];
       if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
       launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
-                   drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos++));
+                   drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos++ % (Fork::N - 1)));
     }
-    launch_logup_small(d_small.as<SmallLogupJob>(), (uint32_t)small_jobs.size(), small_max_log, (const uint32_t* const*)pp_evals.dev(),
-                       drel.as<DevRelations>(), fk.stream(spos));
     fk.join();
     kreg.close();
     logup_finalize_all(jobs, d_sums.u32(), st);
@@ -714,6 +716,8 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     DevBuf d_small_args = upload(small_args, st), d_small_cids = upload(small_cids, st);
     KProfRegion kreg("k_constraints(region)", st);
     Fork fk(st);
+    launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
+                             fk.stream(7));   // first: latency-bound, hidden under the large kernels
     int gi = 0, small_rr = 0;
     // large groups first (descending size) so the long kernels start early
     for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it, ++gi) {
@@ -723,8 +727,6 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
         launch_constraints(c, cargs[c], sc);
       }
     }
-    launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
-                             fk.stream(7));
     fk.join();
     kreg.close();
     for (auto& g : sgroups) sum_slots(accs.at(g.el).dev(), slots.u32() + g.off_words, g.n, g.el, st);
