@@ -615,25 +615,17 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       DevBuf d_table = upload(table, st);
       for (auto& g : grps) interpolate(d_table.as<uint32_t*>() + g.off, g.n, g.log, *P.tw, st);
     }
-    P.commit(t, nullptr, true);
+    P.commit_enqueue(t, nullptr, true, st);
   }
   tr_evals.buf.release();
-  P.tick("interaction_commit");
-  for (int t = 0; t < 3; t++) for (auto l : P.trees[t].coeffs.logs) pf.cells += 1ull << l;
-
-  // ---- stwo prove: composition polynomial ----
-  QM31 random_coeff = ch.draw_felt();
+  // ---- stwo prove: composition polynomial.  Everything that does not depend on the random coefficient (accumulators,
+  // slots, per-component arguments, their uploads and memsets) is prepared and enqueued here, behind the tree-2 kernels;
+  // the root is read back, the coefficient drawn and its powers uploaded right before the launches. ----
   size_t total_constraints = 0;
   std::vector<size_t> coff(air::N_COMPONENTS);
   for (int c = 0; c < air::N_COMPONENTS; c++) { coff[c] = total_constraints; total_constraints += air::component_info(c).n_constraints; }
   std::vector<QM31> powers(total_constraints);
-  {
-    QM31 cur(M31(1));
-    for (size_t g = total_constraints; g-- > 0;) { powers[g] = cur; cur = cur * random_coeff; }
-  }
-  std::vector<uint32_t> powers_w(4 * total_constraints);
-  for (size_t g = 0; g < total_constraints; g++) powers[g].to_u32(&powers_w[4 * g]);
-  DevBuf d_powers = upload(powers_w, st);
+  DevBuf d_powers(16 * total_constraints);
   // accumulators: 4 columns per evaluation log.  The top size gets its own ColumnSet (it becomes the coefficient
   // set of tree 3), all smaller sizes share one — two pointer-table uploads and two memsets instead of one pair
   // per size.
@@ -714,6 +706,17 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       }
     }
     DevBuf d_small_args = upload(small_args, st), d_small_cids = upload(small_cids, st);
+    P.commit_finish(P.trees[2]);
+    P.tick("interaction_commit");
+    for (int t = 0; t < 3; t++) for (auto l : P.trees[t].coeffs.logs) pf.cells += 1ull << l;
+    {
+      QM31 random_coeff = ch.draw_felt();
+      QM31 cur(M31(1));
+      for (size_t g = total_constraints; g-- > 0;) { powers[g] = cur; cur = cur * random_coeff; }
+      std::vector<uint32_t> powers_w(4 * total_constraints);
+      for (size_t g = 0; g < total_constraints; g++) powers[g].to_u32(&powers_w[4 * g]);
+      stage_upload(d_powers.p, powers_w.data(), powers_w.size() * 4, st);
+    }
     KProfRegion kreg("k_constraints(region)", st);
     Fork fk(st);
     launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
@@ -748,8 +751,43 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     for (auto& kv : accs)
       if (kv.first != comp_log) add_columns(acc_top.dev(), (const uint32_t* const*)kv.second.dev(), 4, 1u << kv.first, st);
     t.coeffs = std::move(acc_top);
-    P.commit(t, nullptr, true);
+    P.commit_enqueue(t, nullptr, true, st);
   }
+  // Sampling jobs = (log size, point): every column at the OODS point, plus the previous-row mask
+  // (oods - trace_step(log)) of each component's last LogUp column group.  All jobs share one pointer-table
+  // upload, one scratch buffer and ONE device->host copy of the results.  Everything but the points themselves is
+  // built (and uploaded) here, while tree 3 is being committed; the points follow once its root is in the transcript.
+  struct ORef { int t; uint32_t c; bool prev; };
+  struct OJob { uint32_t log; bool prev; CPoint<QM31> pt; std::vector<ORef> refs; size_t off = 0, out_off = 0; };
+  std::vector<OJob> ojobs;
+  {
+    std::map<uint32_t, std::vector<ORef>> groups;
+    for (int t = 0; t < 4; t++)
+      for (uint32_t c = 0; c < P.trees[t].coeffs.size(); c++) groups[P.trees[t].coeffs.logs[c]].push_back({t, c, false});
+    for (auto& kv : groups) ojobs.push_back(OJob{kv.first, false, {}, kv.second});
+    std::map<uint32_t, std::vector<ORef>> pgroups;
+    for (int c = 0; c < air::N_COMPONENTS; c++) {
+      int ni = air::component_info(c).n_interaction;
+      for (int k = ni - 4; k < ni; k++) pgroups[clog[c]].push_back({2, (uint32_t)(it0[c] + k), true});
+    }
+    for (auto& kv : pgroups) ojobs.push_back(OJob{kv.first, true, {}, kv.second});
+  }
+  size_t n_oods_out = 0;
+  DevBuf d_oods_table, d_oods_out;
+  {
+    std::vector<const uint32_t*> table;
+    for (auto& j : ojobs) {
+      j.off = table.size();
+      j.out_off = n_oods_out;
+      for (auto& r : j.refs) table.push_back(P.trees[r.t].coeffs.ptrs[r.c]);
+      n_oods_out += j.refs.size();
+    }
+    d_oods_table = upload(table, st);
+    d_oods_out.alloc(n_oods_out * 16);
+  }
+  pf.sampled_values.resize(4);
+  for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
+  P.commit_finish(P.trees[3]);
   P.tick("composition_commit");
 
   // host side of compute_fri_quotients for every size group, packed into ONE upload:
@@ -779,51 +817,24 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     oods.y = (t + t) * iv;
   }
   ht.mark("oods: point drawn");
-  pf.sampled_values.resize(4);
-  for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
-  ht.mark("oods: sampled_values resized");
-  // Sampling jobs = (log size, point): every column at the OODS point, plus the previous-row mask
-  // (oods - trace_step(log)) of each component's last LogUp column group.  All jobs share one pointer-table
-  // upload, one scratch buffer and ONE device->host copy of the results.
   std::map<uint32_t, CPoint<QM31>> prev_points;
   {
-    struct Ref { int t; uint32_t c; bool prev; };
-    struct Job { uint32_t log; CPoint<QM31> pt; std::vector<Ref> refs; size_t off = 0, out_off = 0; };
-    std::vector<Job> jobs;
-    {
-      std::map<uint32_t, std::vector<Ref>> groups;
-      for (int t = 0; t < 4; t++)
-        for (uint32_t c = 0; c < P.trees[t].coeffs.size(); c++) groups[P.trees[t].coeffs.logs[c]].push_back({t, c, false});
-      for (auto& kv : groups) jobs.push_back(Job{kv.first, oods, kv.second});
-      std::map<uint32_t, std::vector<Ref>> pgroups;
-      for (int c = 0; c < air::N_COMPONENTS; c++) {
-        int ni = air::component_info(c).n_interaction;
-        for (int k = ni - 4; k < ni; k++) pgroups[clog[c]].push_back({2, (uint32_t)(it0[c] + k), true});
-      }
-      for (auto& kv : pgroups) {
-        CPoint<M31> step = point_at_index(subgroup_gen_index(kv.first));
-        CPoint<QM31> neg{QM31(step.x), QM31(-step.y)};
-        CPoint<QM31> pt = cadd(oods, neg);
-        prev_points[kv.first] = pt;
-        jobs.push_back(Job{kv.first, pt, kv.second});
-      }
-    }
-    ht.mark("oods: jobs built");
-    std::vector<const uint32_t*> table;
-    size_t n_out = 0;
-    for (auto& j : jobs) {
-      j.off = table.size();
-      j.out_off = n_out;
-      for (auto& r : j.refs) table.push_back(P.trees[r.t].coeffs.ptrs[r.c]);
-      n_out += j.refs.size();
-    }
-    DevBuf d_table = upload(table, st), dout(n_out * 16);
-    ht.mark("oods: table uploaded");
+    std::vector<OJob>& jobs = ojobs;
+    const size_t n_out = n_oods_out;
+    DevBuf& dout = d_oods_out;
     {
       std::vector<EapJob> ej;
-      for (auto& j : jobs)
-        ej.push_back(EapJob{j.log, (uint32_t)j.refs.size(), d_table.as<const uint32_t*>() + j.off, j.pt.x, j.pt.y,
+      for (auto& j : jobs) {
+        j.pt = oods;
+        if (j.prev) {
+          CPoint<M31> step = point_at_index(subgroup_gen_index(j.log));
+          CPoint<QM31> neg{QM31(step.x), QM31(-step.y)};
+          j.pt = cadd(oods, neg);
+          prev_points[j.log] = j.pt;
+        }
+        ej.push_back(EapJob{j.log, (uint32_t)j.refs.size(), d_oods_table.as<const uint32_t*>() + j.off, j.pt.x, j.pt.y,
                             dout.u32() + 4 * j.out_off});
+      }
       eval_at_point_multi(ej, st);
     }
     const uint32_t* w = (const uint32_t*)stage_download_async(dout.p, n_out * 16, st);   // read after the sync below
