@@ -928,6 +928,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     DevBuf d_blob = upload(qblob, st);
     const uint8_t* base = d_blob.as<uint8_t>();
     // one kernel per size group, independent outputs: the small groups (latency-bound, ~140 us in a row) overlap the large
+    KProfRegion kregq("k_quotients", st);   // concurrent launches: timed as one interval
     Fork fkq(st);
     int qk = 0;
     for (auto& g : qg) {
@@ -944,6 +945,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       quotients.push_back(std::move(g.out));
     }
     fkq.join();
+    kregq.close();
   }
   P.tick("quotients");
   ht.mark("quotients: gpu done");
