@@ -68,6 +68,20 @@ struct MerkleMultiArgs {
   uint32_t* layers[MERKLE_MULTI_LEVELS];       // output buffer of level lv
 };
 void merkle_multi(const MerkleMultiArgs& a, double alg_bytes, hipStream_t st);
+// The whole top of a tree — layers 2^top_log (9 <= top_log <= MERKLE_TOP_MAX_LOG) down to the root — in ONE launch:
+// every block reduces 256 nodes of layer top_log to one node of layer top_log - 8, the last block to finish (ticket)
+// hashes the remaining <= 256 nodes up to the root.  Replaces 2-3 k_merkle_multi launches + k_merkle_tail.
+constexpr uint32_t MERKLE_TOP_MAX_LOG = 16;
+struct MerkleTopArgs {
+  uint32_t top_log;
+  const uint32_t* prev;                          // hashes of layer top_log + 1, or null
+  const uint32_t* const* cols;                   // device array of all (sorted) column pointers of the tree
+  uint32_t col_begin[MERKLE_TOP_MAX_LOG + 1];    // column range of layer l in `cols`
+  uint32_t col_end[MERKLE_TOP_MAX_LOG + 1];
+  uint32_t* layers[MERKLE_TOP_MAX_LOG + 1];      // output buffer of layer l
+  uint32_t* ticket;                              // zero on entry; the last block leaves it zero again
+};
+void merkle_top(MerkleTopArgs& a, hipStream_t st);   // fills a.ticket
 // device-side transcript step of the FRI commit phase: chan = {digest[8], n_sent} (9 u32);
 // chan <- mix_root(root); felt_out[4] <- draw_felt(); root_log[8] <- root (read back once at the end)
 void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log, hipStream_t st);

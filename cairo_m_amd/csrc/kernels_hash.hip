@@ -92,6 +92,25 @@ void gather_runs(const RowRun* d_runs, uint32_t n_runs, uint32_t* d_out, hipStre
   hipLaunchKernelGGL(k_gather_runs, dim3(n_runs), dim3(64), 0, st, d_runs, d_out);
   CM_HIP(hipGetLastError());
 }
+// ticket counters of k_merkle_top: a zeroed ring per host thread (trees can be in flight on several streams of one
+// prover thread; every launch leaves its counter at zero again)
+static uint32_t* next_ticket() {
+  static thread_local uint32_t* ring = nullptr;
+  static thread_local uint32_t pos = 0;
+  constexpr uint32_t N = 256;
+  if (!ring) {
+    CM_HIP(hipMalloc((void**)&ring, N * 4));
+    CM_HIP(hipMemset(ring, 0, N * 4));
+  }
+  return ring + (pos++ % N);
+}
+void merkle_top(MerkleTopArgs& a, hipStream_t st) {
+  CM_CHECK(a.top_log >= 9 && a.top_log <= MERKLE_TOP_MAX_LOG, "merkle_top: bad layer range");
+  a.ticket = next_ticket();
+  KProfScope kp("k_merkle_top", 0.0, st);
+  hipLaunchKernelGGL(k_merkle_top, dim3(1u << (a.top_log - 8)), dim3(256), 0, st, a);
+  CM_HIP(hipGetLastError());
+}
 void merkle_tail(const MerkleTailArgs& a, hipStream_t st) {
   KProfScope kp("k_merkle_tail", 0.0, st);
   hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(1024), 0, st, a);

@@ -173,6 +173,123 @@ __global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
   }
 }
 
+// Layers 2^top_log .. 2^0 in one launch (see MerkleTopArgs).  Phase 1: 9 levels per block (256 nodes -> 1), one node
+// per lane while >= 128 nodes are active, one node per quad of lanes below (half the dependent latency).  Phase 2: the
+// block that draws the last ticket reads the 2^(top_log-8) nodes the blocks produced and finishes like k_merkle_tail.
+__device__ __forceinline__ void merkle_node_thread(const uint32_t* children, const uint32_t* const* __restrict__ cols, uint32_t c_begin,
+                                                   uint32_t c_end, uint32_t i, uint32_t (&h)[8]) {
+  uint32_t m[16];
+  if (children) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = children[k];
+    b2s_compress(h, m);
+  }
+  uint32_t c0 = c_begin;
+  for (; c0 + 16 <= c_end; c0 += 16) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = cols[c0 + k][i];
+    b2s_compress(h, m);
+  }
+  if (c0 < c_end) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? cols[c0 + k][i] : 0u;
+    b2s_compress(h, m);
+  }
+}
+__device__ __forceinline__ void merkle_node_quad(const uint32_t* children, const uint32_t* const* __restrict__ cols, uint32_t c_begin,
+                                                 uint32_t c_end, uint32_t i, uint32_t q, uint32_t& h0, uint32_t& h1) {
+  uint32_t m[16];
+  if (children) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = children[k];
+    b2s_compress_quad(h0, h1, m, q);
+  }
+  uint32_t c0 = c_begin;
+  for (; c0 + 16 <= c_end; c0 += 16) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = cols[c0 + k][i];
+    b2s_compress_quad(h0, h1, m, q);
+  }
+  if (c0 < c_end) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? cols[c0 + k][i] : 0u;
+    b2s_compress_quad(h0, h1, m, q);
+  }
+}
+__global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
+  __shared__ uint32_t bufA[256 * 8];
+  __shared__ uint32_t bufB[128 * 8];
+  __shared__ uint32_t s_last;
+  uint32_t* buf[2];
+  buf[0] = bufA;
+  buf[1] = bufB;
+  const uint32_t tid = threadIdx.x;
+  int cur = 0;
+  // ---- phase 1: layers top_log .. top_log - 8 of this block's 256-node slice ----
+  uint32_t active = 256;
+#pragma unroll 1
+  for (uint32_t lv = 0; lv <= 8; lv++, active >>= 1) {
+    const uint32_t l = a.top_log - lv;
+    const uint32_t node0 = blockIdx.x * active;
+    const uint32_t c_begin = a.col_begin[l], c_end = a.col_end[l];
+    if (active >= 128) {
+      if (tid < active) {
+        const uint32_t i = node0 + tid;
+        uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t* ch = lv > 0 ? buf[cur ^ 1] + tid * 16 : (a.prev ? a.prev + (size_t)i * 16 : nullptr);
+        merkle_node_thread(ch, a.cols, c_begin, c_end, i, h);
+        uint4* o = reinterpret_cast<uint4*>(a.layers[l] + (size_t)i * 8);
+        o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) buf[cur][tid * 8 + k] = h[k];
+      }
+    } else {
+      const uint32_t node = tid >> 2, q = tid & 3u;
+      if (node < active) {
+        const uint32_t i = node0 + node;
+        uint32_t h0 = 0, h1 = 0;
+        merkle_node_quad(buf[cur ^ 1] + node * 16, a.cols, c_begin, c_end, i, q, h0, h1);
+        uint32_t* o = a.layers[l] + (size_t)i * 8;
+        o[q] = h0; o[4 + q] = h1;
+        buf[cur][node * 8 + q] = h0; buf[cur][node * 8 + 4 + q] = h1;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- ticket: the last block to arrive owns the rest of the tree ----
+  __threadfence();   // every lane's part of this block's layer (top_log - 8) node is visible device-wide ...
+  __syncthreads();   // ... before lane 0 draws the ticket
+  if (tid == 0) {
+    const uint32_t t = atomicAdd(a.ticket, 1u);
+    s_last = (t == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();   // acquire: the other blocks' nodes
+  if (tid == 0) *a.ticket = 0;   // ready for the next launch that uses this counter
+  // ---- phase 2: layers top_log - 9 .. 0, one node per quad of lanes (<= 128 nodes) ----
+  const int base_log = (int)a.top_log - 8;   // layer of gridDim.x nodes, in HBM
+  const uint32_t node = tid >> 2, q = tid & 3u;
+  cur = 0;
+  for (int l = base_log - 1; l >= 0; l--) {
+    const uint32_t n = 1u << l;
+    // 256 threads = 64 quads: loop when the layer has more nodes
+    for (uint32_t nd = node; nd < n; nd += 64) {
+      const bool from_global = (l == base_log - 1);
+      const uint32_t* ch = from_global ? a.layers[base_log] + (size_t)nd * 16 : buf[cur ^ 1] + nd * 16;
+      uint32_t h0 = 0, h1 = 0;
+      merkle_node_quad(ch, a.cols, a.col_begin[l], a.col_end[l], nd, q, h0, h1);
+      uint32_t* o = a.layers[l] + (size_t)nd * 8;
+      o[q] = h0; o[4 + q] = h1;
+      buf[cur][nd * 8 + q] = h0; buf[cur][nd * 8 + 4 + q] = h1;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 // One layer, one node per quad of lanes: for mid-size layers that carry hundreds of columns (poseidon2: 443
 // columns at 2^10 rows) the chain length per node dominates, not the node count.
 __global__ void __launch_bounds__(256) k_merkle_layer_quad(uint32_t log_size, const uint32_t* __restrict__ prev,

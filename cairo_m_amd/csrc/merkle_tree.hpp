@@ -102,7 +102,34 @@ struct MerkleTree {
     layers.resize(max_log + 1);
     size_t ci = 0;
     const int tail_top = (int)std::min<uint32_t>(max_log, MERKLE_TAIL_LOG);
+    static const bool use_top = getenv("CM_NO_MERKLE_TOP") == nullptr;   // A/B switch
     for (int log = (int)max_log; log > tail_top;) {
+      // the whole top of the tree in one launch once no wide layer is left among the per-lane levels
+      if (use_top && log <= (int)MERKLE_TOP_MAX_LOG && log >= 9) {
+        bool wide_inside = false;
+        size_t cj = ci;
+        for (int l = log; l >= log - 8; l--) {
+          size_t cnt = 0;
+          while (cj + cnt < cols.size() && col_logs[cj + cnt] == (uint32_t)l) cnt++;
+          if (cnt >= MERKLE_QUAD_MIN_COLS) wide_inside = true;
+          cj += cnt;
+        }
+        if (!wide_inside) {
+          MerkleTopArgs a;
+          a.top_log = (uint32_t)log;
+          a.prev = (log < (int)max_log) ? layers[log + 1].u32() : nullptr;
+          a.cols = dcols();
+          for (int l = log; l >= 0; l--) {
+            a.col_begin[l] = (uint32_t)ci;
+            while (ci < cols.size() && col_logs[ci] == (uint32_t)l) ci++;
+            a.col_end[l] = (uint32_t)ci;
+            layers[l].alloc((size_t)32 << l);
+            a.layers[l] = layers[l].u32();
+          }
+          merkle_top(a, st);
+          return;
+        }
+      }
       // group of up to MERKLE_MULTI_LEVELS layers per launch (the top layer of a group needs >= 256 nodes)
       int levels = std::min<int>((int)MERKLE_MULTI_LEVELS, log - tail_top);
       if (log < 8) levels = 1;
