@@ -71,7 +71,11 @@ def test_eval_at_point_parity(backend, oracle, log_n):
         backend.col_free(h)
 
 
-@pytest.mark.parametrize("logs", [[6, 6, 6], [8] * 17 + [5] * 3 + [3], [10] * 40 + [9] * 16 + [4] * 5, [1], [12, 3]])
+@pytest.mark.parametrize("logs", [[6, 6, 6], [8] * 17 + [5] * 3 + [3], [10] * 40 + [9] * 16 + [4] * 5, [1], [12, 3],
+                                  # k_merkle_top: multi-block ticket (2^16 = 256 blocks), columns entering at phase-1 and
+                                  # phase-2 levels, single-layer kernels above; a wide layer (70 columns) forces the old path
+                                  [17] * 3 + [16] * 2 + [13] * 5 + [9] * 2 + [7] * 20 + [5] * 3 + [2], [16] * 4, [9] * 33,
+                                  [15] * 2 + [11] * 70 + [6] * 3])
 def test_merkle_commit_parity(backend, oracle, logs):
     rng = np.random.default_rng(len(logs))
     cols = [rng.integers(0, P, size=1 << l, dtype=np.uint32) for l in logs]
