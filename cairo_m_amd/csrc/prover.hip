@@ -441,6 +441,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   // ---- tree 0: preprocessed trace (prover.rs:70-73) ----
   ColumnSet pp_evals;
   std::unique_ptr<Fork> pp_fork;
+  bool build_tree0 = false;
   if (pp_cache_enabled() && tl_pp_cache.valid && tl_pp_cache.log_blowup == cfg.log_blowup_factor) {
     P.trees[0] = std::move(tl_pp_cache.tree);  // both handed back at the end of the proof
     pp_evals = std::move(tl_pp_cache.evals);
@@ -450,10 +451,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     std::vector<uint32_t> logs(air::PREPROC_LOG, air::PREPROC_LOG + air::N_PREPROC);
     pp_evals.alloc(logs, st);
     for (int i = 0; i < air::N_PREPROC; i++) launch_preproc(i, logs[i], pp_evals.ptrs[i], st);
-    // tree 0 is built on a side stream while the execution trace is generated (both are chains of small launches);
-    // its root comes back together with the root of tree 1
-    pp_fork.reset(new Fork(st));
-    P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
+    build_tree0 = true;   // enqueued on a side stream right after the trace-generation launches (below)
   }
   ht.mark("preprocessed enqueued");
   P.tick("preprocessed");
@@ -522,6 +520,13 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     kreg.close();
     flag_host[0] = 0xffffffffu;
     CM_HIP(hipMemcpyAsync(flag_host, flag.p, 4, hipMemcpyDeviceToHost, st));
+  }
+  if (build_tree0) {
+    // tree 0 (a chain of ~30 small launches) is built on a side stream while the transforms and hashes of tree 1 keep
+    // the GPU busy; its root comes back together with the root of tree 1.  Forked from the stream position after the
+    // trace-generation launches so that its chain does not queue in front of them.
+    pp_fork.reset(new Fork(st));
+    P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
   }
   P.tick("trace_gen");
   P.commit_enqueue(P.trees[1], &tr_evals, false, st);
