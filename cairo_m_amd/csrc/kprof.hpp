@@ -20,7 +20,17 @@ struct KProf {
   std::vector<Rec> recs;
   std::map<std::string, Agg> agg;
   std::map<std::string, uint64_t> region_calls;  // extra launches inside timed regions
+  std::vector<hipEvent_t> free_events;           // recycled: creating / destroying two events per launch cost ~5 us
   static KProf& get() { static KProf k; return k; }
+  hipEvent_t new_event() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
   void flush() {  // resolve pending event pairs (caller has synchronised the stream/device)
     std::lock_guard<std::mutex> lk(mu);
     for (auto& r : recs) {
@@ -29,8 +39,8 @@ struct KProf {
         Agg& g = agg[r.name];
         g.calls++; g.ms += ms; g.bytes += r.bytes; g.work += r.work;
       }
-      (void)hipEventDestroy(r.a);
-      (void)hipEventDestroy(r.b);
+      free_events.push_back(r.a);
+      free_events.push_back(r.b);
     }
     recs.clear();
     for (auto& kv : region_calls) agg[kv.first].calls += kv.second;
@@ -56,8 +66,8 @@ struct KProfRegion {
     active = k.on && (k.only.empty() || k.only == nm);
     kprof_current_region() = this;
     if (!active) return;
-    (void)hipEventCreate(&a);
-    (void)hipEventCreate(&b);
+    a = KProf::get().new_event();
+    b = KProf::get().new_event();
     (void)hipEventRecord(a, st);
   }
   // call after the join, on the main stream
@@ -85,8 +95,8 @@ struct KProfScope {
     active = k.on && (k.only.empty() || k.only == name);
     if (!active) return;
     r.name = name; r.bytes = bytes; r.work = work;
-    (void)hipEventCreate(&r.a);
-    (void)hipEventCreate(&r.b);
+    r.a = k.new_event();
+    r.b = k.new_event();
     (void)hipEventRecord(r.a, st);
   }
   ~KProfScope() {
