@@ -35,13 +35,41 @@ __device__ __forceinline__ EmptyEF operator+(EmptyEF, EmptyEF) { return {}; }
 
 struct HistPtrs { uint32_t *rc8, *rc16, *rc20, *bitwise; uint32_t* error_flag; };
 constexpr uint32_t HIST_SMALL = 2048;  // per-block LDS bins for the small range-check values
+// Values outside the small bins go through a block-private tagged cache (direct-mapped, key = table | index) before
+// they touch HBM.  Random keys miss and fall through to a global atomic — those are cheap (27 G/s, tools/atomic_lab.hip)
+// — but a HOT key (a constant limb of the program, a frequent bitwise operand pair) would otherwise be one global
+// atomic per wave on ONE address, and same-address atomics serialise at ~11 ns each on this part (0.09 G/s).
+constexpr uint32_t HIST_CACHE_LOG = 11, HIST_CACHE = 1u << HIST_CACHE_LOG;
+constexpr uint32_t HIST_BINS = 2 * HIST_SMALL + 256;           // [rc20 small][rc16 small][rc8]
+constexpr uint32_t HIST_LDS_WORDS = HIST_BINS + 2 * HIST_CACHE;  // + [tags][counts]
+constexpr uint32_t HIST_EMPTY = 0xffffffffu;
+__device__ __forceinline__ void hist_lds_init(uint32_t* lds) {
+  for (uint32_t i = threadIdx.x; i < HIST_LDS_WORDS; i += blockDim.x) lds[i] = (i >= HIST_BINS && i < HIST_BINS + HIST_CACHE) ? HIST_EMPTY : 0u;
+  __syncthreads();
+}
+__device__ __forceinline__ void hist_lds_flush(const uint32_t* lds, const HistPtrs& h) {
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < HIST_BINS; i += blockDim.x) {
+    uint32_t c = lds[i];
+    if (!c) continue;
+    if (i < HIST_SMALL) atomicAdd(h.rc20 + i, c);
+    else if (i < 2 * HIST_SMALL) atomicAdd(h.rc16 + (i - HIST_SMALL), c);
+    else atomicAdd(h.rc8 + (i - 2 * HIST_SMALL), c);
+  }
+  for (uint32_t i = threadIdx.x; i < HIST_CACHE; i += blockDim.x) {
+    const uint32_t key = lds[HIST_BINS + i];
+    if (key == HIST_EMPTY) continue;
+    uint32_t* t = (key >> 20) == 0 ? h.rc16 : (key >> 20) == 1 ? h.rc20 : h.bitwise;
+    atomicAdd(t + (key & 0xfffffu), lds[HIST_BINS + HIST_CACHE + i]);
+  }
+}
 
 struct HistEval : air::LogupStream<HistEval, M31, EmptyEF> {
   const uint32_t* const* cols;
   uint32_t row;
   int ci = 0;
   HistPtrs h;
-  uint32_t* lds;  // [rc20: HIST_SMALL][rc16: HIST_SMALL][rc8: 256] block-private bins
+  uint32_t* lds;  // [rc20: HIST_SMALL][rc16: HIST_SMALL][rc8: 256][cache tags][cache counts], block-private
   __device__ M31 next() { return M31(cols[ci++][row]); }
   __device__ M31 preproc(int) { return M31(); }
   __device__ M31 c(uint32_t v) { return M31(v); }
@@ -51,7 +79,16 @@ struct HistEval : air::LogupStream<HistEval, M31, EmptyEF> {
   // Lookup values are heavily repeated inside a wave (e.g. clock deltas of a loop body), so plain
   // per-lane atomics serialise on a handful of addresses.  Wave-aggregate first: up to 4 rounds of
   // "leader value -> ballot of equal lanes -> one atomicAdd(popcount)", then per-lane atomics for the rest.
-  __device__ void bump(uint32_t* t, uint32_t idx, uint32_t size) {
+  // n occurrences of (table, idx): block-private cache first, HBM on a tag conflict
+  __device__ void add_count(uint32_t* t, uint32_t table_id, uint32_t idx, uint32_t n) {
+    const uint32_t key = (table_id << 20) | idx;
+    const uint32_t slot = (key * 2654435761u) >> (32 - HIST_CACHE_LOG);
+    uint32_t* tags = lds + HIST_BINS;
+    const uint32_t old = atomicCAS(tags + slot, HIST_EMPTY, key);
+    if (old == HIST_EMPTY || old == key) atomicAdd(tags + HIST_CACHE + slot, n);
+    else atomicAdd(t + idx, n);
+  }
+  __device__ void bump(uint32_t* t, uint32_t table_id, uint32_t idx, uint32_t size) {
     if (idx >= size) { atomicOr(h.error_flag, 1u); return; }
     bool pending = true;
 #pragma unroll 1
@@ -62,21 +99,21 @@ struct HistEval : air::LogupStream<HistEval, M31, EmptyEF> {
       uint32_t lv = (uint32_t)__shfl((int)idx, leader, 64);
       unsigned long long same = __ballot(pending && idx == lv);
       if (pending && idx == lv) {
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(t + idx, (uint32_t)__popcll(same));
+        if ((int)(threadIdx.x & 63) == leader) add_count(t, table_id, idx, (uint32_t)__popcll(same));
         pending = false;
       }
     }
-    if (pending) atomicAdd(t + idx, 1u);
+    if (pending) add_count(t, table_id, idx, 1u);
   }
   __device__ void on_entry(int rel, M31, const M31* v, int) {
     // small values (clock deltas, limbs of small numbers) are counted in block-private LDS bins and
     // flushed once per block; the rest goes to HBM with wave-aggregated atomics
     if (rel == air::REL_RC8) { if (v[0].v < 256u) atomicAdd(lds + 2 * HIST_SMALL + v[0].v, 1u); else atomicOr(h.error_flag, 1u); }
-    else if (rel == air::REL_RC16) { if (v[0].v < HIST_SMALL) atomicAdd(lds + HIST_SMALL + v[0].v, 1u); else bump(h.rc16, v[0].v, 1u << 16); }
-    else if (rel == air::REL_RC20) { if (v[0].v < HIST_SMALL) atomicAdd(lds + v[0].v, 1u); else bump(h.rc20, v[0].v, 1u << 20); }
+    else if (rel == air::REL_RC16) { if (v[0].v < HIST_SMALL) atomicAdd(lds + HIST_SMALL + v[0].v, 1u); else bump(h.rc16, 0u, v[0].v, 1u << 16); }
+    else if (rel == air::REL_RC20) { if (v[0].v < HIST_SMALL) atomicAdd(lds + v[0].v, 1u); else bump(h.rc20, 1u, v[0].v, 1u << 20); }
     else if (rel == air::REL_BITWISE) {
       uint32_t ok = (v[0].v < 3u) & (v[1].v < 256u) & (v[2].v < 256u);
-      bump(h.bitwise, ok ? v[0].v * 65536u + (v[1].v << 8) + v[2].v : 0xffffffffu, 1u << 18);
+      bump(h.bitwise, 2u, ok ? v[0].v * 65536u + (v[1].v << 8) + v[2].v : 0xffffffffu, 1u << 18);
     }
   }
   __device__ void emit_batch(bool, EmptyEF, EmptyEF) {}
