@@ -94,19 +94,23 @@ void gather_runs(const RowRun* d_runs, uint32_t n_runs, uint32_t* d_out, hipStre
 }
 // ticket counters of k_merkle_top: a zeroed ring per host thread (trees can be in flight on several streams of one
 // prover thread; every launch leaves its counter at zero again)
-static uint32_t* next_ticket() {
+static uint32_t* next_ticket(hipStream_t st) {
   static thread_local uint32_t* ring = nullptr;
   static thread_local uint32_t pos = 0;
   constexpr uint32_t N = 256;
   if (!ring) {
     CM_HIP(hipMalloc((void**)&ring, N * 4));
-    CM_HIP(hipMemset(ring, 0, N * 4));
+    // hipMemset runs on the NULL stream and may return before it has executed; the prover's streams are non-blocking
+    // (no implicit ordering with the NULL stream), so zero the ring on the launching stream and wait — once per thread.
+    // (Recycled device memory is not zero: with the plain hipMemset a second prover thread drew garbage tickets.)
+    CM_HIP(hipMemsetAsync(ring, 0, N * 4, st));
+    CM_HIP(hipStreamSynchronize(st));
   }
   return ring + (pos++ % N);
 }
 void merkle_top(MerkleTopArgs& a, hipStream_t st) {
   CM_CHECK(a.top_log >= 9 && a.top_log <= MERKLE_TOP_MAX_LOG, "merkle_top: bad layer range");
-  a.ticket = next_ticket();
+  a.ticket = next_ticket(st);
   KProfScope kp("k_merkle_top", 0.0, st);
   hipLaunchKernelGGL(k_merkle_top, dim3(1u << (a.top_log - 8)), dim3(256), 0, st, a);
   CM_HIP(hipGetLastError());

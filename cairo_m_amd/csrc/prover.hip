@@ -85,6 +85,7 @@ DeviceInput* upload_input(const cm_prover_input& in) {
   up(d->init_tree, in.initial_tree, in.n_initial_tree * sizeof(cm_merkle_node));
   up(d->fin_tree, in.final_tree, in.n_final_tree * sizeof(cm_merkle_node));
   d->public_data = make_public_data(in);
+  CM_HIP(hipDeviceSynchronize());   // the copies ran on the NULL stream; the prover's streams are non-blocking
   return d;
 }
 
@@ -112,6 +113,7 @@ DeviceInput* make_device_input(const cm_prover_input& meta, DevBuf (&bundles)[CM
   for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) d->meta.bundles[i] = nullptr;
   d->meta.data_accesses = nullptr; d->meta.initial_memory = nullptr; d->meta.final_memory = nullptr;
   d->meta.clock_updates = nullptr; d->meta.initial_tree = nullptr; d->meta.final_tree = nullptr;
+  CM_HIP(hipDeviceSynchronize());   // NULL-stream copies above; the prover's streams are non-blocking
   return d;
 }
 DeviceInput* adapt_segment_device(const cm_runner_segment& seg);  // adapter_device.hip
