@@ -56,7 +56,16 @@ struct Pool {
 // One pool per host thread: a freed block may still be read by kernels queued on the freeing thread's stream,
 // so it may only be handed to work that is ordered after them, i.e. to the same thread (= same main stream).
 // Concurrent proofs (one host thread each) therefore never exchange blocks.
-Pool& pool() { static thread_local Pool* p = new Pool(); return *p; }
+// The pool object itself is leaked on purpose (DevBufs released by late destructors still find it); the CACHED blocks
+// of a host thread go back to the driver when that thread exits — prover threads that come and go would otherwise pin
+// a few GB of HBM each.
+struct PoolExitGuard { Pool* p = nullptr; ~PoolExitGuard() { if (p) p->trim(); } };
+Pool& pool() {
+  static thread_local Pool* p = new Pool();
+  static thread_local PoolExitGuard guard;
+  guard.p = p;
+  return *p;
+}
 
 struct Stage {
   std::mutex mu;

@@ -23,3 +23,19 @@ for rnd in range(4):
     print('round', rnd, 'ms', round(dt*1e3, 1), 'bad', bad)
 assert bad == 0
 print('stress ok')
+# thread churn: every round starts NEW host threads (fresh thread-local streams, pools, pinned slots, ticket rings) on
+# recycled device memory — a NULL-stream hipMemset of one of those once raced with the non-blocking prover streams
+import threading
+for rnd in range(6):
+    res = {}
+    def work(i, k):
+        p = be.prove_device(devs[k]); res[i] = (k, p.words().copy()); p.free()
+    ks = [int(x) for x in rng.integers(0, len(devs), size=3)]
+    ts = [threading.Thread(target=work, args=(i, k)) for i, k in enumerate(ks)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    for i, (k, w) in res.items():
+        if not np.array_equal(w, alone[k]): bad += 1
+    print('churn round', rnd, 'sizes', ks, 'bad', bad)
+assert bad == 0
+print('thread churn ok')
