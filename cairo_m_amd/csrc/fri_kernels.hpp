@@ -53,5 +53,8 @@ struct FriTailArgs {
   FriTailLayer layers[FRI_TAIL_MAX_LOG + 1];  // indexed by log
 };
 void fri_tail(const FriTailArgs& a, hipStream_t st);
+// fold_line of layer log_n into layer log_n - 1 fused with fold_circle_into_line of the quotient columns of log_n
+void fold_line_and_circle(uint32_t* const out[4], const uint32_t* const src[4], const uint32_t* const circle[4], uint32_t log_n,
+                          const Twiddles& tw, hipStream_t st, const uint32_t* d_alpha, const uint32_t* d_alpha_circle);
 
 }  // namespace cm

@@ -136,6 +136,24 @@ __global__ void __launch_bounds__(256) k_fold_line(Ptr4 out, CPtr4 src, uint32_t
   st4(out.p, i, (f0 + f1) + alpha * ((f0 - f1) * xinv));
 }
 
+// fold_line into the next layer and, in the same pass, fold the quotient columns of that size in:
+// out[i] = fold_line(src)[i] * alpha_c^2 + fold_circle(circle)[i]   (alpha = this layer's challenge, alpha_c = the first one)
+__global__ void __launch_bounds__(256) k_fold_line_circle(Ptr4 out, CPtr4 src, CPtr4 circle, uint32_t log_n, TwiddleView tw,
+                                                          const uint32_t* __restrict__ alpha_dev, const uint32_t* __restrict__ alpha_c_dev) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << (log_n - 1))) return;
+  const QM31 alpha = QM31::from_u32(alpha_dev), ac = QM31::from_u32(alpha_c_dev);
+  uint32_t L = tw.R - (log_n + 1);
+  M31 xinv(tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + i]);
+  QM31 f0 = ld4(src.p, 2 * i), f1 = ld4(src.p, 2 * i + 1);
+  const QM31 line = (f0 + f1) + alpha * ((f0 - f1) * xinv);
+  // circle evaluation of log_n folds onto the line of log_n - 1 (k_fold_circle with its log = log_n)
+  M31 yinv(tw.iytw[(1u << (log_n - 1)) + i]);
+  QM31 g0 = ld4(circle.p, 2 * i), g1 = ld4(circle.p, 2 * i + 1);
+  const QM31 v = (g0 + g1) + ac * ((g0 - g1) * yinv);
+  st4(out.p, i, line * (ac * ac) + v);
+}
+
 __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
   // Tree levels of <= 256 nodes: one node per QUAD of lanes (b2s_compress_quad, ~1.4 us instead of ~2.7 us per
   // dependent compression) with the level being consumed kept in LDS; larger levels: one node per lane through HBM.
@@ -257,6 +275,15 @@ void fold_line(uint32_t* const out[4], const uint32_t* const src[4], uint32_t lo
   uint32_t n = 1u << (log_n - 1);
   hipLaunchKernelGGL(k_fold_line, dim3((n + 255) / 256), dim3(256), 0, st, d, s, log_n, view(tw), alpha.a.a.v, alpha.a.b.v,
                      alpha.b.a.v, alpha.b.b.v, d_alpha);
+  CM_HIP(hipGetLastError());
+}
+void fold_line_and_circle(uint32_t* const out[4], const uint32_t* const src[4], const uint32_t* const circle[4], uint32_t log_n,
+                          const Twiddles& tw, hipStream_t st, const uint32_t* d_alpha, const uint32_t* d_alpha_circle) {
+  CM_CHECK(log_n >= 2 && log_n + 1 <= tw.R, "fold_line_and_circle: bad log size");
+  Ptr4 d; CPtr4 s, c;
+  for (int i = 0; i < 4; i++) { d.p[i] = out[i]; s.p[i] = src[i]; c.p[i] = circle[i]; }
+  uint32_t n = 1u << (log_n - 1);
+  hipLaunchKernelGGL(k_fold_line_circle, dim3((n + 255) / 256), dim3(256), 0, st, d, s, c, log_n, view(tw), d_alpha, d_alpha_circle);
   CM_HIP(hipGetLastError());
 }
 void fri_tail(const FriTailArgs& a, hipStream_t st) {

@@ -1000,10 +1000,8 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
   }
   ColumnSet layer;
-  if (!pre.empty()) {
-    // the first pre-allocated layer is the accumulation target of the circle folds
-    CM_HIP(hipMemsetAsync(pre[0]->eval.buf.p, 0, pre[0]->eval.buf.bytes, st));
-  } else {
+  bool layer_is_blank = !pre.empty();   // pre[0] is written (not accumulated into) by the first circle fold: no memset
+  if (pre.empty()) {
     layer.alloc(std::vector<uint32_t>(4, layer_log), st, false);
     CM_HIP(hipMemsetAsync(layer.buf.p, 0, layer.buf.bytes, st));
   }
@@ -1050,9 +1048,11 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     while (qi < quotients.size() && q_logs[qi] - 1 == layer_log) {
       const uint32_t* src[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
       uint32_t* dst[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
-      fold_circle_into_line(dst, src, q_logs[qi], *P.tw, unused_alpha, true, st, d_alphas.u32());
+      fold_circle_into_line(dst, src, q_logs[qi], *P.tw, unused_alpha, !layer_is_blank, st, d_alphas.u32());
+      layer_is_blank = false;
       qi++;
     }
+    CM_CHECK(!layer_is_blank, "fri: the first layer received no quotient column");
     cur->tree.commit_prepared(st);
     const size_t li = inner.size() + 1;
     chan_mix_root_draw(d_chan.u32(), cur->tree.layers[0].u32(), d_alphas.u32() + 4 * li, d_roots.u32() + 8 * li, st);
@@ -1066,7 +1066,16 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       for (int c = 0; c < 4; c++) dst[c] = layer.ptrs[c];
     }
     const uint32_t* src[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
-    fold_line(dst, src, layer_log, *P.tw, unused_alpha, st, d_alphas.u32() + 4 * li);
+    // the quotient columns of the next layer's size are folded in by the same kernel (the single-launch tail does its own)
+    const bool next_outside_tail = pi + 1 < pre.size();
+    if (next_outside_tail && qi < quotients.size() && q_logs[qi] == layer_log &&
+        !(qi + 1 < quotients.size() && q_logs[qi + 1] == layer_log)) {
+      const uint32_t* circ[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
+      fold_line_and_circle(dst, src, circ, layer_log, *P.tw, st, d_alphas.u32() + 4 * li, d_alphas.u32());
+      qi++;
+    } else {
+      fold_line(dst, src, layer_log, *P.tw, unused_alpha, st, d_alphas.u32() + 4 * li);
+    }
     layer_log--;
     inner.push_back(std::move(pre[pi]));
     pi++;
