@@ -54,5 +54,8 @@ void launch_preproc(int pp_id, uint32_t log_size, uint32_t* d_col, hipStream_t s
 // d_acc[c][i] += sum_s slots[((s * 4 + c) << log_n) + i]   (c < 4, s < n_slots)
 void sum_slots(uint32_t* const* d_acc, const uint32_t* d_slots, uint32_t n_slots, uint32_t log_n, hipStream_t st);
 void add_columns(uint32_t* const* d_dst, const uint32_t* const* d_src, uint32_t ncols, uint32_t n, hipStream_t st);
+// d_dst[c][i] += sum_k (i < 2^log[k] ? src[k][c][i] : 0): every smaller accumulator in one launch
+struct AddColumnsSrc { uint32_t n; uint32_t log[28]; const uint32_t* const* src[28]; };
+void add_columns_multi(uint32_t* const* d_dst, const AddColumnsSrc& s, uint32_t ncols, hipStream_t st);
 
 }  // namespace cm

@@ -755,8 +755,17 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       for (auto it = accs.rbegin(); it != accs.rend(); ++it, ++k) interpolate(it->second.dev(), 4, it->first, *P.tw, fk.stream(k));
       fk.join();
     }
-    for (auto& kv : accs)
-      if (kv.first != comp_log) add_columns(acc_top.dev(), (const uint32_t* const*)kv.second.dev(), 4, 1u << kv.first, st);
+    {
+      AddColumnsSrc as;
+      as.n = 0;
+      for (auto& kv : accs)
+        if (kv.first != comp_log) {
+          CM_CHECK(as.n < 28, "composition: too many accumulator sizes");
+          as.log[as.n] = kv.first;
+          as.src[as.n++] = (const uint32_t* const*)kv.second.dev();
+        }
+      add_columns_multi(acc_top.dev(), as, 4, st);
+    }
     t.coeffs = std::move(acc_top);
     P.commit_enqueue(t, nullptr, true, st);
   }
