@@ -74,7 +74,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--fib-n", type=int, default=FIB_N)
-    ap.add_argument("--cpu-sample-n", type=int, default=250000)
+    ap.add_argument("--cpu-sample-n", type=int, default=FIB_N,
+                    help="fibonacci_loop size the CPU oracle proves for cpu_baseline (default: the bench workload itself, ~14 s on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kprof", action="store_true", help="debug: no in-library HIP-event kernel timing")
     ap.add_argument("--inflight", type=int, default=1,
