@@ -52,14 +52,23 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
   for (uint32_t rr = 0; rr < G::NR; rr++) {
     const uint32_t r = INVERSE ? rr : (G::NR - 1 - rr);
     const uint32_t b = G::b(r), k = G::k(r);
-    // element e of thread t: j = e & (2^k-1) inside the butterfly group, g = e >> k selects the group
-    uint32_t li[8];
+    // element e of thread t: j = e & (2^k-1) inside the butterfly group, g = e >> k selects the group; the 11-k remaining
+    // bits are rho = (t << (3-k)) | g and the local index is ((rho >> b) << (b+k)) | (j << b) | (rho & (2^b - 1)).
+    // The bits of (j, g) and those of t never overlap, so li[e] = li0(t) + c[e] with c[e] a compile-time constant: the
+    // eight tile addresses of a round are ONE computed base plus immediate offsets (the LDS padding i + (i >> 5) splits
+    // the same way because the low five bits cannot carry), and so are the global indices of the contiguous pass.
+    const uint32_t rho0 = t << (3 - k);
+    const uint32_t li0 = ((rho0 >> b) << (b + k)) | (rho0 & ((1u << b) - 1));
+    const uint32_t pli0 = phys(li0);
+    const uint32_t gi0 = gidx(li0);
+    uint32_t c[8];
 #pragma unroll
     for (uint32_t e = 0; e < 8; e++) {
       const uint32_t j = e & ((1u << k) - 1), g = e >> k;
-      const uint32_t rho = (t << (3 - k)) | g;  // the 11-k remaining bits
-      li[e] = ((rho >> b) << (b + k)) | (j << b) | (rho & ((1u << b) - 1));
+      c[e] = ((g >> b) << (b + k)) | (j << b) | (g & ((1u << b) - 1));
     }
+    auto ptile = [&](uint32_t e) -> uint32_t { return pli0 + c[e] + (c[e] >> 5); };
+    auto gel = [&](uint32_t e) -> uint32_t { return gi0 + (((c[e] >> M) << lo) | (c[e] & ((1u << M) - 1))); };
     const bool staged_in = (rr == 0) && INVERSE && M == 0;
     if (rr == 0 && !staged_in) {
       if (padded) {
@@ -67,14 +76,14 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
         // value is replaced by a select, so the 8 loads still issue back to back
 #pragma unroll
         for (uint32_t e = 0; e < 8; e++) {
-          const uint32_t gi = gidx(li[e]);
+          const uint32_t gi = gel(e);
           const bool in = gi < a.in_len;
           const uint32_t x = src[in ? gi : 0u];
           v[e] = M31(in ? x : 0u);
         }
       } else {  // no per-element bounds test: 8 loads issue back to back instead of 8 exec-masked branches
 #pragma unroll
-        for (uint32_t e = 0; e < 8; e++) { const uint32_t gi = gidx(li[e]); __builtin_assume(gi < (1u << 29)); v[e] = M31(src[gi]); }
+        for (uint32_t e = 0; e < 8; e++) { const uint32_t gi = gel(e); __builtin_assume(gi < (1u << 29)); v[e] = M31(src[gi]); }
       }
     } else {
       if (staged_in) {
@@ -90,7 +99,7 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
       }
 #ifndef CM_FFT_ABL_NO_LDS
 #pragma unroll
-      for (uint32_t e = 0; e < 8; e++) v[e] = M31(tile[phys(li[e])]);
+      for (uint32_t e = 0; e < 8; e++) v[e] = M31(tile[ptile(e)]);
 #endif
     }
     // butterflies: k layers on bits [b, b+k).  h(e) = h0 + (j >> (s+1)) with h0 from the j = 0 element of the group
@@ -110,7 +119,7 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
         const uint32_t e1 = e | (1u << s);
         const uint32_t g0 = e & ~((1u << k) - 1);  // j = 0 element of this group
         const uint32_t j = e & ((1u << k) - 1);
-        uint32_t h = (gidx(li[g0]) >> (layer + 1)) + (j >> (s + 1));
+        uint32_t h = (gel(g0) >> (layer + 1)) + (j >> (s + 1));
         __builtin_assume(h < (1u << 29));  // byte offset fits 32 bits: saddr + 32-bit voffset addressing
         // The 64 lanes of a wave differ in 6 consecutive bits of rho = (t << (3-k)) | g, i.e. local index bits below
         // 9 - k; a round on bits [b, b+k) with 9 - k <= b therefore pairs elements whose twiddle index is the same
@@ -133,13 +142,13 @@ __global__ void __launch_bounds__(256) k_fft_pass_r8(FftPassArgs a) {
       for (uint32_t e = 0; e < 8; e++) {
         M31 o = v[e];
         if (INVERSE && a.scale != 1u) o = o * sc;
-        dst[gidx(li[e])] = o.v;
+        dst[gel(e)] = o.v;
       }
     } else {
 #ifndef CM_FFT_ABL_NO_LDS  /* tools/fft_lab: cost of the LDS exchanges (results are wrong) */
       __syncthreads();  // previous round's readers are done with the tile
 #pragma unroll
-      for (uint32_t e = 0; e < 8; e++) tile[phys(li[e])] = v[e].v;
+      for (uint32_t e = 0; e < 8; e++) tile[ptile(e)] = v[e].v;
       __syncthreads();
 #endif
       if (staged_out) {
