@@ -8,6 +8,13 @@
 
 namespace cm {
 
+// Column pointers come out of device tables as generic pointers; the columns live in HBM, so say so: global loads / stores
+// instead of flat ones (flat instructions also occupy the LDS path and its counter).
+typedef const __attribute__((address_space(1))) uint32_t* cm_gptr;
+typedef __attribute__((address_space(1))) uint32_t* cm_gptr_w;
+#define CM_GCOL(p) ((cm::cm_gptr)(p))
+#define CM_GCOL_W(p) ((cm::cm_gptr_w)(p))
+
 // ---- wave64 / block reductions over M31 / QM31 sums -------------------------------------------
 __device__ __forceinline__ M31 wave_reduce_m31(M31 v) {
 #pragma unroll

@@ -6,6 +6,7 @@
 //   DomainEval — FrameworkComponent::evaluate_constraint_quotients_on_domain (hot loop A)
 // Relations / random-coefficient powers are wave-uniform and come through scalar loads.
 #pragma once
+#include "device_common.hpp"
 #include "field.hpp"
 #include "air/components.hpp"
 
@@ -128,8 +129,8 @@ struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
   int ci = 0, batch = 0;
   QM31 prev;
   const uint32_t* trv = nullptr;  // trace cells of this row already in registers (see k_logup)
-  __device__ M31 next() { return trv ? M31(trv[ci++]) : M31(cols[ci++][row]); }
-  __device__ M31 preproc(int id) { return M31(pp[id][row]); }
+  __device__ M31 next() { return trv ? M31(trv[ci++]) : M31(CM_GCOL(cols[ci++])[row]); }
+  __device__ M31 preproc(int id) { return M31(CM_GCOL(pp[id])[row]); }
   __device__ M31 c(uint32_t v) { return M31(v); }
   __device__ void constraint(M31) {}
   __device__ QM31 combine(int r, const M31* v, int n) { return dev_combine(rels, r, v, n); }
@@ -137,10 +138,10 @@ struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
   __device__ void on_entry(int, M31, const M31*, int) {}
   __device__ void emit_batch(bool, QM31 num, QM31 den) {
     QM31 v = prev + num * inv(den);
-    out[4 * batch + 0][row] = v.a.a.v;
-    out[4 * batch + 1][row] = v.a.b.v;
-    out[4 * batch + 2][row] = v.b.a.v;
-    out[4 * batch + 3][row] = v.b.b.v;
+    CM_GCOL_W(out[4 * batch + 0])[row] = v.a.a.v;
+    CM_GCOL_W(out[4 * batch + 1])[row] = v.a.b.v;
+    CM_GCOL_W(out[4 * batch + 2])[row] = v.b.a.v;
+    CM_GCOL_W(out[4 * batch + 3])[row] = v.b.b.v;
     prev = v;
     batch++;
   }
@@ -159,8 +160,8 @@ struct DomainEval : air::LogupStream<DomainEval, M31, QM31> {
   QM31 prev_col, acc;
   QAcc base_acc;  // sum over the add_constraint constraints of rho^k * C_k, accumulated lazily
   const uint32_t* trv = nullptr;  // trace cells of this row already in registers (see k_constraints)
-  __device__ M31 next() { return trv ? M31(trv[ci++]) : M31(tr[ci++][row]); }
-  __device__ M31 preproc(int id) { return M31(pp[id][row]); }
+  __device__ M31 next() { return trv ? M31(trv[ci++]) : M31(CM_GCOL(tr[ci++])[row]); }
+  __device__ M31 preproc(int id) { return M31(CM_GCOL(pp[id])[row]); }
   __device__ M31 c(uint32_t v) { return M31(v); }
   __device__ void constraint(M31 x) { base_acc.add(coeff + 4 * (kb++), x); }
   __device__ QM31 total() const { return acc + base_acc.value(); }
@@ -168,7 +169,7 @@ struct DomainEval : air::LogupStream<DomainEval, M31, QM31> {
   __device__ QM31 combine(int r, const M31* v, int n) { return dev_combine(rels, r, v, n); }
   __device__ QM31 ef_from(M31 m) { return QM31(m); }
   __device__ void on_entry(int, M31, const M31*, int) {}
-  __device__ QM31 mask(uint32_t r) { return QM31(M31(it[ii][r]), M31(it[ii + 1][r]), M31(it[ii + 2][r]), M31(it[ii + 3][r])); }
+  __device__ QM31 mask(uint32_t r) { return QM31(M31(CM_GCOL(it[ii])[r]), M31(CM_GCOL(it[ii + 1])[r]), M31(CM_GCOL(it[ii + 2])[r]), M31(CM_GCOL(it[ii + 3])[r])); }
   __device__ void emit_batch(bool last, QM31 num, QM31 den) {
     if (!last) {
       QM31 cur = mask(row);

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
         for (; k + 8 <= qb.end; k += 8) {
           uint32_t v[8];
 #pragma unroll
-          for (int j = 0; j < 8; j++) v[j] = a.cols[a.col_index[k + j]][row];
+          for (int j = 0; j < 8; j++) v[j] = CM_GCOL(a.cols[a.col_index[k + j]])[row];
 #pragma unroll
           for (int g = 0; g < 2; g++) {
 #pragma unroll
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
         }
         for (; k < qb.end; k++) {
           const uint32_t* c = a.coef_c + 4 * k;
-          const unsigned long long x = a.cols[a.col_index[k]][row];
+          const unsigned long long x = CM_GCOL(a.cols[a.col_index[k]])[row];
           q0 = fold(q0 + x * c[0]); q1 = fold(q1 + x * c[1]); q2 = fold(q2 + x * c[2]); q3 = fold(q3 + x * c[3]);
         }
         num = QM31(M31::reduce(q0), M31::reduce(q1), M31::reduce(q2), M31::reduce(q3));

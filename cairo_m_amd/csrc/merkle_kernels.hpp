@@ -3,6 +3,7 @@
 #pragma once
 #include "blake2s_dev.hpp"
 #include "engine.hpp"
+#include "device_common.hpp"
 
 namespace cm {
 
@@ -18,6 +19,7 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
   const uint32_t n = 1u << log_size;
   const uint32_t blk0 = blockIdx.x * 256;
   const uint32_t i = blk0 + tid;
+  __builtin_assume(i < (1u << 29));  // byte offsets fit 32 bits: scalar column base + 32-bit lane offset addressing
   const bool full_block = blk0 + 256 <= n;
   uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t m[16];
@@ -48,15 +50,16 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
     }
   }
   if (i < n) {
+    __builtin_assume(i < (1u << 29));
     uint32_t c0 = 0;
     for (; c0 + 16 <= n_cols; c0 += 16) {  // full chunks: 16 loads issue back to back, no per-column bounds branches
 #pragma unroll
-      for (uint32_t k = 0; k < 16; k++) m[k] = cols[c0 + k][i];
+      for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
       b2s_compress(h, m);
     }
     if (c0 < n_cols) {
 #pragma unroll
-      for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? cols[c0 + k][i] : 0u;
+      for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? CM_GCOL(cols[c0 + k])[i] : 0u;
       b2s_compress(h, m);
     }
   }
