@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) k_eval_partial_multi(const EapJobDev* __r
   const uint32_t b = blockIdx.x - jb.block_begin;
   const uint32_t col = b / jb.ngroups, grp = b - col * jb.ngroups;
   const uint32_t c0 = grp * EAP2_GROUP, c1 = min(c0 + EAP2_GROUP, nchunks);
-  const uint32_t* __restrict__ coef = jb.coeffs[col];
+  const cm_gptr coef = CM_GCOL(jb.coeffs[col]);   // HBM column reached through the job table: global, not flat, loads
   const uint32_t* __restrict__ high = scratch + jb.high_off;
   constexpr uint32_t PER = (1u << EAP2_LOW_BITS) / 256;  // low indices per thread
   unsigned long long q[PER][4];
