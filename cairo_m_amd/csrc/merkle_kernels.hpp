@@ -109,12 +109,12 @@ __global__ void __launch_bounds__(256) k_merkle_multi(MerkleMultiArgs a) {
       uint32_t c0 = c_begin;
       for (; c0 + 16 <= c_end; c0 += 16) {
 #pragma unroll
-        for (uint32_t k = 0; k < 16; k++) m[k] = a.cols[c0 + k][i];
+        for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(a.cols[c0 + k])[i];
         b2s_compress(h, m);
       }
       if (c0 < c_end) {
 #pragma unroll
-        for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? a.cols[c0 + k][i] : 0u;
+        for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? CM_GCOL(a.cols[c0 + k])[i] : 0u;
         b2s_compress(h, m);
       }
       uint4* o = reinterpret_cast<uint4*>(a.layers[lv] + (size_t)i * 8);
@@ -159,12 +159,12 @@ __global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
       uint32_t c0 = c_begin;
       for (; c0 + 16 <= c_end; c0 += 16) {
 #pragma unroll
-        for (uint32_t k = 0; k < 16; k++) m[k] = a.cols[c0 + k][node];
+        for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(a.cols[c0 + k])[node];
         b2s_compress_quad(h0, h1, m, q);
       }
       if (c0 < c_end) {
 #pragma unroll
-        for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? a.cols[c0 + k][node] : 0u;
+        for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? CM_GCOL(a.cols[c0 + k])[node] : 0u;
         b2s_compress_quad(h0, h1, m, q);
       }
       uint32_t* o = a.layers[l] + (size_t)node * 8;
@@ -190,12 +190,12 @@ __device__ __forceinline__ void merkle_node_thread(const uint32_t* children, con
   uint32_t c0 = c_begin;
   for (; c0 + 16 <= c_end; c0 += 16) {
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = cols[c0 + k][i];
+    for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
     b2s_compress(h, m);
   }
   if (c0 < c_end) {
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? cols[c0 + k][i] : 0u;
+    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? CM_GCOL(cols[c0 + k])[i] : 0u;
     b2s_compress(h, m);
   }
 }
@@ -210,12 +210,12 @@ __device__ __forceinline__ void merkle_node_quad(const uint32_t* children, const
   uint32_t c0 = c_begin;
   for (; c0 + 16 <= c_end; c0 += 16) {
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = cols[c0 + k][i];
+    for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
     b2s_compress_quad(h0, h1, m, q);
   }
   if (c0 < c_end) {
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? cols[c0 + k][i] : 0u;
+    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? CM_GCOL(cols[c0 + k])[i] : 0u;
     b2s_compress_quad(h0, h1, m, q);
   }
 }
@@ -313,12 +313,12 @@ __global__ void __launch_bounds__(256) k_merkle_layer_quad(uint32_t log_size, co
   uint32_t c0 = 0;
   for (; c0 + 16 <= n_cols; c0 += 16) {
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = cols[c0 + k][i];
+    for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
     b2s_compress_quad(h0, h1, m, q);
   }
   if (c0 < n_cols) {
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? cols[c0 + k][i] : 0u;
+    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? CM_GCOL(cols[c0 + k])[i] : 0u;
     b2s_compress_quad(h0, h1, m, q);
   }
   out[(size_t)i * 8 + q] = h0;
