@@ -17,6 +17,14 @@ struct QuotientBatch {
   uint32_t sum_a[4], sum_b[4];  // sum over the batch of alpha^i * a_i and alpha^i * b_i
   uint32_t batch_coeff[4];   // random_coeff ^ (#columns in the batch)
 };
+// Per-batch job of k_quotient_coeffs: fills coef_c[begin, end), sum_a, sum_b and batch_coeff of *qb from the sampled
+// values (already in HBM after the OODS kernels) and the random coefficient (a kernel argument)
+struct QuotientCoefJob {
+  QuotientBatch* qb;          // begin / end / point set by the host
+  uint32_t* coef_c;           // the group's coef_c array (4 words per entry)
+  const uint32_t* sample_idx; // the group's per-entry index of the sampled value (QM31 = 4 words at 4 * idx)
+};
+void quotient_coeffs(const QuotientCoefJob* d_jobs, uint32_t n_jobs, const uint32_t* d_samples, const QM31& coeff, hipStream_t st);
 struct QuotientArgs {
   TwiddleView tw;
   uint32_t log_size;

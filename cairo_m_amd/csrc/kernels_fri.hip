@@ -101,6 +101,35 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
   }
 }
 
+// compute_fri_quotients' per-sample coefficients on the device (one block per batch): entry k of a batch gets
+// alpha = coeff^(k+1); with v its sampled value and (Px, Py) the batch's point: a = conj(v) - v, c = conj(Py) - Py,
+// b = v c - a Py; coef_c = alpha c, sum_a = sum alpha a, sum_b = sum alpha b, batch_coeff = coeff^n.
+__global__ void __launch_bounds__(256) k_quotient_coeffs(const QuotientCoefJob* __restrict__ jobs, const uint32_t* __restrict__ samples,
+                                                         uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
+  const QuotientCoefJob jb = jobs[blockIdx.x];
+  const QM31 coeff = QM31(M31(q0), M31(q1), M31(q2), M31(q3));
+  const uint32_t begin = jb.qb->begin, end = jb.qb->end;
+  const QM31 py = QM31::from_u32(jb.qb->point + 4);
+  const QM31 cdiff = conj_u(py) - py;
+  QM31 sa, sb;
+  for (uint32_t e = begin + threadIdx.x; e < end; e += 256) {
+    const QM31 alpha = qpow(coeff, (uint64_t)(e - begin) + 1);
+    const QM31 v = QM31::from_u32(samples + 4 * (size_t)jb.sample_idx[e]);
+    const QM31 a = conj_u(v) - v;
+    const QM31 b = v * cdiff - a * py;
+    sa += alpha * a;
+    sb += alpha * b;
+    (alpha * cdiff).to_u32(jb.coef_c + 4 * (size_t)e);
+  }
+  sa = block_reduce_qm31(sa);
+  sb = block_reduce_qm31(sb);
+  if (threadIdx.x == 0) {
+    sa.to_u32(jb.qb->sum_a);
+    sb.to_u32(jb.qb->sum_b);
+    qpow(coeff, (uint64_t)(end - begin)).to_u32(jb.qb->batch_coeff);
+  }
+}
+
 __device__ __forceinline__ QM31 ld4(const uint32_t* const* c, uint32_t i) {
   return QM31(M31(c[0][i]), M31(c[1][i]), M31(c[2][i]), M31(c[3][i]));
 }
@@ -284,6 +313,12 @@ void fold_line_and_circle(uint32_t* const out[4], const uint32_t* const src[4], 
   for (int i = 0; i < 4; i++) { d.p[i] = out[i]; s.p[i] = src[i]; c.p[i] = circle[i]; }
   uint32_t n = 1u << (log_n - 1);
   hipLaunchKernelGGL(k_fold_line_circle, dim3((n + 255) / 256), dim3(256), 0, st, d, s, c, log_n, view(tw), d_alpha, d_alpha_circle);
+  CM_HIP(hipGetLastError());
+}
+void quotient_coeffs(const QuotientCoefJob* d_jobs, uint32_t n_jobs, const uint32_t* d_samples, const QM31& coeff, hipStream_t st) {
+  if (!n_jobs) return;
+  hipLaunchKernelGGL(k_quotient_coeffs, dim3(n_jobs), dim3(256), 0, st, d_jobs, d_samples, coeff.a.a.v, coeff.a.b.v, coeff.b.a.v,
+                     coeff.b.b.v);
   CM_HIP(hipGetLastError());
 }
 void fri_tail(const FriTailArgs& a, hipStream_t st) {

@@ -801,6 +801,13 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     d_oods_table = upload(table, st);
     d_oods_out.alloc(n_oods_out * 16);
   }
+  // where the sampled value of (tree, column) lands in d_oods_out: the DEEP-quotient coefficients are computed on the
+  // device straight from there (k_quotient_coeffs)
+  std::vector<std::vector<uint32_t>> sidx_cur(4), sidx_prev(4);
+  for (int t = 0; t < 4; t++) { sidx_cur[t].assign(P.trees[t].coeffs.size(), 0); sidx_prev[t].assign(P.trees[t].coeffs.size(), 0); }
+  for (auto& j : ojobs)
+    for (size_t i = 0; i < j.refs.size(); i++)
+      (j.refs[i].prev ? sidx_prev : sidx_cur)[j.refs[i].t][j.refs[i].c] = (uint32_t)(j.out_off + i);
   pf.sampled_values.resize(4);
   for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
   P.commit_finish(P.trees[3]);
@@ -809,10 +816,12 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   // host side of compute_fri_quotients for every size group, packed into ONE upload:
   // [column pointers | out pointers | col_index | coef_c | batches] per group, 16-byte aligned
   struct QRef { int t; uint32_t c; };
-  struct QEntry { uint32_t col; const QM31* value; };
+  struct QEntry { uint32_t col; uint32_t sidx; };   // column of the group, index of its sampled value in d_oods_out
   struct QBatch { CPoint<QM31> pt; std::vector<QEntry> entries; };
   struct QGroup { uint32_t log = 0; std::vector<const uint32_t*> cols; std::vector<QBatch> batches; ColumnSet out;
-                  size_t o_cols = 0, o_out = 0, o_ci = 0, o_cc = 0, o_qb = 0; };
+                  size_t o_cols = 0, o_out = 0, o_ci = 0, o_cc = 0, o_qb = 0, o_sidx = 0; };
+  DevBuf d_qblob;
+  size_t o_qjobs = 0, n_qjobs = 0;
   std::vector<QGroup> qg;
   std::vector<uint8_t> qblob;
   auto qput = [&](const void* ptr, size_t bytes) {
@@ -877,7 +886,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
           size_t bi = 0;
           for (; bi < g.batches.size(); bi++) if (g.batches[bi].pt.x == pt.x && g.batches[bi].pt.y == pt.y) break;
           if (bi == g.batches.size()) g.batches.push_back(QBatch{pt, {}});
-          g.batches[bi].entries.push_back(QEntry{i, &pf.sampled_values[r.t][r.c][k]});
+          g.batches[bi].entries.push_back(QEntry{i, (ns == 2 && k == 0) ? sidx_prev[r.t][r.c] : sidx_cur[r.t][r.c]});
         }
       }
       size_t n_entries = 0;
@@ -885,10 +894,38 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       g.out.alloc(std::vector<uint32_t>(4, g.log), st, false);
       g.o_cols = qput(g.cols.data(), g.cols.size() * sizeof(void*));
       g.o_out = qput(g.out.ptrs.data(), 4 * sizeof(void*));
-      g.o_ci = qput(nullptr, n_entries * 4);
-      g.o_cc = qput(nullptr, n_entries * 16);
-      g.o_qb = qput(nullptr, g.batches.size() * sizeof(QuotientBatch));
+      {
+        std::vector<uint32_t> ci, si;
+        std::vector<QuotientBatch> qb(g.batches.size());
+        for (size_t bi = 0; bi < g.batches.size(); bi++) {
+          memset(&qb[bi], 0, sizeof(QuotientBatch));
+          qb[bi].begin = (uint32_t)ci.size();
+          for (auto& en : g.batches[bi].entries) { ci.push_back(en.col); si.push_back(en.sidx); }
+          qb[bi].end = (uint32_t)ci.size();
+          g.batches[bi].pt.x.to_u32(qb[bi].point);   // words = (Pr.x, Pi.x): QM31 = (a.a, a.b, b.a, b.b)
+          g.batches[bi].pt.y.to_u32(qb[bi].point + 4);
+        }
+        g.o_ci = qput(ci.data(), ci.size() * 4);
+        g.o_sidx = qput(si.data(), si.size() * 4);
+        g.o_cc = qput(nullptr, n_entries * 16);            // filled by k_quotient_coeffs
+        g.o_qb = qput(qb.data(), qb.size() * sizeof(QuotientBatch));   // sums / batch coefficient filled on the device
+      }
+      n_qjobs += g.batches.size();
       qg.push_back(std::move(g));
+    }
+    {  // the whole plan goes to the device now, behind the OODS kernels; only the random coefficient is still missing
+      o_qjobs = qput(nullptr, n_qjobs * sizeof(QuotientCoefJob));
+      d_qblob.alloc(qblob.size());
+      uint8_t* base = d_qblob.as<uint8_t>();
+      QuotientCoefJob* qj = (QuotientCoefJob*)(qblob.data() + o_qjobs);
+      size_t k = 0;
+      for (auto& g : qg)
+        for (size_t bi = 0; bi < g.batches.size(); bi++, k++) {
+          qj[k].qb = (QuotientBatch*)(base + g.o_qb) + bi;
+          qj[k].coef_c = (uint32_t*)(base + g.o_cc);
+          qj[k].sample_idx = (const uint32_t*)(base + g.o_sidx);
+        }
+      stage_upload(d_qblob.p, qblob.data(), qblob.size(), st);
     }
     ht.mark("oods: overlapped quotient planning");
     CM_HIP(hipStreamSynchronize(st));
@@ -911,38 +948,9 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   std::vector<uint32_t> q_logs;
   std::vector<ColumnSet> quotients;
   {
-    for (auto& g : qg) {
-      uint32_t* col_index = (uint32_t*)(qblob.data() + g.o_ci);
-      uint32_t* coef_c = (uint32_t*)(qblob.data() + g.o_cc);
-      QuotientBatch* qb = (QuotientBatch*)(qblob.data() + g.o_qb);
-      uint32_t e = 0;
-      for (size_t bi = 0; bi < g.batches.size(); bi++) {
-        const QBatch& bt = g.batches[bi];
-        qb[bi].begin = e;
-        QM31 alpha(M31(1)), sum_a, sum_b;
-        const QM31 cdiff = conj_u(bt.pt.y) - bt.pt.y;
-        for (auto& en : bt.entries) {
-          const QM31 v = *en.value;
-          alpha = alpha * qcoeff;
-          QM31 av = conj_u(v) - v;
-          QM31 bb = v * cdiff - av * bt.pt.y;
-          sum_a += alpha * av;
-          sum_b += alpha * bb;
-          col_index[e] = en.col;
-          (alpha * cdiff).to_u32(coef_c + 4 * e);
-          e++;
-        }
-        qb[bi].end = e;
-        bt.pt.x.to_u32(qb[bi].point);   // words = (Pr.x, Pi.x): QM31 = (a.a, a.b, b.a, b.b)
-        bt.pt.y.to_u32(qb[bi].point + 4);
-        sum_a.to_u32(qb[bi].sum_a);
-        sum_b.to_u32(qb[bi].sum_b);
-        alpha.to_u32(qb[bi].batch_coeff);   // qcoeff^(entries of the batch)
-      }
-    }
-    ht.mark("quotients: coefficient math");
-    DevBuf d_blob = upload(qblob, st);
-    const uint8_t* base = d_blob.as<uint8_t>();
+    // per-sample coefficients, batch sums and batch coefficients: one small kernel on the sampled values in HBM
+    quotient_coeffs((const QuotientCoefJob*)(d_qblob.as<uint8_t>() + o_qjobs), (uint32_t)n_qjobs, d_oods_out.u32(), qcoeff, st);
+    const uint8_t* base = d_qblob.as<uint8_t>();
     // one kernel per size group, independent outputs: the small groups (latency-bound, ~140 us in a row) overlap the large
     KProfRegion kregq("k_quotients", st);   // concurrent launches: timed as one interval
     Fork fkq(st);
