@@ -48,8 +48,10 @@ def pmc_traffic(kernel_class):
         return None, None
 
 
-def cpu_baseline(sample_n):
-    """Oracle (CPU restatement, 'port') on a bounded sample of the same workload family."""
+def cpu_baseline(sample_n, hip_words=None):
+    """Oracle (CPU restatement, 'port') on a bounded sample of the same workload family.  When the sample IS the bench
+    workload (the default) the oracle's proof words are compared with the HIP proof of the same ProverInput: the returned
+    `parity` is True / False, or None when the sample differs from the bench workload."""
     import subprocess
     from tests.oracle_binding import Oracle, oracle_threads
     from cairo_m_amd.lib import synth_fibonacci
@@ -59,11 +61,15 @@ def cpu_baseline(sample_n):
     orc = Oracle(so)
     inp = synth_fibonacci(sample_n)
     t = time.perf_counter()
-    _, cells = orc.prove(inp.view)
+    words, cells = orc.prove(inp.view)
     dt = time.perf_counter() - t
     steps = inp.steps
     inp.free()
-    return {"value": cells / dt, "unit": "M31 trace cells/s", "cores": oracle_threads(), "kind": "port",
+    parity = None
+    if hip_words is not None:
+        import numpy as np
+        parity = bool(words.size == hip_words.size and np.array_equal(words, hip_words))
+    return parity, {"value": cells / dt, "unit": "M31 trace cells/s", "cores": oracle_threads(), "kind": "port",
             "sample": f"fibonacci_loop n={sample_n} ({steps} VM steps, {cells} cells incl. the fixed "
                       f"2^20/2^18/2^16 preprocessed + range-check tables), oracle prove_segment, OpenMP x{oracle_threads()} of {os.cpu_count()} host cores, {dt:.1f} s"}
 
@@ -77,6 +83,7 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=FIB_N,
                     help="fibonacci_loop size the CPU oracle proves for cpu_baseline (default: the bench workload itself, ~14 s on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive `end_to_end` measurements")
     ap.add_argument("--no-kprof", action="store_true", help="debug: no in-library HIP-event kernel timing")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent segment proofs in flight per GPU (one host thread + stream set each)")
@@ -90,7 +97,21 @@ def main():
                          "default recomputes tree 0 in every proof like the reference does")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one process per GPU), exactly the
+        # command the driver uses, so that the line printed can never silently be an N=1 measurement.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -210,6 +231,47 @@ def main():
                      "value": n_pipe * cells / dtp, "unit": "M31 trace cells/s",
                      "note": "throughput with several independent segment proofs in flight on the GPU (not the headline value)"}
 
+    verified = None
+    hip_words = None
+    end_to_end = None
+    if rank == 0:
+        # one more (untimed) proof of the same input: the product verifier must accept it, and its words are what the
+        # cpu_baseline leg compares the oracle's proof with
+        p = be.prove_device(dev)
+        hip_words = p.words().copy()
+        vrc, verr = p.verify()
+        verified = vrc == 0
+        p.free()
+        if not verified:
+            sys.exit(f"bench.py: the HIP proof of the bench workload does not verify: {verr}")
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        # PCIe-inclusive figures (never `value`): (a) cm_prove_segment from a host ProverInput = upload + prove;
+        # (b) runner segment (trace + memory log in host memory) -> device adapter -> prove
+        from cairo_m_amd.lib import synth_fibonacci_segment
+        def best(f, reps=3):
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                f()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t) * 1e3)
+            return min(ts), sum(ts) / len(ts)
+        def from_host():
+            be.prove(inp).free()
+        seg = synth_fibonacci_segment(args.fib_n)
+        def from_runner():
+            d = be.adapt_segment(seg)
+            be.prove_device(d).free()
+            be.free_input(d)
+        h_min, h_avg = best(from_host)
+        r_min, r_avg = best(from_runner)
+        seg.free()
+        end_to_end = {"host_prover_input_ms": {"min": h_min, "avg": h_avg, "api": "cm_prove_segment (pageable host ProverInput: upload + prove)"},
+                      "runner_segment_ms": {"min": r_min, "avg": r_avg, "api": "cm_adapt_segment_device + cm_prove_device (runner trace + memory log in host memory -> device adapter -> proof)"},
+                      "cells_per_s_from_host_input": cells / (h_min * 1e-3),
+                      "note": "PCIe-inclusive; never the headline `value` (inputs resident in HBM)"}
+
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
         value = world * args.steps * cells / dt
@@ -241,15 +303,24 @@ def main():
                "dtype": "u32", "data": "synthetic",
                "config": {"workload": f"fibonacci_loop n={args.fib_n} ({inp.steps} VM steps, one segment, "
                                       f"{cells} committed trace cells), REGULAR_96_BITS PCS config, "
-                                      "ProverInput resident in HBM"
+                                      "ProverInput resident in HBM (upload excluded: see `end_to_end`), twiddle tables "
+                                      "and the preprocessed tree rebuilt inside every proof like the reference does"
                                       + (", preprocessed tree cached between proofs" if args.preprocessed_cache else ""),
                           "cells_per_proof": cells,
                           "vm_steps": inp.steps, "parallelism": f"{world} independent segment replica(s) x {len(workers)} proof(s) in flight per GPU"},
-               "phase_ms": phases, "roofline": roofline, "pipelined": pipelined}
+               "phase_ms": phases, "roofline": roofline, "pipelined": pipelined, "end_to_end": end_to_end,
+               "proof_verified": verified}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
+            same = args.cpu_sample_n == args.fib_n
+            parity, out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, hip_words if same else None)
+            # bit-exactness AT the metric config: the oracle proves the very ProverInput the GPU was timed on
+            out["parity_at_metric_config"] = parity
+            if parity is False:
+                print(json.dumps(out))
+                sys.exit("bench.py: the HIP proof differs from the CPU oracle's proof of the same input")
         else:
             out["cpu_baseline"] = None
+            out["parity_at_metric_config"] = None
         print(json.dumps(out))
     be.free_input(dev)
     inp.free()

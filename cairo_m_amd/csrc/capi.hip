@@ -184,8 +184,8 @@ int32_t cm_merkle_commit(const cm_handle* cols, const uint32_t* col_logs, uint32
     t.root(root, S(s));
   });
 }
-int32_t cm_grind(const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce_out) {
-  return guard([&] { *nonce_out = grind_gpu(digest, pow_bits, 0); });
+int32_t cm_grind(const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce_out, cm_stream_t s) {
+  return guard([&] { *nonce_out = grind_gpu(digest, pow_bits, S(s)); });
 }
 
 }  // extern "C"

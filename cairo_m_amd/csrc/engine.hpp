@@ -17,6 +17,7 @@ struct Twiddles {
   uint32_t *xtw = nullptr, *ixtw = nullptr, *ytw = nullptr, *iytw = nullptr;
 };
 Twiddles* twiddles_create(uint32_t R, hipStream_t st);
+void twiddles_build(const Twiddles& t, hipStream_t st);   // caller-allocated buffers (R set, 2^(R-1) / 2^R words)
 void twiddles_destroy(Twiddles* t);
 
 // in-place IFFT of ncols columns of 2^n (bit-reversed evals -> coefficients)

@@ -308,6 +308,19 @@ __global__ void __launch_bounds__(256) k_reduce_partials_multi(const EapJobDev* 
 }
 
 // ================================================================= host wrappers
+// fills tables whose four buffers the caller allocated (nx = 2^(R-1) words for xtw / ixtw, ny = 2^R for ytw / iytw)
+void twiddles_build(const Twiddles& t, hipStream_t st) {
+  const uint32_t R = t.R;
+  CM_CHECK(R >= 2 && R <= 28, "twiddles: log size out of range (columns are limited to 2^26 rows)");
+  size_t nx = (size_t)1 << (R - 1), ny = (size_t)1 << R;
+  CM_HIP(hipMemsetAsync(t.ytw, 0, 4, st));
+  CM_HIP(hipMemsetAsync(t.iytw, 0, 4, st));
+  CM_HIP(hipMemsetAsync(t.xtw + (nx - 1), 0, 4, st));
+  CM_HIP(hipMemsetAsync(t.ixtw + (nx - 1), 0, 4, st));
+  hipLaunchKernelGGL(k_twiddles_x, dim3((nx + 255) / 256), dim3(256), 0, st, t.xtw, t.ixtw, R);
+  hipLaunchKernelGGL(k_twiddles_y, dim3((ny + 255) / 256), dim3(256), 0, st, t.ytw, t.iytw, R);
+  CM_HIP(hipGetLastError());
+}
 Twiddles* twiddles_create(uint32_t R, hipStream_t st) {
   CM_CHECK(R >= 2 && R <= 28, "twiddles: log size out of range (columns are limited to 2^26 rows)");
   Twiddles* t = new Twiddles();
@@ -317,13 +330,7 @@ Twiddles* twiddles_create(uint32_t R, hipStream_t st) {
   CM_HIP(hipMalloc(&t->ixtw, nx * 4));
   CM_HIP(hipMalloc(&t->ytw, ny * 4));
   CM_HIP(hipMalloc(&t->iytw, ny * 4));
-  CM_HIP(hipMemsetAsync(t->ytw, 0, 4, st));
-  CM_HIP(hipMemsetAsync(t->iytw, 0, 4, st));
-  CM_HIP(hipMemsetAsync(t->xtw + (nx - 1), 0, 4, st));
-  CM_HIP(hipMemsetAsync(t->ixtw + (nx - 1), 0, 4, st));
-  hipLaunchKernelGGL(k_twiddles_x, dim3((nx + 255) / 256), dim3(256), 0, st, t->xtw, t->ixtw, R);
-  hipLaunchKernelGGL(k_twiddles_y, dim3((ny + 255) / 256), dim3(256), 0, st, t->ytw, t->iytw, R);
-  CM_HIP(hipGetLastError());
+  twiddles_build(*t, st);
   return t;
 }
 void twiddles_destroy(Twiddles* t) {

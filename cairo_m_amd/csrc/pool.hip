@@ -71,6 +71,7 @@ struct Stage {
   std::mutex mu;
   uint8_t* base = nullptr;
   size_t size = (size_t)32 << 20, off = 0;
+  std::vector<hipStream_t> users;   // streams with copies out of the ring since the last wrap (main stream + Fork side streams)
   void ensure() {
     if (!base) CM_HIP(hipHostMalloc((void**)&base, size, hipHostMallocDefault));
   }
@@ -87,15 +88,22 @@ void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
   std::lock_guard<std::mutex> lk(s.mu);
   s.ensure();
   size_t need = (bytes + 255) & ~(size_t)255;
-  if (need > s.size / 2) {  // oversize: plain synchronous copy
-    CM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  if (need > s.size / 2) {
+    // oversize: straight from the caller's (pageable) memory, but ORDERED on `st` — the destination usually comes from the
+    // caching pool, whose reuse is only stream-ordered, and a NULL-stream hipMemcpy is not ordered against the library's
+    // non-blocking streams (earlier kernels on `st` could still be using the recycled block).
+    CM_HIP(hipStreamSynchronize(st));
+    CM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    CM_HIP(hipStreamSynchronize(st));
     return;
   }
   if (s.off + need > s.size) {
-    // wrap: make sure every copy still reading the ring has executed
-    CM_HIP(hipStreamSynchronize(st));
+    // wrap: every copy still reading the ring must have executed, on whichever stream it was enqueued
+    for (hipStream_t u : s.users) CM_HIP(hipStreamSynchronize(u));
+    s.users.clear();
     s.off = 0;
   }
+  if (std::find(s.users.begin(), s.users.end(), st) == s.users.end()) s.users.push_back(st);
   memcpy(s.base + s.off, src, bytes);
   CM_HIP(hipMemcpyAsync(dst, s.base + s.off, bytes, hipMemcpyHostToDevice, st));
   s.off += need;

@@ -50,6 +50,8 @@ static PublicData make_public_data(const cm_prover_input& in) {  // PublicData::
   for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) steps += in.n_bundles[i];
   d.clock = M31::reduce(steps).v;
   d.initial_root = in.initial_root; d.final_root = in.final_root;
+  for (uint32_t w : {d.initial_pc, d.initial_fp, d.final_pc, d.final_fp, d.initial_root, d.final_root})
+    CM_CHECK(w < P, "ProverInput: a public register / root word is not a canonical M31");
   std::map<uint32_t, const cm_memory_cell*> init, fin;
   for (uint64_t i = 0; i < in.n_initial_memory; i++) init[in.initial_memory[i].address] = &in.initial_memory[i];
   for (uint64_t i = 0; i < in.n_final_memory; i++) fin[in.final_memory[i].address] = &in.final_memory[i];
@@ -58,7 +60,11 @@ static PublicData make_public_data(const cm_prover_input& in) {  // PublicData::
     for (uint32_t a = range[0]; a < range[1]; a++) {
       PublicEntry e{};
       auto it = m.find(a);
-      if (it != m.end()) { e.present = 1; e.addr = a; for (int k = 0; k < 4; k++) e.value[k] = it->second->value[k]; e.clock = it->second->clock; }
+      if (it != m.end()) {
+        e.present = 1; e.addr = a; for (int k = 0; k < 4; k++) e.value[k] = it->second->value[k]; e.clock = it->second->clock;
+        CM_CHECK(a < P && e.clock < P && e.value[0] < P && e.value[1] < P && e.value[2] < P && e.value[3] < P,
+                 "ProverInput: a public memory entry is not made of canonical M31 words");
+      }
       v.push_back(e);
     }
     return v;
@@ -305,7 +311,20 @@ static uint32_t fri_tail_log() {
 // CM_NO_SMALL_BATCH=1: one launch per small component again (A/B of the batched small-component kernels)
 static bool no_small_batch() { static const bool v = getenv("CM_NO_SMALL_BATCH") != nullptr; return v; }
 
-// Twiddle tables depend only on the domain size: built once per size and kept (like the code objects).
+// Twiddle tables.  The reference recomputes them in every prove_cairo_m (`SimdBackend::precompute_twiddles`, prover.rs:56-60),
+// so by default every proof builds its own tables (in pool memory, on a side stream next to trace generation); they
+// depend only on the domain size, and cm_set_twiddle_cache(1) / CM_TWIDDLE_CACHE=1 keeps one table per size for the
+// process instead (OFF in every quoted number, like the preprocessed-tree cache).
+static std::atomic<int> g_tw_cache{-1};
+static bool tw_cache_enabled() {
+  int v = g_tw_cache.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("CM_TWIDDLE_CACHE");
+    v = (e && *e && *e != '0') ? 1 : 0;
+    g_tw_cache.store(v, std::memory_order_relaxed);
+  }
+  return v == 1;
+}
 static Twiddles* cached_twiddles(uint32_t R, hipStream_t st) {
   static std::mutex mu;
   static std::map<uint32_t, Twiddles*> cache;
@@ -317,6 +336,16 @@ static Twiddles* cached_twiddles(uint32_t R, hipStream_t st) {
   cache[R] = t;
   return t;
 }
+struct ProofTwiddles {   // per-proof tables in pool memory
+  Twiddles t;
+  DevBuf x, ix, y, iy;
+  void build(uint32_t R, hipStream_t s) {
+    t.R = R;
+    x.alloc((size_t)4 << (R - 1)); ix.alloc((size_t)4 << (R - 1)); y.alloc((size_t)4 << R); iy.alloc((size_t)4 << R);
+    t.xtw = x.u32(); t.ixtw = ix.u32(); t.ytw = y.u32(); t.iytw = iy.u32();
+    twiddles_build(t, s);
+  }
+};
 
 // coset_vanishing of CanonicCoset(log).coset at p (QM31 or M31 point)
 template <class F>
@@ -417,7 +446,17 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   std::stable_sort(by_size.begin(), by_size.end(), bigger);
   std::stable_sort(by_size_all.begin(), by_size_all.end(), bigger);
   const uint32_t comp_log = max_log + 1;
-  P.tw = cached_twiddles(comp_log + cfg.log_blowup_factor, st);
+  CM_CHECK(cfg.n_queries >= 1 && cfg.n_queries <= 4096, "PcsConfig: n_queries must be in 1..4096");
+  CM_CHECK(cfg.pow_bits <= 64, "PcsConfig: pow_bits must be at most 64");
+  CM_CHECK(cfg.log_last_layer_degree_bound <= max_log, "PcsConfig: log_last_layer_degree_bound exceeds the largest trace column");
+  ProofTwiddles own_tw;
+  std::unique_ptr<Fork> tw_fork;
+  if (tw_cache_enabled()) P.tw = cached_twiddles(comp_log + cfg.log_blowup_factor, st);
+  else {
+    tw_fork.reset(new Fork(st));
+    own_tw.build(comp_log + cfg.log_blowup_factor, tw_fork->stream(Fork::N - 1));   // joined before the first transform
+    P.tw = &own_tw.t;
+  }
 
   // ---- transcript setup (prover.rs:33-36, 62-66) ----
   ch.mix_u64(cfg.pow_bits);
@@ -523,6 +562,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     flag_host[0] = 0xffffffffu;
     CM_HIP(hipMemcpyAsync(flag_host, flag.p, 4, hipMemcpyDeviceToHost, st));
   }
+  if (tw_fork) tw_fork->join();   // the proof's twiddle tables are complete from here on
   if (build_tree0) {
     // tree 0 (a chain of ~30 small launches) is built on a side stream while the transforms and hashes of tree 1 keep
     // the GPU busy; its root comes back together with the root of tree 1.  Forked from the stream position after the
@@ -1327,7 +1367,7 @@ ProveWorkers& prove_workers() { static ProveWorkers* w = new ProveWorkers(); ret
 }  // namespace cm
 
 namespace cm {
-std::string verify_proof(const ProofData& pf);                                                // verifier.hip
+std::string verify_proof(const ProofData& pf, const cm_pcs_config& expected);                 // verifier.hip
 bool proof_from_words(const uint32_t* w, uint64_t n, ProofData& p, std::string& err);
 }  // namespace cm
 
@@ -1569,18 +1609,18 @@ int32_t cm_constraints_accumulate(int32_t c, const cm_handle* trace_lde, const c
   });
 }
 // verify_cairo_m (crates/prover/src/verifier.rs:17-95): 0 = accepted; status 11 + cm_last_error() = name of the failed check
-int32_t cm_verify_proof(const cm_proof* p) {
+int32_t cm_verify_proof(const cm_proof* p, const cm_pcs_config* expected) {
   return pguard([&] {
-    std::string e = cm::verify_proof(*p->d);
+    std::string e = cm::verify_proof(*p->d, expected ? *expected : default_cfg());
     if (!e.empty()) throw cm::CmError(11, "verification failed: " + e);
   });
 }
-int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words) {
+int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words, const cm_pcs_config* expected) {
   return pguard([&] {
     cm::ProofData pd;
     std::string e;
     if (!cm::proof_from_words(words, n_words, pd, e)) throw cm::CmError(11, "verification failed: " + e);
-    e = cm::verify_proof(pd);
+    e = cm::verify_proof(pd, expected ? *expected : default_cfg());
     if (!e.empty()) throw cm::CmError(11, "verification failed: " + e);
   });
 }
@@ -1614,6 +1654,10 @@ int32_t cm_kprof_enable(int32_t on) {
 // time only one kernel class (name as reported by cm_kprof_report); NULL / "" = all classes
 int32_t cm_set_preprocessed_cache(int32_t on) {
   cm::g_pp_cache.store(on ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
+int32_t cm_set_twiddle_cache(int32_t on) {
+  cm::g_tw_cache.store(on ? 1 : 0, std::memory_order_relaxed);
   return 0;
 }
 int32_t cm_kprof_filter(const char* name) {

@@ -50,6 +50,8 @@ bool proof_from_words(const uint32_t* w, uint64_t n, ProofData& p, std::string& 
       e.present = u(); e.addr = u();
       for (int j = 0; j < 4; j++) e.value[j] = u();
       e.clock = u();
+      if (e.present > 1 || e.addr >= P || e.clock >= P) ok = false;      // canonical M31 words only (M31(x) needs x < P)
+      for (int j = 0; j < 4; j++) if (e.value[j] >= P) ok = false;
       v.push_back(e);
     }
   };
@@ -60,6 +62,7 @@ bool proof_from_words(const uint32_t* w, uint64_t n, ProofData& p, std::string& 
   for (uint32_t k = 0; k < nc; k++) p.claimed_sums.push_back(q());
   PublicData& d = p.public_data;
   d.initial_pc = u(); d.initial_fp = u(); d.final_pc = u(); d.final_fp = u(); d.clock = u(); d.initial_root = u(); d.final_root = u();
+  for (uint32_t w : {d.initial_pc, d.initial_fp, d.final_pc, d.final_fp, d.clock, d.initial_root, d.final_root}) if (w >= P) ok = false;
   entries(d.program); entries(d.input); entries(d.output);
   p.interaction_pow = u64();
   uint32_t nt = cnt(8);
@@ -272,13 +275,19 @@ bool rebuild_evals(const std::vector<uint32_t>& queries, const std::vector<QM31>
 }  // namespace
 
 // "" = the proof verifies; otherwise the name of the failed check
-std::string verify_proof(const ProofData& pf) {
-  const cm_pcs_config& cfg = pf.config;
+// `expected` is the verifier's OWN PcsConfig (verify_cairo_m takes it from the caller, defaulting to REGULAR_96_BITS,
+// verifier.rs:17-31): the security level is never read from the proof.  A proof made under another config fails.
+std::string verify_proof(const ProofData& pf, const cm_pcs_config& expected) {
+  const cm_pcs_config& cfg = expected;
+  if (pf.config.pow_bits != cfg.pow_bits || pf.config.log_blowup_factor != cfg.log_blowup_factor ||
+      pf.config.n_queries != cfg.n_queries || pf.config.log_last_layer_degree_bound != cfg.log_last_layer_degree_bound)
+    return "InvalidStructure(config): the proof was made under a different PcsConfig than the verifier's";
   if (pf.claim_log_sizes.size() != (size_t)air::N_COMPONENTS || pf.claimed_sums.size() != (size_t)air::N_COMPONENTS ||
       pf.commitments.size() != 4 || pf.sampled_values.size() != 4 || pf.decommitments.size() != 4 || pf.queried_values.size() != 4)
     return "InvalidStructure";
   for (auto l : pf.claim_log_sizes) if (l < 4 || l > 26) return "InvalidStructure(log size)";
-  if (cfg.log_blowup_factor != 1 || cfg.n_queries == 0 || cfg.n_queries > 4096 || cfg.pow_bits > 64) return "InvalidStructure(config)";
+  if (cfg.log_blowup_factor != 1 || cfg.n_queries == 0 || cfg.n_queries > 4096 || cfg.pow_bits > 64 ||
+      cfg.log_last_layer_degree_bound > 20) return "InvalidStructure(config)";
   Channel ch;
   ch.mix_u64(cfg.pow_bits);
   ch.mix_u64(cfg.log_blowup_factor);

@@ -108,7 +108,7 @@ class Backend:
     def grind(self, digest, bits):
         d = (C.c_uint8 * 32)(*digest)
         nonce = C.c_uint64(0)
-        self._ck(self.L.cm_grind(d, C.c_uint32(bits), C.byref(nonce)))
+        self._ck(self.L.cm_grind(d, C.c_uint32(bits), C.byref(nonce), C.c_uint64(0)))
         return nonce.value
 
     # -- FieldOps / FriOps / QuotientOps ----------------------------------------------------
@@ -235,9 +235,10 @@ class Proof:
         return {"cells": cells.value, "steps": steps.value,
                 "phase_ms": dict(zip(self.PHASES, [ph[i] for i in range(min(n, 32))]))}
 
-    def verify(self):
-        """verify_cairo_m on this proof (product-side verifier, host code): (status, message)."""
-        rc = self.L.cm_verify_proof(self.h)
+    def verify(self, cfg=None):
+        """verify_cairo_m(proof, pcs_config) on this proof (product-side verifier, host code): (status, message).
+        cfg = the PcsConfig the verifier expects, None = REGULAR_96_BITS (never taken from the proof)."""
+        rc = self.L.cm_verify_proof(self.h, _cfg(cfg))
         buf = C.create_string_buffer(512)
         self.L.cm_last_error(buf, C.c_size_t(512))
         return rc, buf.value.decode(errors="replace") if rc else ""
@@ -402,6 +403,7 @@ def _backend_set_preprocessed_cache(self, on):
 
 
 Backend.set_preprocessed_cache = _backend_set_preprocessed_cache
+Backend.set_twiddle_cache = lambda self, on: self._ck(self.L.cm_set_twiddle_cache(C.c_int32(1 if on else 0)))
 
 
 # ---- compiled-program JSON (crates/common/src/program.rs:143-170, instruction.rs:609-655) ----------------------

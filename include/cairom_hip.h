@@ -76,7 +76,7 @@ int32_t cm_merkle_commit(const cm_handle* cols, const uint32_t* col_logs, uint32
                          cm_stream_t s);
 
 /* ---- GrindOps<Blake2sChannel>::grind (reference: prover.rs:90) ------------------------------- */
-int32_t cm_grind(const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce_out);
+int32_t cm_grind(const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce_out, cm_stream_t s);
 
 /* ---- FieldOps::batch_inverse ---------------------------------------------------------------- */
 int32_t cm_batch_inverse_m31(cm_handle in, cm_handle out, uint64_t n, cm_stream_t s);
@@ -207,9 +207,12 @@ int32_t cm_input_free(cm_device_input* h);
 int32_t cm_prove_device(const cm_device_input* input, const cm_pcs_config* config, cm_proof** out);
 /* verify_cairo_m (crates/prover/src/verifier.rs:17-95 + Stwo verify): host code, works without a GPU.
  * 0 = the proof is accepted; otherwise status 11 and cm_last_error() names the failed check
- * (InvalidLogupSum, OodsNotMatching, Merkle(...), Fri(...), ProofOfWork, ...).  `words` = cm_proof_words format. */
-int32_t cm_verify_proof(const cm_proof* p);
-int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words);
+ * (InvalidLogupSum, OodsNotMatching, Merkle(...), Fri(...), ProofOfWork, ...).  `words` = cm_proof_words format.
+ * `expected` is the VERIFIER's PcsConfig (verify_cairo_m's `pcs_config: Option<PcsConfig>` argument, verifier.rs:19; NULL =
+ * REGULAR_96_BITS {16, 1, 0, 80}): it is what goes into the transcript and what bounds the PoW / query count; a proof
+ * made under any other config is rejected with InvalidStructure(config) — the prover never chooses the security level. */
+int32_t cm_verify_proof(const cm_proof* p, const cm_pcs_config* expected);
+int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words, const cm_pcs_config* expected);
 /* Segment pipeline: prove n independent segments with up to `inflight` (1..8) proofs in flight on the
  * GPU (persistent worker threads inside the library, one stream set / device pool each).  outs[i] = proof of
  * inputs[i]; on error the first failure is returned and the proofs already built stay in outs (free them). */
@@ -220,6 +223,10 @@ int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm
  * does); on = each host thread keeps the committed tree (coefficients, LDE, Merkle layers) between proofs of one
  * PCS config.  Env CM_PREPROCESSED_CACHE=1 sets the initial value.  Proof bytes are identical either way. */
 int32_t cm_set_preprocessed_cache(int32_t on);
+/* Twiddle tables: the reference recomputes them in every prove_cairo_m (prover.rs:56-60), and so does every proof here by
+ * default (pool memory, on a side stream next to trace generation).  on = keep one table per domain size for the whole
+ * process (env CM_TWIDDLE_CACHE=1 sets the initial value).  Off in every quoted number.  Proof bytes are identical. */
+int32_t cm_set_twiddle_cache(int32_t on);
 /* Flat u32 serialisation of the proof (format: cairo_m_amd/csrc/proof.hpp), used by the parity tests. */
 int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* n_out);
 /* JSON text of the proof; *len_out = length without the terminating NUL; the buffer is owned by

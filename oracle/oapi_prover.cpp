@@ -30,11 +30,14 @@ void orc_proof_words(const orc_proof_handle* h, uint32_t* dst) { memcpy(dst, h->
 uint64_t orc_proof_cells(const orc_proof_handle* h) { return h->cells; }
 void orc_proof_free(orc_proof_handle* h) { delete h; }
 
-int orc_verify(const uint32_t* words, uint64_t n) {
+// cfg: {pow_bits, log_blowup, log_last_layer, n_queries} the VERIFIER expects; NULL = REGULAR_96_BITS
+int orc_verify(const uint32_t* words, uint64_t n, const uint32_t* cfg) {
   try {
     Proof p;
     if (!deserialize(words, n, p)) { g_err = "malformed proof words"; return 2; }
-    std::string e = verify_proof(p);
+    PcsConfig c;
+    if (cfg) { c.pow_bits = cfg[0]; c.log_blowup = cfg[1]; c.log_last_layer = cfg[2]; c.n_queries = cfg[3]; }
+    std::string e = verify_proof(p, c);
     if (!e.empty()) { g_err = e; return 1; }
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return 3; }

@@ -74,8 +74,13 @@ inline bool rebuild_evals(const std::vector<size_t>& queries, const std::vector<
   return true;
 }
 
-inline std::string verify_proof(const Proof& pf) {
-  const PcsConfig& cfg = pf.config;
+// `expected`: the verifier's own PcsConfig (verify_cairo_m(proof, pcs_config), verifier.rs:17-31) — never the proof's.
+inline std::string verify_proof(const Proof& pf, const PcsConfig& expected = PcsConfig()) {
+  const PcsConfig& cfg = expected;
+  if (pf.config.pow_bits != cfg.pow_bits || pf.config.log_blowup != cfg.log_blowup || pf.config.n_queries != cfg.n_queries ||
+      pf.config.log_last_layer != cfg.log_last_layer) return "InvalidStructure(config)";
+  if (cfg.n_queries == 0 || cfg.n_queries > 4096 || cfg.pow_bits > 64 || cfg.log_last_layer > 20 || cfg.log_blowup != 1)
+    return "InvalidStructure(config)";
   if (pf.claim_log_sizes.size() != (size_t)air::N_COMPONENTS || pf.commitments.size() != 4) return "InvalidStructure";
   Channel ch;
   ch.mix_u64(cfg.pow_bits);

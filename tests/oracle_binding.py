@@ -114,10 +114,11 @@ def _attach_prover(cls):
         self.L.orc_proof_free(h)
         return w, cells
 
-    def verify(self, words):
+    def verify(self, words, cfg=None):
+        """cfg = the PcsConfig the VERIFIER expects (None = REGULAR_96_BITS), like verify_cairo_m's second argument."""
         setup(self)
         w = np.ascontiguousarray(words, dtype=np.uint32)
-        rc = self.L.orc_verify(_p(w), C.c_uint64(w.size))
+        rc = self.L.orc_verify(_p(w), C.c_uint64(w.size), (C.c_uint32 * 4)(*cfg) if cfg else None)
         return rc, (err(self) if rc else "")
 
     def assert_constraints(self, view):

@@ -36,6 +36,25 @@ def test_interpolate_evaluate_parity(backend, oracle, log_n):
     backend.twiddles_free(tw)
 
 
+@pytest.mark.parametrize("log_n", [21, 22])
+def test_interpolate_evaluate_parity_full_size(backend, oracle, log_n):
+    """The sizes the metric config transforms (2^21-row components, 2^22 LDE): one column, IFFT and LDE bit-exact
+    against the oracle (covers the 3-pass plans 11-5-5 / 11-6-5 / the fused 2-pass plans of kernels_poly.hip)."""
+    rng = np.random.default_rng(900 + log_n)
+    tw = backend.twiddles(log_n + 1)
+    c = rng.integers(0, P, size=1 << log_n, dtype=np.uint32)
+    h = backend.upload(c)
+    backend.interpolate([h], log_n, tw)
+    coeffs = backend.download(h, 1 << log_n)
+    assert np.array_equal(coeffs, oracle.interpolate(c))
+    o = backend.col_alloc(2 << log_n)
+    backend.evaluate([h], log_n, log_n + 1, tw, [o])
+    assert np.array_equal(backend.download(o, 2 << log_n), oracle.evaluate(coeffs, log_n + 1))
+    backend.col_free(h)
+    backend.col_free(o)
+    backend.twiddles_free(tw)
+
+
 def test_lde_roundtrip_large(backend):
     """Full-size property check (no oracle): 2^22 -> LDE 2^23 -> every even-half restriction
     interpolates back; here: interpolate(evaluate(c, n), n) == c and linearity."""
@@ -75,7 +94,10 @@ def test_eval_at_point_parity(backend, oracle, log_n):
                                   # k_merkle_top: multi-block ticket (2^16 = 256 blocks), columns entering at phase-1 and
                                   # phase-2 levels, single-layer kernels above; a wide layer (70 columns) forces the old path
                                   [17] * 3 + [16] * 2 + [13] * 5 + [9] * 2 + [7] * 20 + [5] * 3 + [2], [16] * 4, [9] * 33,
-                                  [15] * 2 + [11] * 70 + [6] * 3])
+                                  [15] * 2 + [11] * 70 + [6] * 3,
+                                  # layers of 2^19 nodes and more go through k_merkle_layer (one node per lane, the dominant
+                                  # kernel of the bench): leaf layer without children, 18- and 4-column layers with children
+                                  [20] * 3 + [19] * 18 + [12] * 2, [19] * 4, [21] + [20] * 42 + [19]])
 def test_merkle_commit_parity(backend, oracle, logs):
     rng = np.random.default_rng(len(logs))
     cols = [rng.integers(0, P, size=1 << l, dtype=np.uint32) for l in logs]
@@ -84,6 +106,40 @@ def test_merkle_commit_parity(backend, oracle, logs):
     want, _ = oracle.merkle_commit(cols)
     assert root == want
     for h in hs:
+        backend.col_free(h)
+
+
+@pytest.mark.parametrize("n_cols", [0, 4, 16, 17, 42])
+@pytest.mark.parametrize("with_prev", [False, True])
+def test_merkle_commit_layer_parity(backend, oracle, n_cols, with_prev):
+    """MerkleOps::commit_on_layer through the C ABI (cm_merkle_commit_layer) at 2^19 nodes = k_merkle_layer: every hash of
+    the layer equals the oracle's, with and without a previous layer, for column counts below / at / above one 16-word
+    Blake2s chunk and for the 42-column shape of the metric config's largest component."""
+    if n_cols == 0 and not with_prev:
+        pytest.skip("a layer needs children or columns")
+    L = 19
+    rng = np.random.default_rng(1000 + n_cols + (100 if with_prev else 0))
+    upper = [rng.integers(0, P, size=2 << L, dtype=np.uint32) for _ in range(3)] if with_prev else []
+    here = [rng.integers(0, P, size=1 << L, dtype=np.uint32) for _ in range(n_cols)]
+    _, layers = oracle.merkle_commit(upper + here)
+    layers = layers.reshape(-1, 8)
+    prev = 0
+    hs = []
+    if with_prev:
+        hu = [backend.upload(c) for c in upper]
+        prev = backend.col_alloc(8 * (2 << L))
+        backend.merkle_commit_layer(L + 1, 0, hu, prev)
+        assert np.array_equal(backend.download(prev, 8 * (2 << L)).reshape(-1, 8), layers[: 2 << L])
+        hs += hu + [prev]
+        want = layers[2 << L: (2 << L) + (1 << L)]
+    else:
+        want = layers[: 1 << L]
+    hc = [backend.upload(c) for c in here]
+    out = backend.col_alloc(8 << L)
+    backend.merkle_commit_layer(L, prev, hc, out)
+    got = backend.download(out, 8 << L).reshape(-1, 8)
+    assert np.array_equal(got, want)
+    for h in hs + hc + [out]:
         backend.col_free(h)
 
 

@@ -68,10 +68,10 @@ def test_u32_loop_program_bit_exact(backend, oracle):
     inp.free()
 
 
-def test_full_size_proof_properties(backend, oracle):
-    """fibonacci_loop at 2^20 steps (BASELINE configs[1]): too big for the oracle prover in a test, so check
-    size-independent properties: determinism (two runs give identical words), the cell count formula, and
-    acceptance by the oracle verifier."""
+def test_configs1_proof_bit_exact(backend, oracle):
+    """BASELINE configs[1] — fibonacci_loop --arguments 100000 (1 000 012 steps, ~2^20 rows) on one MI355X, "proof bytes
+    bit-exact vs CPU": every word of the HIP proof equals the oracle's proof of the same ProverInput; determinism (two
+    runs give identical words); both verifiers accept, a tampered proof is rejected."""
     inp = synth_fibonacci(100_000)
     assert inp.steps == 1_000_012
     dev = backend.upload_input(inp)
@@ -81,7 +81,11 @@ def test_full_size_proof_properties(backend, oracle):
     assert np.array_equal(w1, w2)
     st = p1.stats()
     assert st["steps"] == 1_000_012 and st["cells"] > 4e7
-    # the oracle VERIFIER is cheap at any size: the full-size HIP proof must verify, a tampered one must not
+    want, cells = oracle.prove(inp.view)
+    assert cells == st["cells"]
+    assert w1.size == want.size
+    diff = np.nonzero(w1 != want)[0]
+    assert diff.size == 0, f"first differing words {diff[:5]}"
     rc, err = oracle.verify(w1)
     assert rc == 0, err
     bad = w1.copy()
@@ -92,7 +96,47 @@ def test_full_size_proof_properties(backend, oracle):
     inp.free()
 
 
-def test_metric_config_proof_verifies(backend, oracle):
+def test_live_clock_update_rows_bit_exact(backend, oracle):
+    """clock-update rows only exist when a cell is re-accessed more than 2^20 - 1 steps after its previous
+    access (components/clock_update.rs:77-166).  fibonacci_loop(110 000) = 1 100 012 steps: the return pc / fp slots
+    written by the entry frame are read by `ret` at the very end, so the segment carries LIVE clock-update rows.  The
+    clock_update component's trace and LogUp columns, and the whole proof, must equal the oracle's."""
+    C_CLOCK_UPDATE = 28
+    from cairo_m_amd.lib import RELATION_WORDS
+    inp = synth_fibonacci(110_000)
+    assert inp.steps == 1_100_012
+    n_upd = prover_input_arrays(inp.view)["clock_updates"].shape[0]
+    assert n_upd >= 2, "the workload must carry live clock-update rows"
+    dev = backend.upload_input(inp)
+    n_tr, n_it, _ = backend.component_info(C_CLOCK_UPDATE)
+    log = backend.component_log_size(dev, C_CLOCK_UPDATE)
+    cols = [backend.col_alloc(1 << log) for _ in range(n_tr)]
+    backend.trace_write(dev, C_CLOCK_UPDATE, cols)
+    got = np.stack([backend.download(h, 1 << log) for h in cols])
+    want = oracle.component_trace(inp.view, C_CLOCK_UPDATE)
+    assert np.array_equal(got, want)
+    assert int(got[0].sum()) == n_upd          # enabler column: one live row per clock update
+    rng = np.random.default_rng(28)
+    rel = rng.integers(0, 2**31 - 1, size=RELATION_WORDS, dtype=np.uint32)
+    pp = [backend.col_alloc(1 << 4) for _ in range(7)]      # clock_update reads no preprocessed column
+    out = [backend.col_alloc(1 << log) for _ in range(n_it)]
+    cs = backend.interaction_write(C_CLOCK_UPDATE, cols, pp, log, rel, out)
+    got_it = np.stack([backend.download(h, 1 << log) for h in out])
+    want_it, want_cs = oracle.component_interaction(inp.view, C_CLOCK_UPDATE, rel, n_it, log)
+    assert np.array_equal(got_it, want_it) and np.array_equal(cs, want_cs)
+    for h in cols + pp + out:
+        backend.col_free(h)
+    p = backend.prove_device(dev)
+    w = p.words()
+    want_w, _ = oracle.prove(inp.view)
+    assert w.size == want_w.size and np.array_equal(w, want_w)
+    assert p.verify()[0] == 0
+    p.free()
+    backend.free_input(dev)
+    inp.free()
+
+
+def test_metric_config_proof_bit_exact(backend, oracle):
     """BASELINE metric config (fibonacci_loop n = 419 000, 4 190 012 steps, 2^22 rows): the HIP proof is accepted
     by the oracle verifier; proofs from two concurrent host threads (the `pipelined` mode of bench.py: per-thread
     streams / pools) are identical to the single-threaded one."""
@@ -108,6 +152,12 @@ def test_metric_config_proof_verifies(backend, oracle):
     rc, err = p0.verify()          # product-side verifier (cm_verify_proof)
     assert rc == 0, err
     p0.free()
+    # bit-exact at the metric config itself: the oracle proves the same 4.19 M-step ProverInput (~15 s on 16 threads)
+    want, cells = oracle.prove(inp.view)
+    assert cells == 200_152_208 and want.size == w0.size
+    diff = np.nonzero(w0 != want)[0]
+    assert diff.size == 0, f"first differing words {diff[:5]}"
+    del want
     out = [None, None]
 
     def work(i):

@@ -9,9 +9,10 @@ import pytest
 from cairo_m_amd.lib import load_library, synth_fibonacci, vm_run
 
 
-def _verify(L, words):
+def _verify(L, words, cfg=None):
     w = np.ascontiguousarray(words, dtype=np.uint32)
-    rc = L.cm_verify_proof_words(w.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint64(w.size))
+    rc = L.cm_verify_proof_words(w.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint64(w.size),
+                                 (C.c_uint32 * 4)(*cfg) if cfg else None)
     buf = C.create_string_buffer(512)
     L.cm_last_error(buf, C.c_size_t(512))
     return rc, buf.value.decode(errors="replace")
@@ -58,9 +59,11 @@ def test_nonzero_last_layer_degree_bound(oracle, bound):
     inp = synth_fibonacci(7)
     cfg = (5, 1, bound, 20)
     words, _ = oracle.prove(inp.view, cfg=cfg)
-    assert oracle.verify(words)[0] == 0
-    rc, err = _verify(L, words)
+    assert oracle.verify(words, cfg)[0] == 0
+    rc, err = _verify(L, words, cfg)
     assert rc == 0, err
+    # a verifier expecting REGULAR_96_BITS refuses a proof made under this (weaker) config
+    assert _verify(L, words)[0] != 0 and oracle.verify(words)[0] != 0
     # locate the last-layer polynomial: its (count, 4*count words, log_size) record is unique in the stream
     n = 1 << bound
     hits = [i for i in range(words.size - 4 * n - 1) if words[i] == n and words[i + 1 + 4 * n] == bound
@@ -69,5 +72,40 @@ def test_nonzero_last_layer_degree_bound(oracle, bound):
     for k in range(4 * n):
         bad = words.copy()
         bad[hits[-1] + 1 + k] ^= 1
-        assert _verify(L, bad)[0] != 0 and oracle.verify(bad)[0] != 0
+        assert _verify(L, bad, cfg)[0] != 0 and oracle.verify(bad, cfg)[0] != 0
+    inp.free()
+
+
+def test_verifier_does_not_take_the_security_level_from_the_proof(oracle):
+    """verify_cairo_m takes pcs_config from the CALLER (verifier.rs:17-31).  A proof made with (pow_bits 0, 1 query) is a
+    valid proof under that config and must be rejected by a verifier expecting REGULAR_96_BITS — and rewriting the config
+    words of the stream to claim REGULAR_96_BITS does not help (the transcript and the query count no longer match)."""
+    L = load_library()
+    inp = synth_fibonacci(5)
+    weak = (0, 1, 0, 1)
+    words, _ = oracle.prove(inp.view, cfg=weak)
+    assert _verify(L, words, weak)[0] == 0 and oracle.verify(words, weak)[0] == 0
+    rc, err = _verify(L, words)
+    assert rc != 0 and "config" in err
+    assert oracle.verify(words)[0] != 0
+    forged = words.copy()
+    assert list(forged[1:5]) == [0, 1, 0, 1]
+    forged[1:5] = [16, 1, 0, 80]
+    assert _verify(L, forged)[0] != 0 and oracle.verify(forged)[0] != 0
+    inp.free()
+
+
+def test_public_data_words_must_be_canonical(oracle):
+    """proof_from_words rejects public-data words >= P (M31(x) needs x < P: P would alias 0, 2^31 would alias 1)."""
+    L = load_library()
+    inp = synth_fibonacci(5)
+    words, _ = oracle.prove(inp.view)
+    assert _verify(L, words)[0] == 0
+    n_comp = int(words[5])
+    base = 6 + n_comp + 4 * n_comp           # magic, cfg[4], count, log sizes, claimed sums -> public data scalars
+    for k in range(7):
+        bad = words.copy()
+        bad[base + k] = bad[base + k] + (2**31 - 1) if bad[base + k] < 2**31 - 1 else bad[base + k]
+        rc, err = _verify(L, bad)
+        assert rc != 0 and "malformed" in err, (k, err)
     inp.free()
