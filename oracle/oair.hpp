@@ -1,6 +1,7 @@
 // ORACLE (test infrastructure).  CPU evaluators over the shared AIR descriptions
-// (cairo_m_amd/csrc/air/*.hpp restate the reference's component files; the evaluators below restate
-// Stwo's constraint framework and are written independently of the HIP evaluators):
+// (cairo_m_amd/csrc/air/*.hpp restate the reference's component files — their `eval` half is pinned to vectors derived
+// mechanically from the reference's evaluate() text, tests/golden/air_eval_vectors.json; the evaluators below restate
+// Stwo's constraint framework, incl. the oracle's own LogUp batching (ologup.hpp), independently of the HIP evaluators):
 //   * trace generation            <- Claim::write_trace  (crates/prover/src/components/mod.rs:106-194)
 //   * rc / bitwise histograms     <- range_check_macro.rs:62-112, preprocessed/bitwise.rs:72-157
 //   * LogUp interaction trace     <- InteractionClaim::write_interaction_trace (components/mod.rs:198-281)
@@ -14,6 +15,7 @@
 #pragma once
 #include "ofield.hpp"
 #include "ocircle.hpp"
+#include "ologup.hpp"
 #include "../cairo_m_amd/csrc/air/components.hpp"
 #include "../include/cairom_hip.h"
 #include <vector>
@@ -96,7 +98,7 @@ struct NoEF {};
 inline NoEF operator*(NoEF, NoEF) { return {}; }
 inline NoEF operator*(NoEF, M31) { return {}; }
 inline NoEF operator+(NoEF, NoEF) { return {}; }
-struct HistEval : air::LogupStream<HistEval, M31, NoEF> {
+struct HistEval : LogupAtRow<HistEval, M31, NoEF> {
   const std::vector<Col>* cols;
   size_t row;
   int ci = 0;
@@ -129,8 +131,45 @@ struct HistEval : air::LogupStream<HistEval, M31, NoEF> {
   void emit_batch(bool, NoEF, NoEF) {}
 };
 
+// Row dump: constraint values and relation entries of one row in evaluation order (golden-vector replay,
+// tests/test_air_eval_golden.py).
+struct DumpEval : LogupAtRow<DumpEval, M31, NoEF> {
+  const uint32_t* row;
+  const uint32_t* ppv;
+  int ci = 0;
+  std::vector<uint32_t>* constraints;
+  std::vector<uint32_t>* entries;   // per entry: relation id, multiplicity, n, values...
+  int n_batches = 0;
+  M31 next() { return M31::raw(row[ci++]); }
+  M31 preproc(int id) { return M31::raw(ppv[id]); }
+  M31 c(uint32_t v) { return M31::raw(v); }
+  void constraint(M31 x) { constraints->push_back(x.v); }
+  NoEF combine(int, const M31*, int) { return {}; }
+  NoEF ef_from(M31) { return {}; }
+  void on_entry(int rel, M31 mult, const M31* v, int n) {
+    entries->push_back((uint32_t)rel); entries->push_back(mult.v); entries->push_back((uint32_t)n);
+    for (int i = 0; i < n; i++) entries->push_back(v[i].v);
+  }
+  void emit_batch(bool, NoEF, NoEF) { n_batches++; }
+};
+template <class C>
+int dump_row(const uint32_t* row, const uint32_t* ppv, std::vector<uint32_t>& cons, std::vector<uint32_t>& ents) {
+  DumpEval e;
+  e.row = row; e.ppv = ppv; e.constraints = &cons; e.entries = &ents;
+  C::eval(e);
+  return e.n_batches;
+}
+inline int dump_row_dispatch(int cid, const uint32_t* row, const uint32_t* ppv, std::vector<uint32_t>& cons, std::vector<uint32_t>& ents) {
+  switch (cid) {
+#define ORC_X(id, T) case air::id: return dump_row<air::T>(row, ppv, cons, ents);
+    AIR_ALL_COMPONENTS(ORC_X)
+#undef ORC_X
+  }
+  return -1;
+}
+
 // LogUp column generator (Stwo LogupTraceGenerator): column j = column j-1 + num/den.
-struct LogupGenEval : air::LogupStream<LogupGenEval, M31, QM31> {
+struct LogupGenEval : LogupAtRow<LogupGenEval, M31, QM31> {
   const std::vector<Col>* cols;
   const std::vector<Col>* pp;  // preprocessed columns (trace domain), indexed by PreprocId
   size_t row;
@@ -231,7 +270,7 @@ inline void run_hist_dispatch(const ComponentTrace& ct, HistTables& h, std::stri
 // Generic row evaluator: reads columns at `row` of storage of log `eval_log` (trace domain when
 // eval_log == trace_log, LDE otherwise).  Accumulates sum_k coeff[k] * C_k (coeff = 1 => assert mode collects
 // the first non-zero constraint instead).
-struct RowConstraintEval : air::LogupStream<RowConstraintEval, M31, QM31> {
+struct RowConstraintEval : LogupAtRow<RowConstraintEval, M31, QM31> {
   const std::vector<const M31*>* tr;  // tree-1 columns of the component
   const std::vector<const M31*>* it;  // tree-2 columns
   const M31* const* pp;               // preprocessed columns by PreprocId (same log as the component)
@@ -279,7 +318,7 @@ struct RowConstraintEval : air::LogupStream<RowConstraintEval, M31, QM31> {
 };
 
 // Point evaluator (F = QM31) over OODS mask values.
-struct PointEval : air::LogupStream<PointEval, QM31, QM31> {
+struct PointEval : LogupAtRow<PointEval, QM31, QM31> {
   const QM31* tr;           // tree-1 sampled values (offset 0), one per column
   const QM31* it;           // tree-2 sampled values, flattened in mask order (see build_mask_layout)
   const QM31* pp;           // preprocessed sampled values by PreprocId

@@ -43,6 +43,23 @@ int orc_verify(const uint32_t* words, uint64_t n, const uint32_t* cfg) {
   } catch (const std::exception& e) { g_err = e.what(); return 3; }
 }
 
+// One row through a component's AIR description: constraint values (add_constraint order) and relation entries
+// (relation id, multiplicity, n, values...) in add_to_relation order.  Returns the number of LogUp batches, -1 on error.
+int orc_component_eval_row(int cid, const uint32_t* row, const uint32_t* preproc7, uint32_t* cons_out, uint32_t* n_cons,
+                           uint32_t* ents_out, uint32_t* n_ent_words, uint32_t cap) {
+  try {
+    std::vector<uint32_t> cons, ents;
+    int nb = dump_row_dispatch(cid, row, preproc7, cons, ents);
+    if (cons.size() > cap || ents.size() > cap) { g_err = "orc_component_eval_row: output buffer too small"; return -1; }
+    memcpy(cons_out, cons.data(), cons.size() * 4);
+    memcpy(ents_out, ents.data(), ents.size() * 4);
+    *n_cons = (uint32_t)cons.size();
+    *n_ent_words = (uint32_t)ents.size();
+    return nb;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+const char* orc_component_name(int cid) { return air::component_name(cid); }
+
 // AIR consistency check without PCS (reference: debug_tools/assert_constraints.rs, tests/prover.rs:351-370):
 // relations drawn from a default channel, every constraint must vanish on every row, LogUp sums cancel.
 int orc_assert_constraints(const cm_prover_input* in) {

@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Golden WITNESS vectors for the opcode components, derived mechanically from the reference's `Claim::write_trace`.
+
+For every opcode component whose row closure has the regular shape
+    .for_each(|(row_index, (mut row, input, lookup_data))| { ... })
+this script reads the closure body from /root/reference (AT GENERATION TIME ONLY), parses it with the Rust-subset
+interpreter of tools/rsref/rs_interp.py and executes it lane-wise (N_LANES = 16) on the packed bundles of a synthetic
+all-opcode program run (cairo_m_amd/workloads.py::all_opcodes_program on the product's synthetic VM + host adapter).
+Helper semantics restated here, each a few lines: `Pack::pack` (utils/execution_bundle.rs:29-75), `get_access_field`
+(utils/data_accesses.rs:10-28), `Enabler::packed_at` (utils/enabler.rs:57-75), `ExecutionBundle::default()`
+(adapter/memory.rs:112-124: Ret, all-zero) for the padding lanes.
+
+Output: tests/golden/air_witness_vectors.npz — for every component the expected trace cells `<name>` of shape
+(n_trace_columns, 2^log_size) plus the program parameters; data only.  tests/test_air_witness_golden.py re-runs the
+same program through the VM + adapter, asks the oracle for each component's trace and requires equality cell by cell
+(live AND padding rows).  store_fp_fp / store_fp_imm pre-compute per-lane hints outside the closure and are covered by
+the hand-written numpy model of tests/test_air_hot_independent.py instead.
+
+Usage (build container only):  python tools/rsref/rs_witness.py
+"""
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from rs_interp import Env, Felt, Interp, Packed, Struct, N_LANES, parse_block, parse_expr, standard_globals  # noqa: E402
+from rs_eval import REF, extract_fn_body, opcode_constants, strip_comments  # noqa: E402
+
+ITERS = 21          # 21 live rows per single-use component: one full packed row + a partial one (padding lanes)
+SEED = 0xC0FFEE
+
+# air::ComponentId order (components/opcodes/mod.rs:223-268) -> reference file
+OPCODE_FILES = [
+    "assert_eq_fp_imm", "call_abs_imm", "jmp_imm", "jnz_fp_imm", "ret", "store_imm", "store_fp_fp", "store_fp_imm",
+    "double_deref_fp_imm", "double_deref_fp_fp", "store_frame_pointer", "u32_store_imm", "u32_store_add_fp_imm",
+    "u32_store_mul_fp_imm", "u32_store_div_fp_imm", "u32_store_eq_fp_fp", "u32_store_eq_fp_imm", "u32_store_lt_fp_imm",
+    "u32_store_lt_fp_fp", "u32_store_add_fp_fp", "u32_store_sub_fp_fp", "u32_store_mul_fp_fp", "u32_store_div_fp_fp",
+    "u32_store_bitwise_fp_fp", "u32_store_bitwise_fp_imm", "store_le_fp_imm"]
+CLOSURE_RE = r"\.for_each\(\|\(row_index, \(mut row, input, lookup_data\)\)\| \{"
+
+
+class Enabler:
+    """utils/enabler.rs:57-75"""
+
+    def __init__(self, padding_offset):
+        self.padding_offset = padding_offset
+
+    def packed_at(self, vec_row):
+        off = vec_row * N_LANES
+        return Packed([Felt(1 if off + i < self.padding_offset else 0) for i in range(N_LANES)])
+
+
+def get_access_field(field):
+    """utils/data_accesses.rs:10-28: k-th access of each lane's span, or zero."""
+    def f(inp, data_accesses, k):
+        lanes = []
+        for i in range(N_LANES):
+            s, l = inp.span_start[i], inp.span_len[i]
+            lanes.append(getattr(data_accesses[s + k], field) if k < l else Felt(0))
+        return Packed(lanes)
+    return f
+
+
+class Slots:
+    """`row` / `lookup_data.<kind>`: indexable, grows on assignment."""
+
+    def __init__(self):
+        self.d = {}
+
+    def __setitem__(self, i, v):
+        self.d[i] = v
+
+    def __getitem__(self, i):
+        return self.d[i]
+
+
+class LookupData:
+    def __init__(self):
+        for k in ("memory", "registers", "range_check_8", "range_check_16", "range_check_20", "bitwise", "merkle", "poseidon2"):
+            setattr(self, k, Slots())
+
+
+def file_consts(src, interp):
+    env = Env()
+    for m in re.finditer(r"^(?:pub(?:\([a-z]+\))? )?const ([A-Z0-9_]+): (?:u32|usize|u64|i32) = ([^;]+);", src, re.M):
+        try:
+            interp.g[m.group(1)] = interp.eval(parse_expr(m.group(2)), env)
+        except Exception:
+            pass
+
+
+def pack(bundles, row):
+    """Pack::pack for packed row `row` (utils/execution_bundle.rs:29-75); padding lanes = ExecutionBundle::default()."""
+    lanes = []
+    for i in range(N_LANES):
+        r = row * N_LANES + i
+        if r < len(bundles):
+            lanes.append([int(x) for x in bundles[r]])
+        else:
+            lanes.append([0, 0, 0, 0, 11, 0, 0, 0, 0, 0, 0, 0])      # Ret (opcode 11), span (0, 0)
+    col = lambda k: Packed([Felt(l[k]) for l in lanes])
+    return Struct(pc=col(0), fp=col(1), clock=col(2), inst_prev_clock=col(3), inst_value_0=col(4), inst_value_1=col(5),
+                  inst_value_2=col(6), inst_value_3=col(7), inst_value_4=col(8), inst_value_5=col(9),
+                  span_start=[l[10] for l in lanes], span_len=[l[11] for l in lanes])
+
+
+def interpret_component(fname, bundles, accesses, consts):
+    src = strip_comments(open(f"{REF}/prover/src/components/opcodes/{fname}.rs").read())
+    m = re.search(CLOSURE_RE, src)
+    if not m:
+        return None
+    body = extract_fn_body(src, CLOSURE_RE)
+    g = standard_globals()
+    g.update(consts)
+    interp = Interp(g)
+    file_consts(src, interp)
+    for f in ("value", "prev_value", "prev_clock", "address"):
+        g[f"get_{f}"] = get_access_field(f)
+    n_cols = g["N_TRACE_COLUMNS"]
+    n = len(bundles)
+    log_size = max(4, (max(n, 1) - 1).bit_length())
+    n_rows = 1 << log_size
+    block = parse_block("{" + body + "}")
+    data_accesses = [Struct(address=Felt(a[0]), prev_clock=Felt(a[1]), prev_value=Felt(a[2]), value=Felt(a[3])) for a in accesses]
+    out = np.zeros((n_cols, n_rows), dtype=np.uint32)
+    # the `let`s of write_trace in front of the closure that the closure captures
+    outer = Env()
+    outer.vars.update({"zero": Packed.broadcast(Felt(0)), "one": Packed.broadcast(Felt(1)), "enabler_col": Enabler(n),
+                       "data_accesses": data_accesses})
+    wt = extract_fn_body(src, r"pub fn write_trace<MC: MerkleChannel>\(")
+    for lm in re.finditer(r"\n\s{8}let (\w+) = (PackedM31::from\([^;]+\));", wt[:wt.index(".for_each(")]):
+        outer.vars[lm.group(1)] = interp.eval(parse_expr(lm.group(2)), outer)
+    for vec_row in range(n_rows // N_LANES):
+        env = Env(outer)
+        row, ld = Slots(), LookupData()
+        env.vars.update({"row_index": vec_row, "row": row, "input": pack(bundles, vec_row), "lookup_data": ld})
+        interp.eval(block, env)
+        assert sorted(row.d) == list(range(n_cols)), (fname, sorted(row.d))
+        for c in range(n_cols):
+            out[c, vec_row * N_LANES:(vec_row + 1) * N_LANES] = [x.v for x in row.d[c].lanes]
+    return out
+
+
+def interpret_builtin(fname, rows, n_live, consts):
+    """memory.rs / merkle.rs / clock_update.rs: `input` is the packed array of input columns built in front of the closure
+    (memory.rs:104-133, merkle.rs:103-132, clock_update.rs:86-104: rows padded with zeros, transposed 16 at a time)."""
+    src = strip_comments(open(f"{REF}/prover/src/components/{fname}.rs").read())
+    body = extract_fn_body(src, CLOSURE_RE)
+    g = standard_globals()
+    g.update(consts)
+    interp = Interp(g)
+    file_consts(src, interp)
+    n_cols = g["N_TRACE_COLUMNS"]
+    log_size = max(4, (max(n_live, 1) - 1).bit_length())
+    n_rows = 1 << log_size
+    block = parse_block("{" + body + "}")
+    outer = Env()
+    outer.vars.update({"zero": Packed.broadcast(Felt(0)), "one": Packed.broadcast(Felt(1)), "enabler_col": Enabler(n_live)})
+    wt = src[:src.index(".for_each(|(row_index")]
+    for lm in re.finditer(r"\n\s{8}let (\w+) = ((?:PackedM31|M31)::[^;]+);", wt):
+        try:
+            outer.vars[lm.group(1)] = interp.eval(parse_expr(lm.group(2)), outer)
+        except Exception:
+            pass
+    width = rows.shape[1] if len(rows) else 0
+    out = np.zeros((n_cols, n_rows), dtype=np.uint32)
+    for vec_row in range(n_rows // N_LANES):
+        lanes = [[int(x) for x in rows[vec_row * N_LANES + i]] if vec_row * N_LANES + i < len(rows) else [0] * width for i in range(N_LANES)]
+        inp = [Packed([Felt(l[k]) for l in lanes]) for k in range(width)]
+        env = Env(outer)
+        row, ld = Slots(), LookupData()
+        env.vars.update({"row_index": vec_row, "row": row, "input": inp, "lookup_data": ld})
+        interp.eval(block, env)
+        assert sorted(row.d) == list(range(n_cols)), (fname, sorted(row.d))
+        for c in range(n_cols):
+            out[c, vec_row * N_LANES:(vec_row + 1) * N_LANES] = [x.v for x in row.d[c].lanes]
+    return out
+
+
+def main():
+    from cairo_m_amd.lib import prover_input_arrays, vm_run
+    from cairo_m_amd.workloads import all_opcodes_program
+    prog, steps = all_opcodes_program(ITERS, SEED)
+    inp = vm_run(prog, entry_pc=0, args=(), n_returns=0)
+    assert inp.steps == steps
+    arrs = prover_input_arrays(inp.view)
+    consts = opcode_constants()
+    out = {"iters": np.array([ITERS]), "seed": np.array([SEED]), "steps": np.array([steps])}
+    for cid, fname in enumerate(OPCODE_FILES):
+        cols = interpret_component(fname, arrs[f"bundles{cid}"], arrs["data_accesses"], consts)
+        if cols is None:
+            print(f"{cid:2d} {fname:28s} (irregular closure: covered by tests/test_air_hot_independent.py)")
+            continue
+        out[fname] = cols
+        print(f"{cid:2d} {fname:28s} {arrs[f'bundles{cid}'].shape[0]:4d} live rows -> {cols.shape[0]} columns x {cols.shape[1]} rows")
+    # builtins with a regular closure: memory (rows = initial ++ final cells), merkle (initial ++ final tree nodes), clock_update
+    consts2 = dict(consts)
+    consts2.update({"TREE_HEIGHT": 30, "RC20_LIMIT": (1 << 20) - 1})       # adapter/merkle.rs:58-62, adapter/memory.rs:16
+    roots = arrs["roots"]
+    def mem_rows(a, root):      # cm_memory_cell = (address, value[4], clock, multiplicity) -> [address, clock, v0..v3, multiplicity, root]
+        return np.array([[r[0], r[5], r[1], r[2], r[3], r[4], r[6], root] for r in a], dtype=np.int64).reshape(-1, 8)
+    def tree_rows(a, root):     # cm_merkle_node (8 words) + root
+        return np.array([list(r) + [root] for r in a], dtype=np.int64).reshape(-1, 9)
+    mem = np.concatenate([mem_rows(arrs["initial_memory"], roots[0]), mem_rows(arrs["final_memory"], roots[1])])
+    tree = np.concatenate([tree_rows(arrs["initial_tree"], roots[0]), tree_rows(arrs["final_tree"], roots[1])])
+    # clock updates: the small program has none, so the vector is made from synthetic entries (address, prev_clock, value[4])
+    cu = np.array([[100 + k, 7 * k + 1, 3 * k, k, 0, k + 5] for k in range(19)], dtype=np.int64)
+    for name, rows in (("memory", mem), ("merkle", tree), ("clock_update", cu)):
+        out[name] = interpret_builtin(name, rows, len(rows), consts2)
+        print(f"   {name:28s} {len(rows):4d} live rows -> {out[name].shape[0]} columns x {out[name].shape[1]} rows")
+    out["clock_update_input"] = cu.astype(np.uint32)
+    inp.free()
+    path = os.path.join(ROOT, "tests", "golden", "air_witness_vectors.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
