@@ -339,16 +339,26 @@ void twiddles_destroy(Twiddles* t) {
   delete t;
 }
 
-constexpr uint32_t FFT_TILE_LOG = 11;   // 8 KiB of LDS per block
-constexpr uint32_t FFT_MAX_STRIDED_W = 7;
+constexpr uint32_t FFT_TILE_LOG = 11;        // tile of the generic LDS-sweep kernel (transforms below 2^11)
+constexpr uint32_t FFT_CONTIG_LOG = 12;      // layers of the contiguous pass: three radix-16 rounds (13 = 5 + 3 + 5 when that saves a sweep)
+constexpr uint32_t FFT_MAX_STRIDED_W = 9;    // a strided pass carries up to 9 layers (2^9 x 2^5 tile: 128-B runs, 64 KiB of LDS)
 
-// Plan: layers [0, k0) in one contiguous pass, the rest in strided passes of <= 7 layers.
+// Plan: layers [0, k0) in one contiguous pass, the rest in as few strided passes of <= 9 layers as possible, balanced.
+// Measured on 64 columns x 2^22 (tools/fft_lab.hip, us forward / inverse): contiguous 11 layers 616 / 681, 12 layers
+// 544 / 598, 13 layers 604 / 707; strided (2^14 tile) 6 layers 371, 7: 407, 8: 405 / 423, 9: 472 / 496, 10 (64-B runs):
+// 618 / 872.  So k0 = 12, except that a transform with exactly 22 layers takes 13 + 9 instead of 12 + 10.
+// A 2^21 transform is 12 + 9, a 2^22 one 13 + 9: two sweeps over HBM where the radix-8 plan (11 + 5 + 5 / 11 + 6 + 5) made
+// three.  CM_FFT_OLD_PLAN=1 restores the 11-layer contiguous pass and <= 7-layer strided passes (A/B).
 static void plan_passes(uint32_t n, std::vector<std::pair<uint32_t, uint32_t>>& passes) {
-  uint32_t k0 = n < FFT_TILE_LOG ? n : FFT_TILE_LOG;
+  static const bool old_plan = getenv("CM_FFT_OLD_PLAN") != nullptr;
+  uint32_t contig = old_plan ? 11u : FFT_CONTIG_LOG;
+  const uint32_t max_w = old_plan ? 7u : FFT_MAX_STRIDED_W;
+  if (!old_plan && n == contig + max_w + 1) contig++;
+  uint32_t k0 = n < contig ? n : contig;
   passes.push_back({0, k0});
   uint32_t rest = n - k0;
   if (rest == 0) return;
-  uint32_t np = (rest + FFT_MAX_STRIDED_W - 1) / FFT_MAX_STRIDED_W;
+  uint32_t np = (rest + max_w - 1) / max_w;
   uint32_t lo = k0;
   for (uint32_t i = 0; i < np; i++) {
     uint32_t w = (rest - (lo - k0) + (np - i) - 1) / (np - i);
@@ -365,8 +375,10 @@ static void launch_pass(const uint32_t* const* d_src, uint32_t* const* d_dst, ui
   a.ytw = INV ? tw.iytw : tw.ytw;
   a.R = tw.R; a.n = n; a.lo = lo; a.hi = hi;
   uint32_t W = hi - lo;
+  const uint32_t rb = fft_pass_rb_tile_log(W, lo);
   uint32_t M = 0;
-  if (lo > 0) { M = FFT_TILE_LOG - W; if (M > lo) M = lo; }
+  if (rb) M = rb - W;
+  else if (lo > 0) { M = FFT_TILE_LOG - W; if (M > lo) M = lo; }
   a.M = M; a.in_len = in_len; a.scale = scale;
   uint32_t tile_log = W + M;
   uint32_t ntiles = 1u << (n - tile_log);
@@ -375,7 +387,7 @@ static void launch_pass(const uint32_t* const* d_src, uint32_t* const* d_dst, ui
   KProfScope kp(INV ? "k_fft_pass<ifft>" : "k_fft_pass<fft>",
                 4.0 * ncols * ((double)(1u << n) + (double)(in_len < (1u << n) ? in_len : (1u << n))), st,
                 /* butterflies */ (double)ncols * (double)(1u << (n - 1)) * (double)(hi - lo));
-  if (tile_log == FFT_TILE_LOG && fft_pass_r8_supported(W, M, lo)) launch_fft_pass_r8(INV, a, ntiles, ncols, st);
+  if (rb) launch_fft_pass_rb(INV, a, rb, ntiles, ncols, st);
   else hipLaunchKernelGGL(k_fft_pass<INV>, dim3(ntiles, ncols), dim3(256), lds, st, a);
 }
 void interpolate_oop(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n, const Twiddles& tw,

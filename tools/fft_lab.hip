@@ -1,4 +1,4 @@
-// FFT pass lab (development tool): times k_fft_pass_r8 on 64 columns of 2^22 words and, when built with
+// FFT pass lab (development tool): times k_fft_pass_rb on 64 columns of 2^22 words and, when built with
 // -DCM_FFT_ABL_NO_TW / -DCM_FFT_ABL_NO_LDS, the same kernel without twiddle fetches / LDS exchanges (wrong results,
 // timing only) to see what a butterfly's ~55 cycles are made of.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I cairo_m_amd/csrc [-DCM_FFT_ABL_...] tools/fft_lab.hip -o tools/fft_lab
@@ -20,21 +20,28 @@ int main() {
   uint32_t** d_ptrs;
   CK(hipMalloc(&d_ptrs, ncols * 8));
   CK(hipMemcpy(d_ptrs, ptrs.data(), ncols * 8, hipMemcpyHostToDevice));
-  struct Case { const char* name; bool inv; uint32_t lo, hi; } cases[] = {
-      {"fwd  contiguous 11 layers", false, 0, 11}, {"fwd  strided 5 layers (M=6)", false, 11, 16}, {"fwd  strided 6 layers (M=5)", false, 16, 22},
-      {"inv  contiguous 11 layers", true, 0, 11}, {"inv  strided 5 layers (M=6)", true, 11, 16}};
+  struct Case { const char* name; bool inv; uint32_t lo, hi, tl; } cases[] = {
+      {"fwd  contiguous 11 (TL11 r8)", false, 0, 11, 11}, {"fwd  strided 5 (TL11 M=6)", false, 11, 16, 11}, {"fwd  strided 6 (TL11 M=5)", false, 16, 22, 11},
+      {"inv  contiguous 11 (TL11 r8)", true, 0, 11, 11}, {"inv  strided 5 (TL11 M=6)", true, 11, 16, 11},
+      {"fwd  contiguous 12 (TL12 r16)", false, 0, 12, 12}, {"inv  contiguous 12 (TL12 r16)", true, 0, 12, 12},
+      {"fwd  contiguous 13 (TL13 r32)", false, 0, 13, 13}, {"inv  contiguous 13 (TL13 r32)", true, 0, 13, 13},
+      {"fwd  strided 9 (TL14 M=5)", false, 13, 22, 14}, {"inv  strided 9 (TL14 M=5)", true, 13, 22, 14},
+      {"fwd  strided 8 (TL14 M=6)", false, 13, 21, 14}, {"inv  strided 8 (TL14 M=6)", true, 13, 21, 14},
+      {"fwd  strided 7 (TL14 M=7)", false, 13, 20, 14}, {"fwd  strided 6 (TL14 M=8)", false, 13, 19, 14},
+      {"fwd  strided 7 (TL11 M=4)", false, 13, 20, 11}, {"fwd  strided 6 (TL11 M=5)", false, 13, 19, 11}};
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& c : cases) {
     FftPassArgs a;
     a.src = (const uint32_t* const*)d_ptrs; a.dst = d_ptrs; a.xtw = xtw; a.ytw = ytw; a.R = R; a.n = n; a.lo = c.lo; a.hi = c.hi;
     uint32_t W = c.hi - c.lo;
-    a.M = c.lo ? 11 - W : 0; a.in_len = 1u << n; a.scale = 1;
-    uint32_t ntiles = 1u << (n - 11);
-    launch_fft_pass_r8(c.inv, a, ntiles, ncols, 0);
+    const uint32_t rb = c.tl;
+    a.M = rb - W; a.in_len = 1u << n; a.scale = 1;
+    uint32_t ntiles = 1u << (n - rb);
+    launch_fft_pass_rb(c.inv, a, rb, ntiles, ncols, 0);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 5; i++) launch_fft_pass_r8(c.inv, a, ntiles, ncols, 0);
+    for (int i = 0; i < 5; i++) launch_fft_pass_rb(c.inv, a, rb, ntiles, ncols, 0);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
