@@ -1624,6 +1624,17 @@ int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words, const cm_
     if (!e.empty()) throw cm::CmError(11, "verification failed: " + e);
   });
 }
+// proof object from its flat word stream (cm_proof_words format): host code, no GPU needed — lets a verifier-side process
+// re-serialise a received proof (cm_proof_json) or hand it to cm_verify_proof
+int32_t cm_proof_from_words(const uint32_t* words, uint64_t n_words, cm_proof** out) {
+  return pguard([&] {
+    std::unique_ptr<cm_proof> p(new cm_proof());
+    p->d = new cm::ProofData();
+    std::string e;
+    if (!cm::proof_from_words(words, n_words, *p->d, e)) throw cm::CmError(11, "cm_proof_from_words: " + e);
+    *out = p.release();
+  });
+}
 int32_t cm_proof_free(cm_proof* p) { if (p) { delete p->d; delete p; } return 0; }
 int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out) {
   return pguard([&] {

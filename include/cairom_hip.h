@@ -227,6 +227,8 @@ int32_t cm_set_preprocessed_cache(int32_t on);
  * default (pool memory, on a side stream next to trace generation).  on = keep one table per domain size for the whole
  * process (env CM_TWIDDLE_CACHE=1 sets the initial value).  Off in every quoted number.  Proof bytes are identical. */
 int32_t cm_set_twiddle_cache(int32_t on);
+/* Proof object from its flat word stream (host code, no GPU): re-serialise with cm_proof_json / verify with cm_verify_proof. */
+int32_t cm_proof_from_words(const uint32_t* words, uint64_t n_words, cm_proof** out);
 /* Flat u32 serialisation of the proof (format: cairo_m_amd/csrc/proof.hpp), used by the parity tests. */
 int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* n_out);
 /* JSON text of the proof; *len_out = length without the terminating NUL; the buffer is owned by
