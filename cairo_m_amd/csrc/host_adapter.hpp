@@ -281,6 +281,7 @@ inline uint32_t build_partial_merkle_tree(const std::map<uint32_t, MemState>& me
                                           std::vector<cm_merkle_node>& nodes) {
   struct MV { uint32_t value, mult; };
   std::map<uint32_t, MV> cur;
+  if (memory.empty()) return 0;   // the reference returns (empty tree, None) (adapter/merkle.rs:190-193); callers check `nodes`
   for (auto& kv : memory) {
     uint32_t addr = kv.first;
     bool pub = initial ? ((addr >= prog[0] && addr < prog[1]) || (addr >= inp[0] && addr < inp[1]))

@@ -2,6 +2,7 @@
 #include "../../include/cairom_hip.h"
 #include "host_adapter.hpp"
 #include <string>
+#include <string.h>
 
 struct cm_host_input {
   cm::host::ProverInputOwned owned;
@@ -178,6 +179,21 @@ int32_t cm_adapter_memory_script(const uint32_t* preload, uint32_t n_preload, co
         else for (int k = 1; k < 7; k++) q[k] = 0;
       }
     }
+    return 0;
+  } catch (const std::exception& e) { return cm_set_last_error(e.what()); }
+}
+// Test hook for the reference's partial-Merkle-tree shape tests (adapter/merkle.rs:302-423): cells = n x (addr, v0..v3);
+// nodes_out receives up to cap cm_merkle_node records (8 words each), *n_nodes the total, *root the root (0 when empty).
+int32_t cm_adapter_partial_tree(const uint32_t* cells, uint32_t n, int32_t initial, const uint32_t ranges[6], uint32_t* nodes_out,
+                                uint64_t cap, uint64_t* n_nodes, uint32_t* root) {
+  try {
+    std::map<uint32_t, cm::host::MemState> mem;
+    for (uint32_t i = 0; i < n; i++)
+      mem[cells[5 * i]] = cm::host::MemState{{cells[5 * i + 1], cells[5 * i + 2], cells[5 * i + 3], cells[5 * i + 4]}, 0u, 0u};
+    std::vector<cm_merkle_node> nodes;
+    *root = cm::host::build_partial_merkle_tree(mem, initial != 0, ranges, ranges + 2, ranges + 4, nodes);
+    *n_nodes = nodes.size();
+    for (size_t i = 0; i < nodes.size() && i < cap; i++) memcpy((void*)(nodes_out + 8 * i), (const void*)&nodes[i], 32);
     return 0;
   } catch (const std::exception& e) { return cm_set_last_error(e.what()); }
 }

@@ -181,6 +181,10 @@ int32_t cm_host_input_free(cm_host_input* h);
 int32_t cm_adapter_memory_script(const uint32_t* preload, uint32_t n_preload, const uint32_t* script, uint32_t n,
                                  uint32_t* results, uint32_t* n_clock_updates, uint32_t* clock_updates_out, uint32_t cu_cap,
                                  const uint32_t* query_addrs, uint32_t n_query, uint32_t* state_out);
+/* Test hook: build_partial_merkle_tree (crates/prover/src/adapter/merkle.rs:183-295) over n cells (addr, v0..v3); nodes_out
+ * = up to cap cm_merkle_node records, *n_nodes = their total count, *root = the root (0 for an empty memory). */
+int32_t cm_adapter_partial_tree(const uint32_t* cells, uint32_t n, int32_t initial, const uint32_t ranges[6], uint32_t* nodes_out,
+                                uint64_t cap, uint64_t* n_nodes, uint32_t* root);
 /* Poseidon2-M31 t=16 permutation in place (reference KAT: crates/prover/tests/poseidon2.rs:14-34). */
 int32_t cm_poseidon2_permute(uint32_t state[16]);
 

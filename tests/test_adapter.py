@@ -167,3 +167,44 @@ def test_compiled_program_json_roundtrip():
     assert all(np.array_equal(a[k], b[k]) if hasattr(a[k], "shape") else a[k] == b[k] for k in a)
     with pytest.raises(ValueError):
         load_program_json('{"data": [], "entrypoints": {}, "metadata": {}, "extra": 1}')
+
+
+def _partial_tree(cells, initial=True, ranges=(0, 0, 0, 0, 0, 0)):
+    import ctypes as C
+    from cairo_m_amd.lib import load_library
+    L = load_library()
+    c = np.ascontiguousarray(np.array(cells, dtype=np.uint32).reshape(-1, 5))
+    cap = 4096
+    out = np.zeros((cap, 8), dtype=np.uint32)
+    n, root = C.c_uint64(0), C.c_uint32(0)
+    u = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+    assert L.cm_adapter_partial_tree(u(c), C.c_uint32(c.shape[0]), C.c_int32(1 if initial else 0), (C.c_uint32 * 6)(*ranges), u(out),
+                                     C.c_uint64(cap), C.byref(n), C.byref(root)) == 0
+    return out[:n.value], root.value
+
+
+def test_partial_merkle_tree_shapes(oracle):
+    """The reference's build_partial_merkle_tree tests (adapter/merkle.rs:302-423), restated on the host builder: empty
+    memory -> empty tree; one cell -> nodes up to the root; two cells -> the depth-30 leaf pairs hold the QM31 words
+    (address a -> leaves 4a..4a+3); addresses 0 and 2^28 - 1 -> nodes at every depth 30..1.  Plus: the root equals the
+    hash chain recomputed with the oracle's Poseidon2 (pinned by the reference KAT)."""
+    nodes, root = _partial_tree([])
+    assert nodes.shape[0] == 0 and root == 0                                  # test_empty_tree
+    nodes, root = _partial_tree([[5, 42, 0, 0, 0]])                           # test_single_element_tree
+    assert nodes.shape[0] > 0 and root != 0
+    assert sorted(set(nodes[:, 1].tolist())) == list(range(1, 31))            # one path: every depth 30..1
+    nodes, root = _partial_tree([[0, 10, 11, 12, 13], [1, 20, 21, 22, 23]])   # test_multiple_elements_tree
+    find = lambda idx, depth: nodes[(nodes[:, 0] == idx) & (nodes[:, 1] == depth)][0]
+    assert find(0, 30)[2:4].tolist() == [10, 11] and find(2, 30)[2:4].tolist() == [12, 13] and find(4, 30)[2:4].tolist() == [20, 21]
+    nodes, root = _partial_tree([[0, 1, 0, 0, 0], [(1 << 28) - 1, 2, 0, 0, 0]])  # test_tree_builds_to_root
+    assert nodes[:, 1].min() == 1 and nodes[:, 1].max() == 30
+    # every node's parent_value = poseidon2(left, right)[0], and the depth-1 node's parent value is the root
+    for nd in nodes[::7]:
+        st = np.zeros(16, dtype=np.uint32)
+        st[0], st[1] = nd[2], nd[3]
+        assert oracle.poseidon2_permute(st)[0] == nd[4]
+    assert nodes[nodes[:, 1] == 1][0][4] == root
+    # multiplicities: leaves of a public (program-range) cell count twice in the initial tree (adapter/merkle.rs:210-223)
+    nodes, _ = _partial_tree([[3, 7, 0, 0, 0]], initial=True, ranges=(0, 8, 0, 0, 0, 0))
+    leaf = nodes[(nodes[:, 1] == 30) & (nodes[:, 0] == 12)][0]
+    assert leaf[5] == 2 and leaf[6] == 2

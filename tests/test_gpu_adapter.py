@@ -111,3 +111,52 @@ def test_large_boundary_memory_uses_device_trees(backend):
     assert a["initial_memory"].shape[0] >= 3000 and a["initial_tree"].shape[0] > 10_000
     _check(backend, hi, hs)
     hi.free(); hs.free()
+
+
+def test_runner_artifact_files_to_proof(backend, oracle, tmp_path):
+    """SURVEY 8 f-3 end to end: the runner's on-disk artifacts — binary trace ((fp, pc) LE u32 pairs, execution.rs:28-66),
+    binary memory trace (u32 program_length header + (address, 4 value words) records, io.rs:38-80) and the compiled
+    Program JSON (program.rs:143-170) — are written to files, read back, fed through cm_segment_from_artifacts ->
+    cm_adapt_segment_device -> cm_prove_device; the proof equals the oracle's proof of the in-memory host-adapted input."""
+    import ctypes as C
+    from cairo_m_amd.lib import HostSegment, load_program_json, program_to_json, vm_run, vm_segment
+    from tests.test_oracle_air import felt_program
+
+    class Seg(C.Structure):
+        _fields_ = [("trace", C.c_void_p), ("n_trace", C.c_uint64), ("memory_trace", C.c_void_p), ("n_memory_trace", C.c_uint64),
+                    ("initial_memory", C.c_void_p), ("n_initial_memory", C.c_uint64), ("ranges", C.c_uint32 * 6)]
+
+    L = backend.L
+    (tmp_path / "program.json").write_text(program_to_json(felt_program(), {"main": {"pc": 0, "returns": [{"name": "r", "ty": "Felt"}]}}))
+    cells, entry = load_program_json((tmp_path / "program.json").read_text())
+    main = entry["main"]
+    hs = vm_segment(cells, entry_pc=main["pc"], args=(), n_returns=main["n_returns"])
+    n = C.c_uint64(0)
+    L.cm_segment_serialize_trace(hs.view, None, C.c_uint64(0), C.byref(n))
+    tb = (C.c_uint8 * n.value)()
+    assert L.cm_segment_serialize_trace(hs.view, tb, C.c_uint64(n.value), C.byref(n)) == 0
+    L.cm_segment_serialize_memory_trace(hs.view, 1, None, C.c_uint64(0), C.byref(n))
+    mb = (C.c_uint8 * n.value)()
+    assert L.cm_segment_serialize_memory_trace(hs.view, 1, mb, C.c_uint64(n.value), C.byref(n)) == 0
+    (tmp_path / "trace.bin").write_bytes(bytes(tb))
+    (tmp_path / "memory.bin").write_bytes(bytes(mb))
+    s = C.cast(hs.view, C.POINTER(Seg)).contents
+    init = np.ctypeslib.as_array(C.cast(s.initial_memory, C.POINTER(C.c_uint32)), shape=(int(4 * s.n_initial_memory),)).copy()
+    ranges = (C.c_uint32 * 6)(*list(s.ranges))
+    hs.free()
+    # ---- a fresh reader: only the files (+ the initial memory / public ranges the reference keeps out of band)
+    t = (tmp_path / "trace.bin").read_bytes()
+    m = (tmp_path / "memory.bin").read_bytes()
+    h2 = C.c_void_p()
+    assert L.cm_segment_from_artifacts(t, C.c_uint64(len(t)), m, C.c_uint64(len(m)), 1, init.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       C.c_uint64(init.size // 4), ranges, C.byref(h2)) == 0
+    seg = HostSegment(L, h2)
+    dev = backend.adapt_segment(seg)
+    p = backend.prove_device(dev)
+    hi = vm_run(felt_program(), entry_pc=0, args=(), n_returns=1)
+    want, _ = oracle.prove(hi.view)
+    assert np.array_equal(p.words(), want)
+    assert p.verify()[0] == 0
+    p.free()
+    backend.free_input(dev)
+    seg.free(); hi.free()
