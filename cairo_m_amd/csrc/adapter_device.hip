@@ -8,7 +8,7 @@
 //   2. all log entries are sorted by (address, entry index) with one 64-bit radix sort (hipCUB): the
 //      predecessor in the sorted order IS the previous access of the cell (or the segment's initial memory);
 //   3. clock-update rows (gaps > 2^20 - 1) are counted per entry, scanned and scattered in log order;
-//   4. steps are bucketed per opcode component with a stable 5-bit radix sort, bundles and data accesses are
+//   4. steps are bucketed per (opcode component, opcode) with a stable 11-bit radix sort, bundles and data accesses are
 //      written straight into the device-resident ProverInput;
 //   5. one record per touched cell (first value, last value, last clock) is compacted for the host, which
 //      builds the boundary-memory rows, public multiplicities and the two partial Merkle trees (small:
@@ -40,7 +40,9 @@ __global__ void k_step_counts(const uint32_t* __restrict__ trace, uint32_t n_ste
   if (op >= 64u || !tab.valid[op]) { atomicOr(err, 1u); n_entries[t] = 0; n_acc[t] = 0; comp[t] = 0; return; }
   n_entries[t] = 1u + (tab.size[op] > 4 ? 1u : 0u) + tab.acc[op];
   n_acc[t] = tab.acc[op];
-  comp[t] = tab.comp[op];
+  // sort key: component, then opcode — inside a component the reference concatenates the bundles of its opcode variants in
+  // the order of `define_opcodes!` (components/opcodes/mod.rs:51-58, 223-268), which is ascending opcode id for every group
+  comp[t] = ((uint32_t)tab.comp[op] << 6) | op;
 }
 // keys[e] = (address << 32) | e ; clock of entry e = step + 1
 __global__ void k_entry_keys(const uint32_t* __restrict__ trace, uint32_t n_steps, const uint32_t* __restrict__ entry_off,
@@ -121,11 +123,11 @@ __global__ void k_iota(uint32_t* p, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
 }
-// sorted[] is non-decreasing with values < 32: ends[v] = index after the last occurrence of v
+// sorted[] is non-decreasing (component << 6 | opcode): ends[c] = index after the last step of component c
 __global__ void k_run_ends(const uint32_t* __restrict__ sorted, uint32_t n, uint32_t* __restrict__ ends) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (i + 1 == n || sorted[i + 1] != sorted[i]) ends[sorted[i]] = i + 1;
+  if (i + 1 == n || (sorted[i + 1] >> 6) != (sorted[i] >> 6)) ends[sorted[i] >> 6] = i + 1;
 }
 struct BundleDst { cm_bundle* p[CM_N_OPCODE_COMPONENTS]; uint32_t start[CM_N_OPCODE_COMPONENTS + 1]; };
 // i = position in the component-sorted (stable) order of the steps
@@ -137,7 +139,7 @@ __global__ void k_bundles(const uint32_t* __restrict__ sorted_step, uint32_t n_s
                           cm_data_access* __restrict__ accesses, OpTable tab) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_steps) return;
-  uint32_t t = sorted_step[i], c = comp[t];
+  uint32_t t = sorted_step[i], c = comp[t] >> 6;
   uint32_t e0 = entry_off[t], ne = n_entries[t], na = n_acc[t];
   uint32_t ninst = ne - na;  // 1 or 2 instruction-word entries
   cm_bundle b;
@@ -338,11 +340,11 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
   DevBuf d_cu((size_t)n_cu * sizeof(cm_clock_update) + 4);
   hipLaunchKernelGGL(k_clock_updates, grid1(n_mem), dim3(256), 0, st, d_mem.u32(), n_mem, d_cuc.u32(), d_cuoff.u32(), d_cup.u32(),
                      d_hent.u32(), d_init.u32(), n_init, d_cu.as<cm_clock_update>());
-  // ---- 4. bundles per opcode component (stable 5-bit sort of the steps), data accesses ----
+  // ---- 4. bundles per opcode component, opcode variants grouped inside (stable 11-bit sort of the steps), data accesses ----
   DevBuf d_steps((size_t)n_steps * 4 + 4), d_steps_sorted((size_t)n_steps * 4 + 4), d_comp_sorted((size_t)n_steps * 4 + 4);
   hipLaunchKernelGGL(k_iota, grid1(n_steps), dim3(256), 0, st, d_steps.u32(), n_steps);
   with_temp([&](void* t, size_t& b) {
-    CM_HIP(hipcub::DeviceRadixSort::SortPairs(t, b, d_comp.u32(), d_comp_sorted.u32(), d_steps.u32(), d_steps_sorted.u32(), (int)n_steps, 0, 5, st));
+    CM_HIP(hipcub::DeviceRadixSort::SortPairs(t, b, d_comp.u32(), d_comp_sorted.u32(), d_steps.u32(), d_steps_sorted.u32(), (int)n_steps, 0, 11, st));
   });
   // component counts: the sorted component array is non-decreasing -> count = upper bound difference
   DevBuf d_counts(32 * 4);

@@ -439,6 +439,12 @@ inline ProverInputOwned import_segment(const Segment& seg, const uint32_t prog[2
     out.bundles[comp].push_back(b);
     clock++;
   }
+  // Row order inside a component = the reference's: `states_by_opcodes` keeps one Vec per OPCODE in step order
+  // (adapter/mod.rs:118-130) and Claim::write_trace concatenates the variants of a component in `define_opcodes!` order
+  // (components/opcodes/mod.rs:51-58, 223-268: ascending opcode id in every group) — e.g. store_fp_fp = all adds, then all
+  // subs, muls, divs.  A stable sort by opcode keeps the step order inside each variant.
+  for (int c = 0; c < CM_N_OPCODE_COMPONENTS; c++)
+    std::stable_sort(out.bundles[c].begin(), out.bundles[c].end(), [](const cm_bundle& x, const cm_bundle& y) { return x.inst[0] < y.inst[0]; });
   out.clock_updates = mt.clock_updates;
   out.n_steps = seg.trace.size() - 1;
   out.final_pc = seg.trace.back()[0];

@@ -208,3 +208,31 @@ def test_partial_merkle_tree_shapes(oracle):
     nodes, _ = _partial_tree([[3, 7, 0, 0, 0]], initial=True, ranges=(0, 8, 0, 0, 0, 0))
     leaf = nodes[(nodes[:, 1] == 30) & (nodes[:, 0] == 12)][0]
     assert leaf[5] == 2 and leaf[6] == 2
+
+
+def test_bundle_order_inside_a_component_follows_the_reference():
+    """`states_by_opcodes` is one Vec per OPCODE in step order (adapter/mod.rs:118-130) and Claim::write_trace concatenates
+    the variants of a component in `define_opcodes!` order (components/opcodes/mod.rs:51-58, 223-268): the rows of
+    store_fp_fp are all StoreAddFpFp steps, then all StoreSubFpFp, StoreMulFpFp, StoreDivFpFp — NOT interleaved in step
+    order.  Same for jmp_imm (abs, rel) and store_fp_imm (add, mul)."""
+    from cairo_m_amd.lib import prover_input_arrays, vm_run
+    prog = [
+        [9, 7, 0], [9, 3, 1],
+        [3, 0, 1, 2],        # div first
+        [0, 0, 1, 3],        # add
+        [2, 0, 1, 4],        # mul
+        [1, 0, 1, 5],        # sub
+        [0, 2, 3, 6],        # add again
+        [6, 6, 5, 7],        # mul imm
+        [4, 7, 9, 8],        # add imm
+        [13, 2],             # jmp rel +2
+        [9, 1, 9],           # skipped
+        [12, 12],            # jmp abs 12
+        [11],
+    ]
+    a = prover_input_arrays(vm_run(prog, entry_pc=0, args=(), n_returns=0).view)
+    fpfp = a["bundles6"]
+    assert fpfp[:, 4].tolist() == [0, 0, 1, 2, 3]                 # opcode variants grouped in macro order ...
+    assert fpfp[:2, 2].tolist() == sorted(fpfp[:2, 2].tolist())   # ... step order (clock) kept inside a variant
+    assert fpfp[:, 2].tolist() == [4, 7, 6, 5, 3]
+    assert a["bundles7"][:, 4].tolist() == [4, 6] and a["bundles2"][:, 4].tolist() == [12, 13]
