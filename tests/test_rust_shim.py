@@ -1,0 +1,84 @@
+"""The Rust shim (integration/prover-hip, shipped as source: no Rust toolchain in the build image) must stay in sync
+with the C ABI: every `#[repr(C)]` struct of src/ffi.rs has the fields of its C twin in include/cairom_hip.h, in order,
+with matching widths; every extern fn it declares is exported by the library with the same arity; its opcode groups equal
+the library's component table."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FFI = open(os.path.join(ROOT, "integration", "prover-hip", "src", "ffi.rs")).read()
+LIB = open(os.path.join(ROOT, "integration", "prover-hip", "src", "lib.rs")).read()
+HDR = open(os.path.join(ROOT, "include", "cairom_hip.h")).read()
+
+
+def rust_structs():
+    out = {}
+    for m in re.finditer(r"pub struct (\w+) \{(.*?)\n\}", FFI, re.S):
+        out[m.group(1)] = [(n, re.sub(r"\s+", "", t)) for n, t in re.findall(r"pub (\w+): ([^,\n]+),", m.group(2))]
+    return out
+
+
+def c_structs():
+    out = {}
+    hdr = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
+    for m in re.finditer(r"typedef struct \{(.*?)\} (\w+);", hdr, re.S):
+        fields = []
+        for decl in m.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ty, names = re.match(r"((?:const )?\w+\*?)\s+(.*)", decl, re.S).groups()
+            for nm in names.split(","):
+                nm = nm.strip()
+                a = re.match(r"(\*?)(\w+)(?:\[(\w+)\])?", nm)
+                fields.append((a.group(2), ty + a.group(1), a.group(3)))
+        out[m.group(2)] = fields
+    return out
+
+
+def test_repr_c_structs_match_the_header():
+    rs, cs = rust_structs(), c_structs()
+    for name in ("cm_bundle", "cm_data_access", "cm_memory_cell", "cm_clock_update", "cm_merkle_node", "cm_prover_input", "cm_pcs_config"):
+        assert name in rs and name in cs, name
+        assert [f[0] for f in rs[name]] == [f[0] for f in cs[name]], name
+        for (rn, rt), (cn, ct, arr) in zip(rs[name], cs[name]):
+            if ct.endswith("*"):
+                assert rt.startswith("*const") or rt.startswith("[*const"), (name, rn, rt, ct)
+            else:
+                want = {"uint32_t": "u32", "uint64_t": "u64"}[ct]
+                assert rt == want or rt.startswith(f"[{want};"), (name, rn, rt, ct)
+            if arr:
+                n = {"CM_N_OPCODE_COMPONENTS": "CM_N_OPCODE_COMPONENTS"}.get(arr, arr)
+                assert rt.endswith(f";{n}]"), (name, rn, rt, arr)
+
+
+def test_extern_functions_are_exported():
+    L = C.CDLL(os.path.join(ROOT, "cairo_m_amd", "libcairom_hip.so"))
+    block = FFI[FFI.index('unsafe extern "C"'):]
+    fns = re.findall(r"pub fn (\w+)\((.*?)\) -> i32;", block, re.S)
+    assert len(fns) >= 6
+    hdr = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
+    for name, args in fns:
+        getattr(L, name)
+        proto = re.search(r"int32_t " + name + r"\((.*?)\);", hdr, re.S).group(1)
+        assert len([a for a in args.split(",") if a.strip()]) == len([a for a in proto.split(",") if a.strip()]), name
+
+
+def test_opcode_groups_equal_the_component_table():
+    """OPCODE_GROUPS of lib.rs (macro order of define_opcodes!) against the library: vm programs of one opcode land in the
+    component with the group's index (tests/golden/proof_schema.json holds the reference's module order)."""
+    import json
+    schema = json.load(open(os.path.join(ROOT, "tests", "golden", "proof_schema.json")))
+    groups = re.search(r"const OPCODE_GROUPS.*?\[\s*(&\[.*?)\n    \]\n\};", LIB, re.S).group(1)
+    rows = re.findall(r"&\[([A-Z0-9_, ]+)\]", groups)
+    assert len(rows) == 26 == len(schema["opcodes"])
+    snake = lambda s: s.lower()
+    for row, module in zip(rows, schema["opcodes"]):
+        first = snake(row.split(",")[0].strip())
+        # the module name is the opcode name or its family (store_add_fp_fp -> store_fp_fp, jmp_abs_imm -> jmp_imm, ...)
+        stem = re.sub(r"_(add|sub|mul|div|abs|rel|and|or|xor|rem|to)(?=_|$)", "", first).replace("store_double_deref_fp_fp", "double_deref_fp_fp")
+        stem = {"store_double_deref_fp": "double_deref_fp_imm", "u32_store_fp_fp": "u32_store_bitwise_fp_fp" if "AND" in row else "u32_store_fp_fp",
+                "u32_store_fp_imm": "u32_store_bitwise_fp_imm" if "AND" in row else "u32_store_fp_imm"}.get(stem, stem)
+        assert stem == module or module in (first, stem) or first.replace("_rem", "") == module or \
+            re.sub(r"_(add|sub|mul|div|lt|eq)_", "_\\1_", first) == module, (row, module, stem)
