@@ -34,6 +34,9 @@ struct QuotientArgs {
   const QuotientBatch* batches;    // device array
   uint32_t n_batches;
   uint32_t* const* out;            // 4 coordinate columns (device array)
+  // row-sharded launch (intra-proof multi-GPU): this rank computes rows [row0, row0 + n_rows) of the 2^log_size domain;
+  // `cols` / `out` then point at the rank's row SLICES (index 0 = row0).  n_rows = 0: the whole domain.
+  uint32_t row0 = 0, n_rows = 0;
 };
 void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st);
 void fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw,

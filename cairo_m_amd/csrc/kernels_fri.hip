@@ -30,10 +30,10 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
   constexpr int ROWS = 256 / S;
   __shared__ uint32_t red[S > 1 ? 256 * 4 : 4];
   const uint32_t slice = threadIdx.x / ROWS, rl = threadIdx.x % ROWS;
-  const uint32_t row = blockIdx.x * ROWS + rl;
-  const bool live = row < (1u << a.log_size);
+  const uint32_t row = blockIdx.x * ROWS + rl;          // index into the columns (a row slice when the launch is sharded)
+  const bool live = row < (a.n_rows ? a.n_rows : (1u << a.log_size));
   M31 px, py;
-  if (live) domain_point_at_row(a.tw, a.log_size, row, px, py);
+  if (live) domain_point_at_row(a.tw, a.log_size, a.row0 + row, px, py);
   QM31 acc;
   for (uint32_t b = 0; b < a.n_batches; b++) {
     const QuotientBatch& qb = a.batches[b];
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
 
 // ================================================================= host wrappers
 void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st) {
-  uint32_t n = 1u << a.log_size;
+  uint32_t n = a.n_rows ? a.n_rows : (1u << a.log_size);
   KProfScope kp("k_quotients", (4.0 * n_cols + 16.0) * (double)n, st);
   if (a.log_size >= 14) hipLaunchKernelGGL(k_quotients<1>, dim3((n + 255) / 256), dim3(256), 0, st, a);
   else if (a.log_size >= 10) hipLaunchKernelGGL(k_quotients<8>, dim3((n + 31) / 32), dim3(256), 0, st, a);

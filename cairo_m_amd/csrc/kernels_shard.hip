@@ -1,0 +1,56 @@
+// Data-movement kernels of the intra-proof sharded prover (prover_sharded.inc): packing row slices of columns for the
+// all-to-all that turns component (column) ownership into row-range ownership, and the element-wise reductions that
+// follow an exchange.  Pure HBM streaming, coalesced dwords / 16-byte words.
+#include "field.hpp"
+#include "device_common.hpp"
+#include "engine.hpp"
+#include "shard_kernels.hpp"
+
+namespace cm {
+
+// one block column (blockIdx.y) per segment, grid-stride over its words
+__global__ void __launch_bounds__(256) k_copy_segments(const CopySeg* __restrict__ segs) {
+  const CopySeg s = segs[blockIdx.y];
+  const uint32_t* __restrict__ src = s.src;
+  uint32_t* __restrict__ dst = s.dst;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s.words; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// out[i] = sum over k < n_copies of in[k * stride + i]   (plain u32 adds: histogram counts) or the same sum mod P
+template <bool MODULAR>
+__global__ void __launch_bounds__(256) k_sum_copies(const uint32_t* __restrict__ in, uint32_t n_copies, uint64_t stride, uint64_t words,
+                                                    uint32_t* __restrict__ out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (MODULAR) {
+      M31 acc(in[i]);
+      for (uint32_t k = 1; k < n_copies; k++) acc = acc + M31(in[k * stride + i]);
+      out[i] = acc.v;
+    } else {
+      uint32_t acc = in[i];
+      for (uint32_t k = 1; k < n_copies; k++) acc += in[k * stride + i];
+      out[i] = acc;
+    }
+  }
+}
+
+void copy_segments(const std::vector<CopySeg>& segs, hipStream_t st) {
+  if (segs.empty()) return;
+  uint64_t mx = 0;
+  for (auto& s : segs) mx = s.words > mx ? s.words : mx;
+  if (!mx) return;
+  DevBuf d = upload(segs, st);
+  uint32_t bx = (uint32_t)((mx + 1023) / 1024);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(k_copy_segments, dim3(bx, (uint32_t)segs.size()), dim3(256), 0, st, d.as<CopySeg>());
+  CM_HIP(hipGetLastError());
+  CM_HIP(hipStreamSynchronize(st));   // the segment table is a temporary
+}
+void sum_copies(const uint32_t* d_in, uint32_t n_copies, uint64_t stride, uint64_t words, uint32_t* d_out, bool modular, hipStream_t st) {
+  if (!words) return;
+  uint32_t blocks = (uint32_t)((words + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (modular) hipLaunchKernelGGL(k_sum_copies<true>, dim3(blocks), dim3(256), 0, st, d_in, n_copies, stride, words, d_out);
+  else hipLaunchKernelGGL(k_sum_copies<false>, dim3(blocks), dim3(256), 0, st, d_in, n_copies, stride, words, d_out);
+  CM_HIP(hipGetLastError());
+}
+
+}  // namespace cm

@@ -14,6 +14,7 @@
 #include "kprof.hpp"
 #include "point_eval.hpp"
 #include "host_adapter.hpp"
+#include "shard_kernels.hpp"
 #include <atomic>
 #include <chrono>
 #include <deque>
@@ -1326,6 +1327,8 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   return out.release();
 }
 
+#include "prover_sharded.inc"
+
 }  // namespace cm
 
 // ---- segment pipeline: several independent segment proofs in flight on one GPU ---------------
@@ -1416,6 +1419,26 @@ int32_t cm_prove_segment(const cm_prover_input* input, const cm_pcs_config* conf
   rc = cm_prove_device(di, config, out);
   cm_input_free(di);
   return rc;
+}
+int32_t cm_shard_plan(const cm_prover_input* input, uint32_t world, int32_t owner_out[CM_N_COMPONENTS], uint64_t* staging_words) {
+  return pguard([&] {
+    CM_CHECK(world >= 1 && world <= 8 && (world & (world - 1)) == 0, "cm_shard_plan: world must be 1, 2, 4 or 8");
+    uint32_t clog[air::N_COMPONENTS];
+    cm::component_logs(*input, clog);
+    int owner[air::N_COMPONENTS];
+    cm::shard_plan(clog, world, owner);
+    for (int c = 0; c < air::N_COMPONENTS; c++) if (owner_out) owner_out[c] = owner[c];
+    if (staging_words) *staging_words = cm::shard_staging_words(clog, owner, world);
+  });
+}
+int32_t cm_prove_sharded(const cm_device_input* input, const cm_pcs_config* config, const cm_comm* comm, cm_proof** out) {
+  return pguard([&] {
+    CM_CHECK(comm && comm->all_gather && comm->all_to_all_v && comm->send_buf && comm->recv_buf, "cm_prove_sharded: incomplete cm_comm");
+    cm_pcs_config cfg = config ? *config : default_cfg();
+    cm_proof* p = new cm_proof();
+    p->d = cm::prove_sharded(*input->d, cfg, *comm);
+    *out = p;
+  });
 }
 int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
                       cm_proof** outs) {

@@ -1,0 +1,178 @@
+"""Host side of the intra-proof sharded prover (include/cairom_hip.h: cm_comm, cm_shard_plan, cm_prove_sharded).
+
+The library does the proving and the packing; THIS module provides the two collectives it asks for, over
+torch.distributed: backend "nccl" (= RCCL over xGMI on a multi-GPU node: device tensors go straight into
+all_to_all_single / all_gather_into_tensor) or "gloo" (tests: several ranks sharing one GPU, or no GPU at all — the
+staging buffers are copied through host memory).  One process per rank; launch with
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m cairo_m_amd.sharded --fib-n 419000
+
+Every rank ends up with the same proof, bit-identical to the single-GPU one (tests/test_gpu_sharded.py).
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+from .lib import N_COMPONENTS, Backend, CmError, Proof, _cfg, load_library, synth_fibonacci
+
+_A2A = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+_AG = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64)
+
+
+class CmComm(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("ctx", C.c_void_p), ("send_buf", C.c_void_p), ("recv_buf", C.c_void_p),
+                ("buf_words", C.c_uint64), ("all_to_all_v", _A2A), ("all_gather", _AG)]
+
+
+def shard_plan(host_input, world, lib=None):
+    """(owner per component, staging words) — host code, identical on every rank."""
+    L = lib or load_library()
+    owner = (C.c_int32 * N_COMPONENTS)()
+    words = C.c_uint64(0)
+    rc = L.cm_shard_plan(host_input.view, C.c_uint32(world), owner, C.byref(words))
+    if rc:
+        raise CmError(f"cm_shard_plan failed with status {rc}")
+    return list(owner), words.value
+
+
+class TorchComm:
+    """cm_comm over torch.distributed.  `staging` = (send, recv) int32 tensors: CUDA tensors for a real run, CPU tensors when
+    the collectives are exercised without a GPU (tests/test_multirank_cpu.py)."""
+
+    def __init__(self, staging_words, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        dev = torch.device("cuda", device) if device is not None else torch.device("cpu")
+        self.send = torch.empty(staging_words, dtype=torch.int32, device=dev)
+        self.recv = torch.empty(staging_words, dtype=torch.int32, device=dev)
+        self.direct = self.backend == "nccl"        # device tensors straight into the collective
+        self.bytes_moved = 0
+        self.calls = 0
+        self._a2a, self._ag = _A2A(self._all_to_all_v), _AG(self._all_gather)   # keep the thunks alive
+        self.c = CmComm(self.rank, self.world, None, self.send.data_ptr(), self.recv.data_ptr(), staging_words, self._a2a, self._ag)
+
+    def _sync(self):
+        if self.send.is_cuda:
+            self.torch.cuda.synchronize()
+
+    def _all_to_all_v(self, _ctx, send_words, recv_words):
+        try:
+            n = self.world
+            sw = [int(send_words[i]) for i in range(n)]
+            rw = [int(recv_words[i]) for i in range(n)]
+            src = self.send[:sum(sw)]
+            dst = self.recv[:sum(rw)]
+            if self.direct:
+                self.dist.all_to_all_single(dst, src, output_split_sizes=rw, input_split_sizes=sw, group=self.group)
+            else:
+                s = src.cpu()
+                r = self.torch.empty(sum(rw), dtype=self.torch.int32)
+                outs = list(r.split(rw)) if sum(rw) else [r[:0]] * n
+                ins = list(s.split(sw)) if sum(sw) else [s[:0]] * n
+                # gloo has no all_to_all on every build: pairwise exchange, deadlock-free order
+                reqs = []
+                for k in range(n):
+                    peer_s, peer_r = (self.rank + k) % n, (self.rank - k) % n
+                    if k == 0:
+                        outs[self.rank].copy_(ins[self.rank])
+                        continue
+                    if sw[peer_s]:
+                        reqs.append(self.dist.isend(ins[peer_s].contiguous(), self._global(peer_s), group=self.group))
+                    if rw[peer_r]:
+                        reqs.append(self.dist.irecv(outs[peer_r], self._global(peer_r), group=self.group))
+                for q in reqs:
+                    q.wait()
+                dst.copy_(r)
+            self._sync()
+            self.bytes_moved += 4 * sum(sw)
+            self.calls += 1
+            return 0
+        except Exception as e:  # noqa: BLE001 — a Python exception must not unwind through the C frame
+            print(f"[rank {self.rank}] all_to_all_v failed: {e!r}", file=sys.stderr)
+            return 1
+
+    def _global(self, group_rank):
+        return self.dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
+
+    def _all_gather(self, _ctx, words_per_rank):
+        try:
+            w, n = int(words_per_rank), self.world
+            if w == 0:
+                return 0
+            src, dst = self.send[:w], self.recv[:w * n]
+            if self.direct:
+                self.dist.all_gather_into_tensor(dst, src, group=self.group)
+            else:
+                s = src.cpu()
+                parts = [self.torch.empty(w, dtype=self.torch.int32) for _ in range(n)]
+                self.dist.all_gather(parts, s, group=self.group)
+                dst.copy_(self.torch.cat(parts))
+            self._sync()
+            self.bytes_moved += 4 * w * (n - 1)
+            self.calls += 1
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {self.rank}] all_gather failed: {e!r}", file=sys.stderr)
+            return 1
+
+
+def prove_sharded(backend, dev_input, comm, cfg=None):
+    """cm_prove_sharded: every rank of comm's group calls this with the SAME input; returns this rank's copy of the proof."""
+    h = C.c_void_p()
+    backend._ck(backend.L.cm_prove_sharded(dev_input, _cfg(cfg), C.byref(comm.c), C.byref(h)))
+    return Proof(backend.L, h)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fib-n", type=int, default=1000)
+    ap.add_argument("--dist-backend", default="nccl")
+    ap.add_argument("--force-device", type=int, default=-1, help="every rank uses this GPU (tests: ranks sharing one GPU over gloo)")
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--out", default="", help="rank r writes its proof words to <out>.<r>.npy")
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    local = int(os.environ.get("LOCAL_RANK", "0")) if a.force_device < 0 else a.force_device
+    torch.cuda.set_device(local)
+    if a.dist_backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(a.dist_backend)
+    be = Backend(local)
+    inp = synth_fibonacci(a.fib_n)
+    owner, words = shard_plan(inp, dist.get_world_size(), be.L)
+    comm = TorchComm(words, device=local)
+    dev = be.upload_input(inp)
+    p = prove_sharded(be, dev, comm)          # warm-up + the proof that is written out
+    w = p.words().copy()
+    cells = p.stats()["cells"]
+    p.free()
+    ms = []
+    for _ in range(a.steps):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        prove_sharded(be, dev, comm).free()
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t) * 1e3)
+    if a.out:
+        np.save(f"{a.out}.{dist.get_rank()}.npy", w)
+    if dist.get_rank() == 0:
+        print({"world": dist.get_world_size(), "owner": owner, "staging_words": words, "ms": ms, "cells": cells,
+               "comm_calls_per_proof": comm.calls // (a.steps + 1), "comm_MB_per_proof": comm.bytes_moved / (a.steps + 1) / 1e6})
+    be.free_input(dev)
+    inp.free()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

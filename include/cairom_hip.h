@@ -217,6 +217,29 @@ int32_t cm_prove_device(const cm_device_input* input, const cm_pcs_config* confi
  * made under any other config is rejected with InvalidStructure(config) — the prover never chooses the security level. */
 int32_t cm_verify_proof(const cm_proof* p, const cm_pcs_config* expected);
 int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words, const cm_pcs_config* expected);
+/* ---- intra-proof sharding (BASELINE configs[3]): `world` ranks (one process per GPU) prove ONE segment.
+ * Whole components are assigned to ranks (cm_shard_plan: longest-processing-time bin packing by columns x rows) for trace
+ * generation, LogUp, IFFT / LDE, constraint evaluation and OODS sampling; an all-to-all turns the committed LDE columns
+ * into row-range ownership, so every rank hashes the Merkle subtree of its rows (sub-roots are all-gathered, the top
+ * log2(world) levels are hashed by everyone) and accumulates the DEEP quotients of its rows; partial composition
+ * accumulators are reduced across ranks.  The preprocessed tree, the composition tree and FRI are computed by every rank
+ * (replicated) in this version.  Every rank returns the same proof, bit-identical to cm_prove_device's.
+ * The library does no communication itself: the host side (torch.distributed / RCCL in bench.py, anything else
+ * elsewhere) provides two blocking collectives over two DEVICE staging buffers it owns.  Layouts are rank-major and
+ * contiguous: all_to_all_v sends send_words[d] words to rank d from send_buf (blocks in rank order) and receives
+ * recv_words[s] words from rank s into recv_buf; all_gather sends send_buf[0, words_per_rank) and receives world blocks. */
+typedef struct cm_comm {
+  uint32_t rank, world;              /* world: a power of two, 1..8 */
+  void* ctx;
+  uint32_t* send_buf;
+  uint32_t* recv_buf;
+  uint64_t buf_words;                /* capacity of each staging buffer (cm_shard_plan reports what a proof needs) */
+  int32_t (*all_to_all_v)(void* ctx, const uint64_t* send_words, const uint64_t* recv_words);
+  int32_t (*all_gather)(void* ctx, uint64_t words_per_rank);
+} cm_comm;
+/* host code (no GPU): which rank owns which component, and the staging capacity (words) a sharded proof of `input` needs */
+int32_t cm_shard_plan(const cm_prover_input* input, uint32_t world, int32_t owner[CM_N_COMPONENTS], uint64_t* staging_words);
+int32_t cm_prove_sharded(const cm_device_input* input, const cm_pcs_config* config, const cm_comm* comm, cm_proof** out);
 /* Segment pipeline: prove n independent segments with up to `inflight` (1..8) proofs in flight on the
  * GPU (persistent worker threads inside the library, one stream set / device pool each).  outs[i] = proof of
  * inputs[i]; on error the first failure is returned and the proofs already built stay in outs (free them). */

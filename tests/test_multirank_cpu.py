@@ -1,49 +1,70 @@
-"""N > 1 path on CPU (gloo, world_size 2): the bench's sharding logic — every rank proves an independent
-segment (no data-path collective); the only collectives are the barrier and the max-over-ranks time.
-Here each rank checks its own segment with the CPU oracle and the ranks agree on the aggregate."""
+"""Multi-rank plumbing on CPU (gloo, world_size 2, no GPU):
+* the sharded prover's host side — every rank derives the SAME component -> rank plan (cm_shard_plan is host code) and the
+  two cm_comm collectives (cairo_m_amd/sharded.py::TorchComm) move exactly the rank-major blocks the library expects;
+* replicas over segments: each rank checks the AIR of its own continuation segment with the CPU oracle."""
 import os
+import socket
 import subprocess
 import sys
-import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-WORKER = textwrap.dedent("""
-    import os, sys, time
-    sys.path.insert(0, %r)
-    import torch, torch.distributed as dist
-    from cairo_m_amd.lib import vm_run
-    from tests.oracle_binding import Oracle
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
-    # a cell cannot be read and written in the same step (clock deltas must be >= 1): ping-pong between two cells
-    prog = [[9, 1, 0]] + [[4, 0, 1, 1], [4, 1, 1, 0]] * 3 + [[4, 0, 1, 1]] + [[11]]
-    # one program cut into `world` continuation segments: rank r owns segment r
-    inp = vm_run(prog, max_steps=5, segment=rank)
-    assert inp.n_segments == world, inp.n_segments
-    orc = Oracle(os.path.join(%r, "oracle", "liboracle.so"))
-    dist.barrier()
-    t0 = time.perf_counter()
-    rc, err = orc.assert_constraints(inp.view)
-    dt = time.perf_counter() - t0
-    assert rc == 0, err
-    t = torch.tensor([dt, float(inp.steps)], dtype=torch.float64)
-    tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-    assert tmax[0] >= t[0]
-    assert int(tsum[1]) == 9  # 9 VM steps in total across the segments
-    dist.barrier()
-    dist.destroy_process_group()
-    open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank%%d.ok" %% rank), "w").write("ok")
-""")
+WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CM_ROOT"])
+from cairo_m_amd.lib import synth_fibonacci
+from cairo_m_amd.sharded import TorchComm, shard_plan
+from tests.oracle_binding import Oracle
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+# ---- plan: identical on every rank, every component owned, the two biggest components on different ranks
+inp = synth_fibonacci(3000)
+owner, words = shard_plan(inp, world)
+t = torch.tensor(owner, dtype=torch.int32)
+ref = t.clone(); dist.broadcast(ref, 0)
+assert torch.equal(t, ref) and set(owner) == set(range(world)) and words > 0
+big, _ = shard_plan(synth_fibonacci(100_000), world)
+assert big[7] != big[6]              # store_fp_imm and store_fp_fp, the two heaviest components of a large fibonacci_loop
+# ---- collectives on CPU staging buffers (the GPU path differs only in where the buffers live)
+comm = TorchComm(1 << 12)
+send = np.frombuffer((C.c_uint32 * (1 << 12)).from_address(comm.send.data_ptr()), dtype=np.uint32)
+recv = np.frombuffer((C.c_uint32 * (1 << 12)).from_address(comm.recv.data_ptr()), dtype=np.uint32)
+# all_gather: block r of every recv buffer = rank r's send block
+send[:5] = 100 * rank + np.arange(5)
+assert comm.c.all_gather(None, 5) == 0
+assert recv[:10].tolist() == list(range(0, 5)) + list(range(100, 105))
+# all_to_all_v with unequal splits: rank r sends (r + 1) words to rank 0 and 2 * (r + 1) words to rank 1
+sw = [(rank + 1), 2 * (rank + 1)]
+send[:sum(sw)] = 1000 * rank + np.arange(sum(sw))
+rw = [(s + 1) * (1 if rank == 0 else 2) for s in range(world)]
+assert comm.c.all_to_all_v(None, (C.c_uint64 * 2)(*sw), (C.c_uint64 * 2)(*rw)) == 0
+want = []
+for s in range(world):
+    off = 0 if rank == 0 else (s + 1)
+    want += [1000 * s + off + k for k in range(rw[s])]
+assert recv[:sum(rw)].tolist() == want, (rank, recv[:sum(rw)].tolist(), want)
+inp.free()
+# ---- replicas: rank r checks continuation segment r with the oracle
+orc = Oracle(os.path.join(os.environ["CM_ROOT"], "oracle", "liboracle.so"))
+seg = synth_fibonacci(30, max_steps=200, segment=rank)
+rc, err = orc.assert_constraints(seg.view)
+assert rc == 0, err
+ok = torch.tensor([1]); dist.all_reduce(ok)
+assert ok.item() == world
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
 
 
-def test_two_rank_gloo(tmp_path, oracle):
+def test_two_ranks_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % (ROOT, ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
-                         capture_output=True, text=True, timeout=600, env=env)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+    script.write_text(WORKER)
+    env = dict(os.environ, CM_ROOT=ROOT, PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok") == 2
