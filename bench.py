@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=FIB_N,
                     help="fibonacci_loop size the CPU oracle proves for cpu_baseline (default: the bench workload itself, ~14 s on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the second mode (one proof sharded over all ranks)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive `end_to_end` measurements")
     ap.add_argument("--no-kprof", action="store_true", help="debug: no in-library HIP-event kernel timing")
     ap.add_argument("--inflight", type=int, default=1,
@@ -231,6 +232,34 @@ def main():
                      "value": n_pipe * cells / dtp, "unit": "M31 trace cells/s",
                      "note": "throughput with several independent segment proofs in flight on the GPU (not the headline value)"}
 
+    sharded = None
+    if world > 1 and not args.no_sharded:
+        # Second mode (BASELINE configs[3]): the `world` ranks prove ONE segment together — components split across
+        # the ranks, rows split for Merkle hashing and DEEP quotients, collectives over RCCL (cairo_m_amd/sharded.py).  This is
+        # single-proof LATENCY scaling (strong scaling); the headline `value` above stays the replica throughput.
+        from cairo_m_amd.sharded import TorchComm, prove_sharded, shard_plan
+        owner, words = shard_plan(inp, world, be.L)
+        comm = TorchComm(words, device=local_rank)
+        p = prove_sharded(be, dev, comm)              # warm-up; also the proof whose words are compared below
+        sh_words = p.words().copy()
+        p.free()
+        p = be.prove_device(dev)
+        same = bool(sh_words.size == p.words().size and (sh_words == p.words()).all())
+        p.free()
+        sync()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            prove_sharded(be, dev, comm).free()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - ts
+        tt = torch.tensor([dts, 0.0 if same else 1.0], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dts, all_same = float(tt[0].item()), tt[1].item() == 0.0
+        sharded = {"mode": "one proof sharded over all ranks (strong scaling)", "ms_per_proof": dts * 1e3 / args.steps,
+                   "value": st["cells"] * args.steps / dts, "unit": "M31 trace cells/s", "bit_identical_to_single_gpu_proof": all_same,
+                   "component_owner": owner, "collectives_per_proof": comm.calls // (args.steps + 1),
+                   "MB_sent_per_rank_per_proof": comm.bytes_moved / (args.steps + 1) / 1e6,
+                   "note": "trees 0 / 3 and FRI are replicated in this version; whole components are the sharding unit"}
     verified = None
     hip_words = None
     end_to_end = None
@@ -308,7 +337,7 @@ def main():
                                       + (", preprocessed tree cached between proofs" if args.preprocessed_cache else ""),
                           "cells_per_proof": cells,
                           "vm_steps": inp.steps, "parallelism": f"{world} independent segment replica(s) x {len(workers)} proof(s) in flight per GPU"},
-               "phase_ms": phases, "roofline": roofline, "pipelined": pipelined, "end_to_end": end_to_end,
+               "phase_ms": phases, "roofline": roofline, "pipelined": pipelined, "sharded": sharded, "end_to_end": end_to_end,
                "proof_verified": verified}
         if world == 1 and not args.no_cpu_baseline:
             same = args.cpu_sample_n == args.fib_n
