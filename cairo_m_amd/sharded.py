@@ -156,18 +156,20 @@ def main():
     w = p.words().copy()
     cells = p.stats()["cells"]
     p.free()
-    ms = []
+    ms, phases = [], {}
     for _ in range(a.steps):
         dist.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter()
-        prove_sharded(be, dev, comm).free()
+        q = prove_sharded(be, dev, comm)
         torch.cuda.synchronize()
         ms.append((time.perf_counter() - t) * 1e3)
+        phases = {k: round(v, 3) for k, v in q.stats()["phase_ms"].items()}
+        q.free()
     if a.out:
         np.save(f"{a.out}.{dist.get_rank()}.npy", w)
     if dist.get_rank() == 0:
-        print({"world": dist.get_world_size(), "owner": owner, "staging_words": words, "ms": ms, "cells": cells,
+        print({"world": dist.get_world_size(), "owner": owner, "staging_words": words, "ms": ms, "phase_ms": phases, "cells": cells,
                "comm_calls_per_proof": comm.calls // (a.steps + 1), "comm_MB_per_proof": comm.bytes_moved / (a.steps + 1) / 1e6})
     be.free_input(dev)
     inp.free()
