@@ -237,29 +237,32 @@ def main():
         # Second mode (BASELINE configs[3]): the `world` ranks prove ONE segment together — components split across
         # the ranks, rows split for Merkle hashing and DEEP quotients, collectives over RCCL (cairo_m_amd/sharded.py).  This is
         # single-proof LATENCY scaling (strong scaling); the headline `value` above stays the replica throughput.
-        from cairo_m_amd.sharded import TorchComm, prove_sharded, shard_plan
-        owner, words = shard_plan(inp, world, be.L)
-        comm = TorchComm(words, device=local_rank)
-        p = prove_sharded(be, dev, comm)              # warm-up; also the proof whose words are compared below
-        sh_words = p.words().copy()
-        p.free()
-        p = be.prove_device(dev)
-        same = bool(sh_words.size == p.words().size and (sh_words == p.words()).all())
-        p.free()
-        sync()
-        ts = time.perf_counter()
-        for _ in range(args.steps):
-            prove_sharded(be, dev, comm).free()
-        torch.cuda.synchronize()
-        dts = time.perf_counter() - ts
-        tt = torch.tensor([dts, 0.0 if same else 1.0], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dts, all_same = float(tt[0].item()), tt[1].item() == 0.0
-        sharded = {"mode": "one proof sharded over all ranks (strong scaling)", "ms_per_proof": dts * 1e3 / args.steps,
-                   "value": st["cells"] * args.steps / dts, "unit": "M31 trace cells/s", "bit_identical_to_single_gpu_proof": all_same,
-                   "component_owner": owner, "collectives_per_proof": comm.calls // (args.steps + 1),
-                   "MB_sent_per_rank_per_proof": comm.bytes_moved / (args.steps + 1) / 1e6,
-                   "note": "trees 0 / 3 and FRI are replicated in this version; whole components are the sharding unit"}
+        try:
+            from cairo_m_amd.sharded import TorchComm, prove_sharded, shard_plan
+            owner, words = shard_plan(inp, world, be.L)
+            comm = TorchComm(words, device=local_rank)
+            p = prove_sharded(be, dev, comm)              # warm-up; also the proof whose words are compared below
+            sh_words = p.words().copy()
+            p.free()
+            p = be.prove_device(dev)
+            same = bool(sh_words.size == p.words().size and (sh_words == p.words()).all())
+            p.free()
+            sync()
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                prove_sharded(be, dev, comm).free()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts
+            tt = torch.tensor([dts, 0.0 if same else 1.0], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts, all_same = float(tt[0].item()), tt[1].item() == 0.0
+            sharded = {"mode": "one proof sharded over all ranks (strong scaling)", "ms_per_proof": dts * 1e3 / args.steps,
+                       "value": st["cells"] * args.steps / dts, "unit": "M31 trace cells/s", "bit_identical_to_single_gpu_proof": all_same,
+                       "component_owner": owner, "collectives_per_proof": comm.calls // (args.steps + 1),
+                       "MB_sent_per_rank_per_proof": comm.bytes_moved / (args.steps + 1) / 1e6,
+                       "note": "whole components are the sharding unit; Merkle hashing of all four trees and the DEEP quotients are row-sharded; the (cheap) transforms of trees 0 / 3 and FRI are replicated in this version"}
+        except Exception as e:  # noqa: BLE001 — the replica measurement above must survive a failure of the second mode
+            sharded = {"mode": "one proof sharded over all ranks (strong scaling)", "error": repr(e)}
     verified = None
     hip_words = None
     end_to_end = None

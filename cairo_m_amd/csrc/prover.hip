@@ -241,7 +241,7 @@ struct Prover {
   }
   // everything of a commitment except the root read-back, on stream `s` (tree 0 is built on a side stream while the
   // execution trace is generated: both are chains of small launches)
-  void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s) {
+  void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true) {
     const std::vector<uint32_t> logs = from_coeffs ? t.coeffs.logs : evals->logs;
     UploadBatch ub;
     if (!from_coeffs) { t.coeffs.alloc(logs, s, false); ub.add(t.coeffs.ptrs, &t.coeffs.d_view); }
@@ -263,8 +263,10 @@ struct Prover {
     const uint32_t** d_table = nullptr;
     ub.add(table, &d_table);
     std::vector<const uint32_t*> cols(t.lde.ptrs.begin(), t.lde.ptrs.end());
-    t.merkle.prepare(cols, t.lde.logs);
-    ub.add(t.merkle.cols, &t.merkle.d_cols_view);
+    if (with_merkle) {        // (the sharded prover hashes row slices of the LDE instead: prover_sharded.inc)
+      t.merkle.prepare(cols, t.lde.logs);
+      ub.add(t.merkle.cols, &t.merkle.d_cols_view);
+    }
     t.tables = ub.flush(s);   // ONE host->device copy for the whole tree
     for (auto& g : grps) {
       const uint32_t* const* dsrc = d_table + g.off;
@@ -273,7 +275,7 @@ struct Prover {
       if (!from_coeffs) interpolate_oop(dsrc, dco, g.n, g.log, *tw, s);
       evaluate((const uint32_t* const*)dco, dld, g.n, g.log, g.log + cfg.log_blowup_factor, *tw, s);
     }
-    t.merkle.commit_prepared(s);
+    if (with_merkle) t.merkle.commit_prepared(s);
   }
 };
 
