@@ -15,8 +15,10 @@ namespace cm {
 struct Twiddles {
   uint32_t R = 0;  // tables cover CanonicCoset(R).circle_domain() and every smaller canonic domain
   uint32_t *xtw = nullptr, *ixtw = nullptr, *ytw = nullptr, *iytw = nullptr;
+  uint32_t* scratch = nullptr;   // point tables the build kernels read (twiddles_scratch_words(R) words)
 };
 Twiddles* twiddles_create(uint32_t R, hipStream_t st);
+size_t twiddles_scratch_words(uint32_t R);
 void twiddles_build(const Twiddles& t, hipStream_t st);   // caller-allocated buffers (R set, 2^(R-1) / 2^R words)
 void twiddles_destroy(Twiddles* t);
 

@@ -341,11 +341,12 @@ static Twiddles* cached_twiddles(uint32_t R, hipStream_t st) {
 }
 struct ProofTwiddles {   // per-proof tables in pool memory
   Twiddles t;
-  DevBuf x, ix, y, iy;
+  DevBuf x, ix, y, iy, scratch;
   void build(uint32_t R, hipStream_t s) {
     t.R = R;
     x.alloc((size_t)4 << (R - 1)); ix.alloc((size_t)4 << (R - 1)); y.alloc((size_t)4 << R); iy.alloc((size_t)4 << R);
-    t.xtw = x.u32(); t.ixtw = ix.u32(); t.ytw = y.u32(); t.iytw = iy.u32();
+    scratch.alloc(twiddles_scratch_words(R) * 4);
+    t.xtw = x.u32(); t.ixtw = ix.u32(); t.ytw = y.u32(); t.iytw = iy.u32(); t.scratch = scratch.u32();
     twiddles_build(t, s);
   }
 };

@@ -13,11 +13,15 @@ for r in csv.DictReader(open(m)):
     ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r['Direction'][12:], '-', ''))
 ev.sort()
 gi = [i for i, e in enumerate(ev) if 'k_grind' in e[2]]
-# a proof has two grinds (interaction PoW, final PoW): the last proof starts after the previous proof's gather/copies
-i0 = gi[-3] + 1
-while i0 < len(ev) and ('gather' in ev[i0][2] or 'COPY' in ev[i0][2] or 'copyBuffer' in ev[i0][2]) and 'k_preproc' not in ev[i0][2]:
-    i0 += 1
-sub = ev[i0:]
+# a proof has two grinds (interaction PoW, final PoW).  bench.py's LAST proof is the verification proof made on the main host
+# thread (cold device pool: hipMallocs), so the proof analysed is the one before it: the last TIMED proof.
+def proof_start(after_grind):
+    i = after_grind + 1
+    while i < len(ev) and ('gather' in ev[i][2] or 'COPY' in ev[i][2] or 'copyBuffer' in ev[i][2]) and 'k_preproc' not in ev[i][2]:
+        i += 1
+    return i
+i0, i1 = proof_start(gi[-5]), proof_start(gi[-3])
+sub = ev[i0:i1]
 t0 = sub[0][0]
 cur, busy, gaps, prev = t0, 0, [], None
 for s, e, n, q, g in sub:
