@@ -903,7 +903,34 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       CM_HIP(hipMemsetAsync(acc_rest.buf.p, 0, acc_rest.buf.bytes, st));
     }
   }
-  CM_CHECK(cfg.log_blowup_factor == 1, "constraint evaluation reuses the committed LDE: log_blowup_factor must be 1");
+  // The constraints are evaluated on CanonicCoset(log + 1).  With log_blowup_factor = 1 (REGULAR_96_BITS) that is the
+  // committed LDE domain and the kernels read the committed columns; with a larger blowup every polynomial is evaluated
+  // on its (log + 1) domain separately (Stwo does the same: `poly.evaluate(eval_domain)`), at the cost of one more forward
+  // transform per column and its memory.
+  CM_CHECK(cfg.log_blowup_factor >= 1 && cfg.log_blowup_factor <= 4, "PcsConfig: log_blowup_factor must be in 1..4");
+  ColumnSet cdom[3];   // evaluation-domain copies of trees 0..2 (only when log_blowup_factor > 1)
+  if (cfg.log_blowup_factor > 1) {
+    for (int t = 0; t < 3; t++) {
+      std::vector<uint32_t> logs(P.trees[t].coeffs.logs);
+      for (auto& l : logs) l += 1;
+      cdom[t].alloc(logs, st);
+      std::vector<const uint32_t*> table;
+      struct Grp { uint32_t log, n; size_t off; };
+      std::vector<Grp> grps;
+      for (auto& kv : by_log(P.trees[t].coeffs.logs)) {
+        grps.push_back(Grp{kv.first, (uint32_t)kv.second.size(), table.size()});
+        for (auto i : kv.second) table.push_back(P.trees[t].coeffs.ptrs[i]);
+        for (auto i : kv.second) table.push_back(cdom[t].ptrs[i]);
+      }
+      DevBuf d_table = upload(table, st);
+      const uint32_t** dt = d_table.as<const uint32_t*>();
+      for (auto& g : grps) evaluate((const uint32_t* const*)(dt + g.off), (uint32_t* const*)(dt + g.off + g.n), g.n, g.log, g.log + 1, *P.tw, st);
+      CM_HIP(hipStreamSynchronize(st));   // d_table is a temporary
+    }
+  }
+  auto cdom_cols = [&](int t, size_t first) -> const uint32_t* const* {
+    return (const uint32_t* const*)(cfg.log_blowup_factor > 1 ? cdom[t].dev(first) : P.trees[t].lde.dev(first));
+  };
   {
     // Components are independent except for the shared per-size accumulator.  Small sizes (many idle
     // components of 2^4 rows, each a latency-bound launch) get a private zeroed accumulator slot per
@@ -940,9 +967,9 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       for (int c : it->second) {
         const air::ComponentInfo& info = air::component_info(c);
         ConstraintArgs& a = cargs[c];
-        a.tr = (const uint32_t* const*)P.trees[1].lde.dev(tr0[c]);
-        a.it = (const uint32_t* const*)P.trees[2].lde.dev(it0[c]);
-        a.pp = (const uint32_t* const*)P.trees[0].lde.dev();
+        a.tr = cdom_cols(1, tr0[c]);
+        a.it = cdom_cols(2, it0[c]);
+        a.pp = cdom_cols(0, 0);
         a.rels = drel.as<DevRelations>();
         a.coeff = d_powers.u32() + 4 * coff[c];
         a.acc = slot_of[c] >= 0 ? d_slot_tab.as<uint32_t*>() + 4 * slot_of[c] : accs.at(it->first).dev();

@@ -286,7 +286,7 @@ std::string verify_proof(const ProofData& pf, const cm_pcs_config& expected) {
       pf.commitments.size() != 4 || pf.sampled_values.size() != 4 || pf.decommitments.size() != 4 || pf.queried_values.size() != 4)
     return "InvalidStructure";
   for (auto l : pf.claim_log_sizes) if (l < 4 || l > 26) return "InvalidStructure(log size)";
-  if (cfg.log_blowup_factor != 1 || cfg.n_queries == 0 || cfg.n_queries > 4096 || cfg.pow_bits > 64 ||
+  if (cfg.log_blowup_factor < 1 || cfg.log_blowup_factor > 4 || cfg.n_queries == 0 || cfg.n_queries > 4096 || cfg.pow_bits > 64 ||
       cfg.log_last_layer_degree_bound > 20) return "InvalidStructure(config)";
   Channel ch;
   ch.mix_u64(cfg.pow_bits);

@@ -225,10 +225,24 @@ void accumulate_constraints(const ComponentTrace& ct, const TraceLocation& loc, 
   uint32_t n = ct.log_size, en = n + 1;
   size_t N = (size_t)1 << en;
   std::vector<const M31*> tr(info.n_trace), it(info.n_interaction);
-  for (int i = 0; i < info.n_trace; i++) tr[i] = pcs.trees[1].evals[loc.tr0 + i].data();
-  for (int i = 0; i < info.n_interaction; i++) it[i] = pcs.trees[2].evals[loc.it0 + i].data();
   const M31* pp[air::N_PREPROC];
-  for (int i = 0; i < air::N_PREPROC; i++) pp[i] = pcs.trees[0].evals[i].data();
+  // The constraints are evaluated on CanonicCoset(log + 1) (max constraint degree bound 2 x the trace size).  With
+  // log_blowup_factor = 1 that IS the committed LDE domain; with a larger blowup the polynomials are evaluated there
+  // separately (Stwo: `poly.evaluate(eval_domain)` when the committed evaluation is on another domain).
+  std::vector<Col> tmp;
+  if (pcs.cfg.log_blowup == 1) {
+    for (int i = 0; i < info.n_trace; i++) tr[i] = pcs.trees[1].evals[loc.tr0 + i].data();
+    for (int i = 0; i < info.n_interaction; i++) it[i] = pcs.trees[2].evals[loc.it0 + i].data();
+    for (int i = 0; i < air::N_PREPROC; i++) pp[i] = pcs.trees[0].evals[i].data();
+  } else {
+    tmp.reserve(info.n_trace + info.n_interaction + air::N_PREPROC);
+    for (int i = 0; i < info.n_trace; i++) { tmp.push_back(evaluate(pcs.trees[1].polys[loc.tr0 + i], en)); tr[i] = tmp.back().data(); }
+    for (int i = 0; i < info.n_interaction; i++) { tmp.push_back(evaluate(pcs.trees[2].polys[loc.it0 + i], en)); it[i] = tmp.back().data(); }
+    for (int i = 0; i < air::N_PREPROC; i++) {
+      pp[i] = nullptr;      // a component only reads preprocessed columns of its own size
+      if (pcs.trees[0].poly_logs[i] == n) { tmp.push_back(evaluate(pcs.trees[0].polys[i], en)); pp[i] = tmp.back().data(); }
+    }
+  }
   // 1 / vanishing of the trace coset on the two cosets of the evaluation domain
   CircleDomain ed = CanonicCoset(en).circle_domain();
   M31 dinv[2];

@@ -79,7 +79,7 @@ inline std::string verify_proof(const Proof& pf, const PcsConfig& expected = Pcs
   const PcsConfig& cfg = expected;
   if (pf.config.pow_bits != cfg.pow_bits || pf.config.log_blowup != cfg.log_blowup || pf.config.n_queries != cfg.n_queries ||
       pf.config.log_last_layer != cfg.log_last_layer) return "InvalidStructure(config)";
-  if (cfg.n_queries == 0 || cfg.n_queries > 4096 || cfg.pow_bits > 64 || cfg.log_last_layer > 20 || cfg.log_blowup != 1)
+  if (cfg.n_queries == 0 || cfg.n_queries > 4096 || cfg.pow_bits > 64 || cfg.log_last_layer > 20 || cfg.log_blowup < 1 || cfg.log_blowup > 4)
     return "InvalidStructure(config)";
   if (pf.claim_log_sizes.size() != (size_t)air::N_COMPONENTS || pf.commitments.size() != 4) return "InvalidStructure";
   Channel ch;

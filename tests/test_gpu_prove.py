@@ -351,3 +351,22 @@ def test_u32_loop_at_scale_verifies(backend, oracle):
     p.free()
     backend.free_input(dev)
     hs.free()
+
+
+@pytest.mark.parametrize("cfg", [(5, 2, 0, 12), (3, 3, 1, 10)])
+def test_log_blowup_factor_above_one_bit_exact(backend, oracle, cfg):
+    """prove_cairo_m takes any Option<PcsConfig> (prover.rs:23-29).  With log_blowup_factor > 1 the committed LDE domain
+    (log + blowup) is no longer the constraint-evaluation domain (log + 1): the prover evaluates every polynomial there
+    separately.  Whole proof bit-identical to the oracle's, both verifiers accept under the same config and refuse it under
+    REGULAR_96_BITS."""
+    from cairo_m_amd.lib import vm_run
+    from tests.test_oracle_air import u32_program
+    for inp in (synth_fibonacci(60), vm_run(u32_program(), entry_pc=0, args=(), n_returns=0)):
+        p = backend.prove(inp, cfg=cfg)
+        got = p.words()
+        want, _ = oracle.prove(inp.view, cfg=cfg)
+        assert got.size == want.size and np.array_equal(got, want)
+        assert p.verify(cfg)[0] == 0 and oracle.verify(got, cfg)[0] == 0
+        assert p.verify()[0] != 0 and oracle.verify(got)[0] != 0
+        p.free()
+        inp.free()

@@ -109,3 +109,21 @@ def test_public_data_words_must_be_canonical(oracle):
         rc, err = _verify(L, bad)
         assert rc != 0 and "malformed" in err, (k, err)
     inp.free()
+
+
+@pytest.mark.parametrize("cfg", [(5, 2, 1, 12)])
+def test_log_blowup_factor_above_one(oracle, cfg):
+    """PcsConfig with log_blowup_factor 2 (3 is covered on the GPU, tests/test_gpu_prove.py): the committed LDE domain differs from the constraint-evaluation domain.
+    Both verifiers accept the oracle's proof under that config and reject flips."""
+    L = load_library()
+    inp = synth_fibonacci(6)
+    words, _ = oracle.prove(inp.view, cfg=cfg)
+    assert oracle.verify(words, cfg)[0] == 0
+    rc, err = _verify(L, words, cfg)
+    assert rc == 0, err
+    rng = np.random.default_rng(2)
+    for pos in rng.integers(8, words.size - 1, size=12):
+        bad = words.copy()
+        bad[pos] ^= 1
+        assert (_verify(L, bad, cfg)[0] == 0) == (oracle.verify(bad, cfg)[0] == 0)
+    inp.free()
