@@ -41,7 +41,7 @@ def test_hip_witness_equals_reference_derived_cells(backend):
         for h in cols:
             backend.col_free(h)
         checked += 1
-    assert checked == 26
+    assert checked == 28          # 26 opcode components + memory + merkle
     backend.free_input(dev)
     inp.free()
 

@@ -13,8 +13,8 @@ Helper semantics restated here, each a few lines: `Pack::pack` (utils/execution_
 Output: tests/golden/air_witness_vectors.npz — for every component the expected trace cells `<name>` of shape
 (n_trace_columns, 2^log_size) plus the program parameters; data only.  tests/test_air_witness_golden.py re-runs the
 same program through the VM + adapter, asks the oracle for each component's trace and requires equality cell by cell
-(live AND padding rows).  store_fp_fp / store_fp_imm pre-compute per-lane hints outside the closure and are covered by
-the hand-written numpy model of tests/test_air_hot_independent.py instead.
+(live AND padding rows).  store_fp_fp / store_fp_imm derive per-lane hints in a closure over the unpacked bundles in
+front of the row closure: both closures are interpreted (interpret_prepacked).
 
 Usage (build container only):  python tools/rsref/rs_witness.py
 """
@@ -146,6 +146,78 @@ def interpret_component(fname, bundles, accesses, consts):
     return out
 
 
+class Instr:
+    """cairo_m_common::Instruction as far as the pre-pack closures use it: opcode_value() and the `imm` field of
+    StoreAddFpImm / StoreMulFpImm (words = [opcode, src_off, imm, dst_off], instruction.rs:343-356)."""
+
+    def __init__(self, words):
+        self.words = words
+        self.imm = Felt(words[2])
+
+    def opcode_value(self):
+        return self.words[0]
+
+
+def bundle_struct(row):
+    """ExecutionBundle (adapter/memory.rs:98-110) from a cm_bundle row."""
+    r = [int(x) for x in row]
+    return Struct(registers=Struct(pc=Felt(r[0]), fp=Felt(r[1])), clock=Felt(r[2]),
+                  instruction=Struct(instruction=Instr(r[4:10]), prev_clock=Felt(r[3])),
+                  access_span=Struct(start=r[10], len=r[11]), raw=r)
+
+
+def closure_text(src, anchor_re):
+    """text of the closure passed to the call matched by anchor_re (`....map(` / `....for_each(`): from its first `|` to the
+    call's closing parenthesis"""
+    m = re.search(anchor_re, src)
+    i = m.end()
+    depth, j = 1, i
+    while depth:
+        depth += src[j] in "([{"
+        depth -= src[j] in ")]}"
+        j += 1
+    return src[i:j - 1].strip().rstrip(",").strip()
+
+
+def interpret_prepacked(fname, bundles, accesses, consts):
+    """store_fp_fp.rs / store_fp_imm.rs: write_trace first maps every chunk of 16 bundles through a closure that packs them AND
+    derives per-lane hints (operand inverse, two opcode-flag bits), then runs the row closure on (input, hints...).  Both
+    closures are interpreted.  The one construct outside the interpreter's subset — a `match` on the Instruction variant that
+    only extracts the `imm` field (store_fp_imm.rs:172-176) — is rewritten to that field access before parsing."""
+    src = strip_comments(open(f"{REF}/prover/src/components/opcodes/{fname}.rs").read())
+    src = re.sub(r"match x\.instruction\.instruction \{\s*Instruction::StoreAddFpImm \{ imm, \.\. \} => imm,\s*Instruction::StoreMulFpImm \{ imm, \.\. \} => imm,\s*_ => unreachable!\(\),\s*\}",
+                 "x.instruction.instruction.imm", src)
+    g = standard_globals()
+    g.update(consts)
+    interp = Interp(g)
+    file_consts(src, interp)
+    for f in ("value", "prev_value", "prev_clock", "address"):
+        g[f"get_{f}"] = get_access_field(f)
+    g["DataAccess::default"] = lambda: Struct(address=Felt(0), prev_clock=Felt(0), prev_value=Felt(0), value=Felt(0))
+    g["Pack::pack"] = lambda arr: pack([b.raw for b in arr], 0)
+    n_cols = g["N_TRACE_COLUMNS"]
+    n = len(bundles)
+    log_size = max(4, (max(n, 1) - 1).bit_length())
+    n_rows = 1 << log_size
+    data_accesses = [Struct(address=Felt(a[0]), prev_clock=Felt(a[1]), prev_value=Felt(a[2]), value=Felt(a[3])) for a in accesses]
+    outer = Env()
+    outer.vars.update({"zero": Packed.broadcast(Felt(0)), "one": Packed.broadcast(Felt(1)), "enabler_col": Enabler(n),
+                       "data_accesses": data_accesses})
+    prepack = interp.eval(parse_expr(closure_text(src, r"\.par_chunks_exact\(N_LANES\)\s*\.map\(")), outer)
+    rowfn = interp.eval(parse_expr(closure_text(src, r"\.enumerate\(\)\s*\.for_each\(")), outer)
+    default = [0, 0, 0, 0, 11, 0, 0, 0, 0, 0, 0, 0]       # ExecutionBundle::default(): Ret, span (0, 0)
+    out = np.zeros((n_cols, n_rows), dtype=np.uint32)
+    for vec_row in range(n_rows // N_LANES):
+        chunk = [bundle_struct(bundles[vec_row * N_LANES + i] if vec_row * N_LANES + i < n else default) for i in range(N_LANES)]
+        packed = prepack(chunk)                               # (PackedExecutionBundle, hint, flag0, flag1)
+        row, ld = Slots(), LookupData()
+        rowfn((vec_row, (row, packed, ld)))
+        assert sorted(row.d) == list(range(n_cols)), (fname, sorted(row.d))
+        for c in range(n_cols):
+            out[c, vec_row * N_LANES:(vec_row + 1) * N_LANES] = [x.v for x in row.d[c].lanes]
+    return out
+
+
 def interpret_builtin(fname, rows, n_live, consts):
     """memory.rs / merkle.rs / clock_update.rs: `input` is the packed array of input columns built in front of the closure
     (memory.rs:104-133, merkle.rs:103-132, clock_update.rs:86-104: rows padded with zeros, transposed 16 at a time)."""
@@ -193,9 +265,8 @@ def main():
     out = {"iters": np.array([ITERS]), "seed": np.array([SEED]), "steps": np.array([steps])}
     for cid, fname in enumerate(OPCODE_FILES):
         cols = interpret_component(fname, arrs[f"bundles{cid}"], arrs["data_accesses"], consts)
-        if cols is None:
-            print(f"{cid:2d} {fname:28s} (irregular closure: covered by tests/test_air_hot_independent.py)")
-            continue
+        if cols is None:       # store_fp_fp / store_fp_imm: per-lane hints computed in a pre-pack closure
+            cols = interpret_prepacked(fname, arrs[f"bundles{cid}"], arrs["data_accesses"], consts)
         out[fname] = cols
         print(f"{cid:2d} {fname:28s} {arrs[f'bundles{cid}'].shape[0]:4d} live rows -> {cols.shape[0]} columns x {cols.shape[1]} rows")
     # builtins with a regular closure: memory (rows = initial ++ final cells), merkle (initial ++ final tree nodes), clock_update
