@@ -32,8 +32,9 @@ def _run_sharded(world, fib_n, out):
     return r.stdout
 
 
-@pytest.mark.parametrize("world,fib_n", [(2, 50), (2, 30_000), (4, 2_000)])
+@pytest.mark.parametrize("world,fib_n", [(2, 50), (2, 30_000), (4, 2_000), (8, 419_000), (2, 1_677_000)])
 def test_sharded_proof_equals_single_gpu_proof(backend, oracle, tmp_path, world, fib_n):
+    # (8, 419 000): the metric config over 8 ranks; (2, 1 677 000): BASELINE configs[3]'s 2^24-row segment (7.7e8 cells)
     inp = synth_fibonacci(fib_n)
     p = backend.prove(inp)
     want = p.words().copy()
