@@ -72,5 +72,20 @@ def test_clock_update_witness_matches_reference_derived_cells(oracle, run):
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
+def test_poseidon2_witness_matches_reference_derived_cells(oracle, run):
+    """poseidon2.rs:210-319 (round loops + the file's helper functions, interpreted) on the first 200 hash inputs of the
+    run's partial Merkle trees: live rows equal the oracle's poseidon2 trace, and an all-padding packed row equals an
+    all-padding row of the oracle's (443 columns each).  Round constants: KAT-pinned (tools/rsref/rs_poseidon2.py)."""
+    want = GOLD["poseidon2"]
+    got = oracle.component_trace(run.view, 29)
+    a = prover_input_arrays(run.view)
+    nodes = np.concatenate([a["initial_tree"], a["final_tree"]])
+    assert np.array_equal(GOLD["poseidon2_inputs"][:, :2], nodes[:200, 2:4])
+    assert got.shape[0] == want.shape[0] == 443 and got.shape[1] >= 2048
+    assert np.array_equal(got[:, :192], want[:, :192])                       # 12 fully live packed rows
+    assert np.array_equal(got[1:, nodes.shape[0] + 16:nodes.shape[0] + 32], want[1:, 224:240])   # padding rows (enabler column aside)
+    assert not got[0, nodes.shape[0]:].any() and not want[0, 200:].any()
+
+
 def test_coverage():
     assert set(OPCODE_FILES) <= set(GOLD.files)          # all 26 opcode components

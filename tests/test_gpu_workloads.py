@@ -42,6 +42,14 @@ def test_hip_witness_equals_reference_derived_cells(backend):
             backend.col_free(h)
         checked += 1
     assert checked == 28          # 26 opcode components + memory + merkle
+    # poseidon2 (443 columns): the first 192 rows (the golden holds the first 200 hash inputs of the run)
+    log = backend.component_log_size(dev, 29)
+    cols = [backend.col_alloc(1 << log) for _ in range(443)]
+    backend.trace_write(dev, 29, cols)
+    got = np.stack([backend.download(h, 192) for h in cols])
+    assert np.array_equal(got, GOLD["poseidon2"][:, :192])
+    for h in cols:
+        backend.col_free(h)
     backend.free_input(dev)
     inp.free()
 

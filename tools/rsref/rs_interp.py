@@ -91,6 +91,29 @@ class Packed:
     def __repr__(self): return f"Packed({[x.v for x in self.lanes]})"
 
 
+class Ref:
+    """`&mut` element of an array (what `iter_mut()` yields): reads and writes go to the slot."""
+    __slots__ = ("lst", "i")
+
+    def __init__(self, lst, i):
+        self.lst, self.i = lst, i
+
+    def get(self):
+        return self.lst[self.i]
+
+    def set(self, v):
+        self.lst[self.i] = v
+
+
+def deref(v):
+    return v.get() if isinstance(v, Ref) else v
+
+
+def copy_value(v):
+    """Rust arrays / tuples of Copy types have value semantics: `let a = b;` and `x = b;` copy."""
+    return list(v) if isinstance(v, list) else v
+
+
 class Struct:
     """Plain record (PackedExecutionBundle, DataAccess, ...)."""
 
@@ -249,6 +272,8 @@ class Parser:
         lhs = self.binop(0)
         if self.at("op", "..") or self.at("op", "..="):
             incl = self.eat("op")[1] == "..="
+            if self.at("op", "]") or self.at("op", ")"):
+                return ("range", lhs, None, incl)          # `a[1..]`
             rhs = self.binop(0)
             return ("range", lhs, rhs, incl)
         return lhs
@@ -281,7 +306,7 @@ class Parser:
             return ("not", self.unary())
         if self.at("op", "*"):
             self.i += 1
-            return self.unary()            # deref: values are handled by reference already
+            return ("deref", self.unary())
         if self.at("op", "&"):
             self.i += 1
             self.opt("id", "mut")
@@ -426,6 +451,33 @@ class Parser:
         raise SyntaxError(f"unexpected token {self.peek()} at {self.i}: {self.t[max(0, self.i - 6):self.i + 4]}")
 
 
+def parse_fn(src):
+    """`fn name<..>(a: T, b: &mut U) -> R where .. { body }` -> (name, [param names], body AST)"""
+    m = re.search(r"fn (\w+)", src)
+    name = m.group(1)
+    i = src.index("(", m.end())
+    depth, j = 0, i
+    while True:
+        depth += src[j] == "("
+        depth -= src[j] == ")"
+        if depth == 0:
+            break
+        j += 1
+    params = []
+    depth, cur = 0, ""
+    for ch in src[i + 1:j] + ",":
+        if ch == "," and depth == 0:
+            if cur.strip():
+                params.append(cur.split(":")[0].replace("mut", "").strip())
+            cur = ""
+            continue
+        depth += ch in "([<"
+        depth -= ch in ")]>"
+        cur += ch
+    b = src.index("{", j)
+    return name, params, Parser(lex(src[b:])).block()
+
+
 def parse_block(src):
     p = Parser(lex(src))
     b = p.block()
@@ -511,7 +563,24 @@ class Interp:
         return fn
 
     def assign(self, lhs, op, rhs, env):
-        val = self.eval(rhs, env)
+        val = copy_value(deref(self.eval(rhs, env)))
+        if lhs[0] == "deref":
+            tgt = self.eval(lhs[1], env) if lhs[1][0] == "path" else None
+            if isinstance(tgt, Ref):
+                if op != "=":
+                    val = self.arith({"+=": "+", "-=": "-", "*=": "*"}[op], tgt.get(), val)
+                tgt.set(val)
+                return None
+            return self.assign_to(lhs[1], op, val, env)
+        return self.assign_to(lhs, op, val, env)
+
+    def assign_to(self, lhs, op, val, env):
+        if lhs[0] == "array":              # destructuring assignment: [a, b, c] = expr
+            vals = list(val)
+            assert len(vals) == len(lhs[1])
+            for t, v in zip(lhs[1], vals):
+                self.assign_to(t, op, v, env)
+            return None
         if lhs[0] == "path":
             if op != "=":
                 val = self.arith({"+=": "+", "-=": "-", "*=": "*"}[op], env.get(lhs[1]), val)
@@ -531,6 +600,7 @@ class Interp:
         raise SyntaxError(f"cannot assign to {lhs[0]}")
 
     def arith(self, op, a, b):
+        a, b = deref(a), deref(b)
         if isinstance(a, bool) or isinstance(b, bool):
             if op == "==": return a == b
             if op == "!=": return a != b
@@ -588,8 +658,10 @@ class Interp:
             return [self.eval(x, env) for x in n[1]]
         if k == "repeat":
             return [self.eval(n[1], env)] * self.eval(n[2], env)
+        if k == "deref":
+            return deref(self.eval(n[1], env))
         if k == "neg":
-            return -self.eval(n[1], env)
+            return -deref(self.eval(n[1], env))
         if k == "not":
             return not self.truthy(self.eval(n[1], env))
         if k == "cast":
@@ -617,12 +689,15 @@ class Interp:
         if k == "assign":
             return self.assign(n[2], n[1], n[3], env)
         if k == "index":
-            base, idx = self.eval(n[1], env), self.eval(n[2], env)
+            base = deref(self.eval(n[1], env))
+            if n[2][0] == "range" and n[2][2] is None:      # a[k..]
+                return list(base[self.eval(n[2][1], env):])
+            idx = self.eval(n[2], env)
             if isinstance(idx, list):          # slice by range
                 return [base[i] for i in idx]
             return base[idx]
         if k == "field":
-            base = self.eval(n[1], env)
+            base = deref(self.eval(n[1], env))
             if isinstance(n[2], int):
                 if isinstance(base, Felt):
                     assert n[2] == 0
@@ -640,7 +715,7 @@ class Interp:
 
     def stmt(self, st, env):
         if st[0] == "let":
-            bind(st[1], self.eval(st[2], env) if st[2] is not None else None, env)
+            bind(st[1], copy_value(deref(self.eval(st[2], env))) if st[2] is not None else None, env)
         elif st[0] == "expr":
             self.eval(st[1], env)
         elif st[0] == "for":
@@ -650,8 +725,18 @@ class Interp:
                 self.eval(st[3], e)
 
     def method(self, r, name, a):
+        r = deref(r)
+        if name == "iter_mut":
+            return [Ref(r, i) for i in range(len(r))]
+        if name == "clone" and isinstance(r, list):
+            return list(r)
+        if name == "fold":
+            acc = a[0]
+            for x in r:
+                acc = a[1](acc, x)
+            return acc
         # value-preserving adaptors
-        if name in ("clone", "iter", "into_iter", "iter_mut", "collect", "try_into", "unwrap", "copied", "cloned", "to_vec",
+        if name in ("clone", "iter", "into_iter", "collect", "try_into", "unwrap", "copied", "cloned", "to_vec",
                     "as_slice", "into", "rev_placeholder"):
             return r
         if name == "to_array":
