@@ -810,6 +810,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   stage_upload(drel.p, &drel_h, sizeof(DevRelations), st);
 
   // ---- tree 2: interaction trace (prover.rs:96-102) ----
+  hipEvent_t sums_ready = nullptr;
   ColumnSet it_evals;
   {
     std::vector<uint32_t> logs;
@@ -851,10 +852,13 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     static_assert(PIN_SUMS + air::N_COMPONENTS * 4 <= PIN_ALPHAS, "pinned slot layout");
     const uint32_t* sums = pinned_words() + PIN_SUMS;
     CM_HIP(hipMemcpyAsync((void*)sums, d_sums.p, air::N_COMPONENTS * 16, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipStreamSynchronize(st));
-    for (int c = 0; c < air::N_COMPONENTS; c++) pf.claimed_sums.push_back(QM31::from_u32(sums + 4 * c));
+    // the host only waits for THIS copy (an event), after the tree-2 transforms and hashes have been enqueued behind it:
+    // no GPU idle time while the host reads and mixes the 34 sums
+    static thread_local hipEvent_t ev_sums = nullptr;
+    if (!ev_sums) CM_HIP(hipEventCreateWithFlags(&ev_sums, hipEventDisableTiming));
+    CM_HIP(hipEventRecord(ev_sums, st));
+    sums_ready = ev_sums;
   }
-  for (auto& cs : pf.claimed_sums) ch.mix_felts(&cs, 1);
   P.tick("interaction_gen");
   // interpolate in place: coeffs alias the evaluation buffer
   {
@@ -872,6 +876,12 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       for (auto& g : grps) interpolate(d_table.as<uint32_t*>() + g.off, g.n, g.log, *P.tw, st);
     }
     P.commit_enqueue(t, nullptr, true, st);
+  }
+  {
+    CM_HIP(hipEventSynchronize(sums_ready));
+    const uint32_t* sums = pinned_words() + PIN_SUMS;
+    for (int c = 0; c < air::N_COMPONENTS; c++) pf.claimed_sums.push_back(QM31::from_u32(sums + 4 * c));
+    for (auto& cs : pf.claimed_sums) ch.mix_felts(&cs, 1);
   }
   tr_evals.buf.release();
   // ---- stwo prove: composition polynomial.  Everything that does not depend on the random coefficient (accumulators,
