@@ -12,6 +12,7 @@ its launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 
 """
 import argparse
 import ctypes as C
+import datetime
 import json
 import os
 import sys
@@ -74,6 +75,60 @@ def cpu_baseline(sample_n, hip_words=None):
                       f"2^20/2^18/2^16 preprocessed + range-check tables), oracle prove_segment, OpenMP x{oracle_threads()} of {os.cpu_count()} host cores, {dt:.1f} s"}
 
 
+def run_sharded_child(args, world):
+    """`python -m torch.distributed.run ... -m cairo_m_amd.sharded --json` with a time limit; returns bench.py's `sharded` object."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith("TORCHELASTIC_") or k.startswith("ROLE_") or k.startswith("GROUP_") or
+                   k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"))}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "cairo_m_amd.sharded", "--fib-n", str(args.fib_n), "--steps", str(args.steps),
+           "--dist-backend", args.dist_backend, "--check-single", "--json"]
+    if args.force_device >= 0:
+        cmd += ["--force-device", str(args.force_device)]
+    mode = "one proof sharded over all ranks (strong scaling)"
+    import tempfile
+    with tempfile.TemporaryFile("w+") as fo, tempfile.TemporaryFile("w+") as fe:     # files, not pipes: nothing can block on them
+        p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=fo, stderr=fe, start_new_session=True)
+        try:
+            p.wait(timeout=args.sharded_timeout)
+        except subprocess.TimeoutExpired:
+            # the launcher and every rank it started (the ranks sit in process groups of their own): exactly those PIDs
+            import psutil
+            procs = []
+            try:
+                procs = psutil.Process(p.pid).children(recursive=True)
+            except psutil.Error:
+                pass
+            for q in procs:
+                try:
+                    q.kill()
+                except psutil.Error:
+                    pass
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            p.wait()
+            return {"mode": mode, "error": f"no result within {args.sharded_timeout} s (child job killed)"}
+        fo.seek(0)
+        fe.seek(0)
+        out, err = fo.read(), fe.read()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"mode": mode, "error": f"child job exited with status {p.returncode}", "stderr_tail": err[-1500:]}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"mode": mode, "error": f"unparsable child output: {e!r}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +138,7 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=FIB_N,
                     help="fibonacci_loop size the CPU oracle proves for cpu_baseline (default: the bench workload itself, ~14 s on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded-timeout", type=int, default=300, help="N > 1: time limit in seconds of the sharded-mode child job")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the second mode (one proof sharded over all ranks)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive `end_to_end` measurements")
     ap.add_argument("--no-kprof", action="store_true", help="debug: no in-library HIP-event kernel timing")
@@ -237,32 +293,14 @@ def main():
         # Second mode (BASELINE configs[3]): the `world` ranks prove ONE segment together — components split across
         # the ranks, rows split for Merkle hashing and DEEP quotients, collectives over RCCL (cairo_m_amd/sharded.py).  This is
         # single-proof LATENCY scaling (strong scaling); the headline `value` above stays the replica throughput.
-        try:
-            from cairo_m_amd.sharded import TorchComm, prove_sharded, shard_plan
-            owner, words = shard_plan(inp, world, be.L)
-            comm = TorchComm(words, device=local_rank)
-            p = prove_sharded(be, dev, comm)              # warm-up; also the proof whose words are compared below
-            sh_words = p.words().copy()
-            p.free()
-            p = be.prove_device(dev)
-            same = bool(sh_words.size == p.words().size and (sh_words == p.words()).all())
-            p.free()
-            sync()
-            ts = time.perf_counter()
-            for _ in range(args.steps):
-                prove_sharded(be, dev, comm).free()
-            torch.cuda.synchronize()
-            dts = time.perf_counter() - ts
-            tt = torch.tensor([dts, 0.0 if same else 1.0], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dts, all_same = float(tt[0].item()), tt[1].item() == 0.0
-            sharded = {"mode": "one proof sharded over all ranks (strong scaling)", "ms_per_proof": dts * 1e3 / args.steps,
-                       "value": st["cells"] * args.steps / dts, "unit": "M31 trace cells/s", "bit_identical_to_single_gpu_proof": all_same,
-                       "component_owner": owner, "collectives_per_proof": comm.calls // (args.steps + 1),
-                       "MB_sent_per_rank_per_proof": comm.bytes_moved / (args.steps + 1) / 1e6,
-                       "note": "whole components are the sharding unit; Merkle hashing of all four trees and the DEEP quotients are row-sharded; the (cheap) transforms of trees 0 / 3 and FRI are replicated in this version"}
-        except Exception as e:  # noqa: BLE001 — the replica measurement above must survive a failure of the second mode
-            sharded = {"mode": "one proof sharded over all ranks (strong scaling)", "error": repr(e)}
+        # It runs as a CHILD job (its own N ranks, launched by rank 0 with a time limit) after the replica measurement is
+        # complete: a collective that hangs or a rank that dies in this mode can then cost the `sharded` object, never the line.
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            sharded = run_sharded_child(args, world)
+            store.set("cm_sharded_child_done", "1")
+        else:
+            store.wait(["cm_sharded_child_done"], datetime.timedelta(seconds=args.sharded_timeout + 120))
     verified = None
     hip_words = None
     end_to_end = None

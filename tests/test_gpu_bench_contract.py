@@ -46,3 +46,11 @@ def test_gpus_2_self_spawns_and_reports_both_modes():
     s = d["sharded"]
     assert "error" not in s, s
     assert s["bit_identical_to_single_gpu_proof"] is True and s["ms_per_proof"] > 0 and len(s["component_owner"]) == 34
+
+
+def test_a_stuck_sharded_child_costs_only_the_sharded_object():
+    # a 1-second limit is shorter than the child's start-up: the child job is killed, the replica line must still be complete
+    d = _bench("--gpus", "2", "--dist-backend", "gloo", "--force-device", "0", "--steps", "1", "--warmup", "1", "--fib-n", "3000",
+               "--no-cpu-baseline", "--pipelined", "0", "--sharded-timeout", "1")
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["proof_verified"] is True
+    assert "error" in d["sharded"] and "killed" in d["sharded"]["error"]
