@@ -132,6 +132,17 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
         const uint32_t L = a.R - a.n + layer - 1;
         twp = a.xtw + ((1u << (a.R - 1)) - (1u << (a.R - 1 - L)));
       }
+      if (!INVERSE && rr == 0 && ss == 0) {
+        // first layer a forward transform applies = the top layer of this pass.  When it is the top layer of the TRANSFORM
+        // and the upper half of the input is implicit zero padding (an LDE: in_len <= 2^(n-1)), every butterfly is
+        // (x, 0) -> (x, x): no twiddle, no multiplication — one layer in ~22 of a 2^21 / 2^22 extension
+        if (a.hi == a.n && a.in_len <= (1u << (a.n - 1))) {
+#pragma clang loop unroll(full)
+          for (uint32_t e = 0; e < NE; e++)
+            if (!((e >> s) & 1u)) v[e | (1u << s)] = v[e];
+          continue;
+        }
+      }
 #pragma clang loop unroll(full)
       for (uint32_t e = 0; e < NE; e++) {
         if ((e >> s) & 1u) continue;

@@ -29,7 +29,12 @@ struct GatherBatch {
   std::vector<const uint32_t*> word_addrs, hash_addrs;
   std::vector<RowRun> runs;
   size_t run_words = 0;
-  std::vector<uint32_t> words, hashes, run_out;  // results (hashes: 8 words each)
+  // results (hashes: 8 words each): they stay in the calling thread's pinned landing buffer — valid until that thread's next
+  // stage_download_async (a proof carries ~1 MB of witnesses; zero-filling and copying them into vectors first cost ~80 us
+  // with the GPU idle)
+  const uint32_t* words = nullptr;
+  const uint32_t* hashes = nullptr;
+  const uint32_t* run_out = nullptr;
   size_t add_word(const uint32_t* p) { word_addrs.push_back(p); return word_addrs.size() - 1; }
   size_t add_hash(const uint32_t* p) { hash_addrs.push_back(p); return hash_addrs.size() - 1; }
   // values d_cols[c][row], c < n_cols  ->  run_out[returned offset + c]
@@ -41,10 +46,7 @@ struct GatherBatch {
   }
   void run(hipStream_t st) {
     // one upload (all address tables), three gather launches into one output buffer, ONE device->host copy
-    words.resize(word_addrs.size());
-    hashes.resize(hash_addrs.size() * 8);
-    run_out.resize(run_words);
-    const size_t nw = words.size(), nh = hashes.size(), nr = run_out.size(), total = nw + nh + nr;
+    const size_t nw = word_addrs.size(), nh = hash_addrs.size() * 8, nr = run_words, total = nw + nh + nr;
     if (!total) return;
     UploadBatch ub;
     const uint32_t** d_w = nullptr;
@@ -59,9 +61,9 @@ struct GatherBatch {
     if (nr) gather_runs(d_r, (uint32_t)runs.size(), out.u32() + nw + nh, st);
     const uint32_t* host = (const uint32_t*)stage_download_async(out.p, total * 4, st);
     CM_HIP(hipStreamSynchronize(st));
-    std::copy(host, host + nw, words.begin());
-    std::copy(host + nw, host + nw + nh, hashes.begin());
-    std::copy(host + nw + nh, host + total, run_out.begin());
+    words = host;
+    hashes = host + nw;
+    run_out = host + nw + nh;
   }
 };
 
@@ -202,22 +204,36 @@ struct MerkleTree {
 
   // Symbolic decommitment walk (Stwo MerkleProver::decommit).  queries_per_log_size: log -> sorted unique positions.
   DecommitPlan plan_decommit(const std::map<uint32_t, std::vector<uint32_t>>& queries_per_log_size, GatherBatch& gb) const {
+    const std::vector<uint32_t>* by_log[64] = {};
+    for (auto& kv : queries_per_log_size) if (kv.first < 64) by_log[kv.first] = &kv.second;
+    return plan_decommit(by_log, gb);
+  }
+  // one queried size only (FRI layer trees)
+  DecommitPlan plan_decommit(uint32_t log, const std::vector<uint32_t>& positions, GatherBatch& gb) const {
+    const std::vector<uint32_t>* by_log[64] = {};
+    by_log[log] = &positions;
+    return plan_decommit(by_log, gb);
+  }
+  DecommitPlan plan_decommit(const std::vector<uint32_t>* const (&by_log)[64], GatherBatch& gb) const {
     DecommitPlan plan;
     plan.hash0 = gb.hash_addrs.size();
     size_t ci = 0;
     size_t max_q = 0;
-    for (auto& kv : queries_per_log_size) max_q = std::max(max_q, kv.second.size());
+    for (auto* v : by_log) if (v) max_q = std::max(max_q, v->size());
     std::vector<uint32_t> last, total;   // scratch reused across the layers (no per-layer allocation)
     last.reserve(max_q);
     total.reserve(max_q);
-    plan.segs.reserve(max_q * layers.size());
+    {
+      size_t col_layers = 0;   // layers that carry columns (a FRI layer tree: one)
+      for (size_t c = 0; c < col_logs.size(); c++) if (c == 0 || col_logs[c] != col_logs[c - 1]) col_layers++;
+      plan.segs.reserve(max_q * col_layers);
+    }
     for (int layer_log = (int)layers.size() - 1; layer_log >= 0; layer_log--) {
       size_t c0 = ci;
       while (ci < cols.size() && col_logs[ci] == (uint32_t)layer_log) ci++;
       bool has_prev = (size_t)layer_log + 1 < layers.size();
       static const std::vector<uint32_t> empty;
-      auto it = queries_per_log_size.find((uint32_t)layer_log);
-      const std::vector<uint32_t>& colq = it == queries_per_log_size.end() ? empty : it->second;
+      const std::vector<uint32_t>& colq = (layer_log < 64 && by_log[layer_log]) ? *by_log[layer_log] : empty;
       total.clear();
       size_t pi = 0, qi = 0;
       while (pi < last.size() || qi < colq.size()) {
@@ -254,9 +270,13 @@ struct MerkleTree {
   static void finish_decommit(const DecommitPlan& plan, const GatherBatch& gb, std::vector<uint32_t>& queried_values,
                               MerkleDecommitment& d) {
     d.hash_witness.resize(plan.n_hash);
-    for (size_t i = 0; i < plan.n_hash; i++) memcpy(d.hash_witness[i].data(), &gb.hashes[8 * (plan.hash0 + i)], 32);
+    if (plan.n_hash) memcpy(d.hash_witness[0].data(), &gb.hashes[8 * plan.hash0], 32 * plan.n_hash);   // Hash32 = 32 contiguous bytes
+    size_t nq = 0, nwit = 0;
+    for (const auto& sg : plan.segs) (sg.is_query ? nq : nwit) += sg.count;
+    queried_values.reserve(queried_values.size() + nq);
+    d.column_witness.reserve(d.column_witness.size() + nwit);
     for (const auto& sg : plan.segs) {
-      const uint32_t* v = (sg.is_run ? gb.run_out.data() : gb.words.data()) + sg.off;
+      const uint32_t* v = (sg.is_run ? gb.run_out : gb.words) + sg.off;
       std::vector<uint32_t>& dst = sg.is_query ? queried_values : d.column_witness;
       dst.insert(dst.end(), v, v + sg.count);
     }

@@ -381,12 +381,15 @@ static QGather plan_gather_q(const uint32_t* const col4[4], const std::vector<ui
   return g;
 }
 static void finish_gather_q(const QGather& g, const GatherBatch& gb, std::vector<QM31>& out) {
+  out.reserve(out.size() + g.n);
   for (size_t i = 0; i < g.n; i++) out.push_back(QM31::from_u32(&gb.words[g.w0 + 4 * i]));
 }
 // compute_decommitment_positions_and_witness_evals (fold step 1): decommitment positions + witness requests
 static QGather plan_fri_positions(const uint32_t* const col4[4], const std::vector<uint32_t>& queries, std::vector<uint32_t>& positions,
                                   GatherBatch& gb) {
   std::vector<uint32_t> wpos;
+  wpos.reserve(queries.size());
+  positions.reserve(2 * queries.size());
   size_t i = 0;
   while (i < queries.size()) {
     uint32_t start = (queries[i] >> 1) << 1;
@@ -1296,7 +1299,8 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   // ---- queries + decommitment ----
   Queries queries;
   {
-    std::set<uint32_t> s;
+    std::vector<uint32_t>& s = queries.positions;
+    s.reserve(cfg.n_queries);
     uint32_t cnt = 0, mask = (1u << q_logs[0]) - 1;
     bool done = false;
     while (!done) {
@@ -1304,15 +1308,18 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       for (int k = 0; k < 8 && !done; k++) {
         uint32_t w;
         memcpy(&w, b.data() + 4 * k, 4);
-        s.insert(w & mask);
+        s.push_back(w & mask);
         if (++cnt == cfg.n_queries) done = true;
       }
     }
-    queries.positions.assign(s.begin(), s.end());
+    std::sort(s.begin(), s.end());                       // BTreeSet order: sorted, unique
+    s.erase(std::unique(s.begin(), s.end()), s.end());
     queries.log_domain_size = q_logs[0];
   }
+  ht.mark("decommit: queries drawn");
   std::map<uint32_t, std::vector<uint32_t>> qpos;
   for (auto l : q_logs) qpos[l] = queries.fold(queries.log_domain_size - l).positions;
+  ht.mark("decommit: qpos");
   {
     // One batched gather for every tree of the proof: FRI first layer, inner layers, the 4 commitment trees.
     GatherBatch gb;
@@ -1330,7 +1337,9 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       first_w.push_back(plan_fri_positions(c4, qpos[q_logs[k]], pos, gb));
       first_dpos[q_logs[k]] = pos;
     }
+    ht.mark("decommit: first positions");
     DecommitPlan first_plan = first_tree.plan_decommit(first_dpos, gb);
+    ht.mark("decommit: first tree plan");
     std::vector<QGather> inner_w;
     std::vector<DecommitPlan> inner_plan;
     {
@@ -1339,9 +1348,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
         const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
         std::vector<uint32_t> pos;
         inner_w.push_back(plan_fri_positions(c4, lq.positions, pos, gb));
-        std::map<uint32_t, std::vector<uint32_t>> dpos;
-        dpos[il->log] = pos;
-        inner_plan.push_back(il->tree.plan_decommit(dpos, gb));
+        inner_plan.push_back(il->tree.plan_decommit(il->log, pos, gb));
         lq = lq.fold(1);
       }
     }
