@@ -80,6 +80,23 @@ int32_t cm_shutdown(void) {
     g_inited = false;
   });
 }
+int32_t cm_pool_trim(void) {
+  return guard([&] {
+    bind_thread_to_library_device();
+    CM_HIP(hipStreamSynchronize(thread_main_stream()));
+    pool_trim();
+  });
+}
+int32_t cm_device_mem_info(uint64_t* free_bytes, uint64_t* total_bytes) {
+  return guard([&] {
+    CM_CHECK(free_bytes && total_bytes, "cm_device_mem_info: null output");
+    bind_thread_to_library_device();
+    size_t f = 0, t = 0;
+    CM_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes = f;
+    *total_bytes = t;
+  });
+}
 int32_t cm_stream_create(cm_stream_t* out) {
   return guard([&] {
     hipStream_t st;

@@ -404,6 +404,17 @@ def _backend_set_preprocessed_cache(self, on):
 
 Backend.set_preprocessed_cache = _backend_set_preprocessed_cache
 Backend.set_twiddle_cache = lambda self, on: self._ck(self.L.cm_set_twiddle_cache(C.c_int32(1 if on else 0)))
+Backend.pool_trim = lambda self: self._ck(self.L.cm_pool_trim())   # this thread's cached device blocks back to the driver
+
+
+def _backend_mem_info(self):
+    """cm_device_mem_info: (free, total) bytes of the library device's HBM."""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    self._ck(self.L.cm_device_mem_info(C.byref(f), C.byref(t)))
+    return f.value, t.value
+
+
+Backend.mem_info = _backend_mem_info
 
 
 # ---- compiled-program JSON (crates/common/src/program.rs:143-170, instruction.rs:609-655) ----------------------

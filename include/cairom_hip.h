@@ -35,6 +35,11 @@ typedef uint64_t cm_stream_t;
 /* ---- runtime ------------------------------------------------------------------------------- */
 int32_t cm_init(int32_t device);
 int32_t cm_shutdown(void);
+/* Returns the calling host thread's cached device blocks to the driver (the per-thread pool otherwise keeps the high-water
+ * mark of the largest segment proved: a 2^26-row segment leaves ~116 GiB cached). */
+int32_t cm_pool_trim(void);
+/* Free / total bytes of the library device's HBM (hipMemGetInfo): segment sizing for the 288 GB of an MI355X. */
+int32_t cm_device_mem_info(uint64_t* free_bytes, uint64_t* total_bytes);
 int32_t cm_last_error(char* buf, size_t buf_len);
 int32_t cm_stream_create(cm_stream_t* out);
 int32_t cm_stream_destroy(cm_stream_t s);
