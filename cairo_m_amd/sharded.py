@@ -133,6 +133,8 @@ def prove_sharded(backend, dev_input, comm, cfg=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fib-n", type=int, default=1000)
+    ap.add_argument("--mixed-iters", type=int, default=0,
+                    help="prove the all-opcode loop (cairo_m_amd/workloads.py, BASELINE configs[4]) with this many iterations instead")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--force-device", type=int, default=-1, help="every rank uses this GPU (tests: ranks sharing one GPU over gloo)")
     ap.add_argument("--steps", type=int, default=1)
@@ -150,7 +152,12 @@ def main():
     else:
         dist.init_process_group(a.dist_backend)
     be = Backend(local)
-    inp = synth_fibonacci(a.fib_n)
+    if a.mixed_iters:
+        from .lib import vm_run
+        from .workloads import all_opcodes_program
+        inp = vm_run(all_opcodes_program(a.mixed_iters)[0], entry_pc=0, args=(), n_returns=0)
+    else:
+        inp = synth_fibonacci(a.fib_n)
     owner, words = shard_plan(inp, dist.get_world_size(), be.L)
     comm = TorchComm(words, device=local)
     dev = be.upload_input(inp)

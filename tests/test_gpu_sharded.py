@@ -22,10 +22,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_sharded(world, fib_n, out):
+def _run_sharded(world, fib_n, out, mixed_iters=0):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "-m", "cairo_m_amd.sharded", "--fib-n", str(fib_n), "--dist-backend", "gloo",
-           "--force-device", "0", "--steps", "0", "--out", out]
+           "--force-device", "0", "--steps", "0", "--out", out, "--mixed-iters", str(mixed_iters)]
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -41,6 +41,27 @@ def test_sharded_proof_equals_single_gpu_proof(backend, oracle, tmp_path, world,
     p.free()
     out = str(tmp_path / "proof")
     log = _run_sharded(world, fib_n, out)
+    for r in range(world):
+        got = np.load(f"{out}.{r}.npy")
+        assert got.size == want.size, (r, got.size, want.size, log[-500:])
+        diff = np.nonzero(got != want)[0]
+        assert diff.size == 0, f"rank {r}: first differing words {diff[:8]} of {got.size}"
+    assert oracle.verify(want)[0] == 0
+    inp.free()
+
+
+@pytest.mark.parametrize("world,iters", [(2, 300), (4, 24_000), (8, 100_000)])
+def test_sharded_all_opcode_proof_equals_single_gpu_proof(backend, oracle, tmp_path, world, iters):
+    """BASELINE configs[4] shape: every opcode component live (24 of them with ~iters rows each), so the ownership plan spreads
+    many equal-size components over the ranks instead of fibonacci's five; (8, 100 000) is 4.35 M steps."""
+    from cairo_m_amd.lib import vm_run
+    from cairo_m_amd.workloads import all_opcodes_program
+    inp = vm_run(all_opcodes_program(iters)[0], entry_pc=0, args=(), n_returns=0)
+    p = backend.prove(inp)
+    want = p.words().copy()
+    p.free()
+    out = str(tmp_path / "proof")
+    log = _run_sharded(world, 0, out, mixed_iters=iters)
     for r in range(world):
         got = np.load(f"{out}.{r}.npy")
         assert got.size == want.size, (r, got.size, want.size, log[-500:])
