@@ -42,6 +42,26 @@ int main() {
     }
     printf("fork/join over %d streams: avg %.1f us  best %.1f us  (k=0: two kernels back to back)\n", k, sum / reps * 1000, best * 1000);
   }
+  // the same join when the side streams finished long before the main stream reaches it (main carries a kernel 10x longer)
+  for (int k = 0; k <= N; k++) {
+    float sum = 0; const int reps = 20;
+    for (int r = 0; r < reps + 3; r++) {
+      hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, main_s, d, 2000000u);
+      CK(hipEventRecord(t0, main_s));
+      if (k > 0) {
+        CK(hipEventRecord(fork_ev, main_s));
+        for (int i = 0; i < k; i++) { CK(hipStreamWaitEvent(s[i], fork_ev, 0)); hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s[i], d, W); }
+      }
+      hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, main_s, d, 10 * W);   // the big kernel stays on the main stream
+      for (int i = 0; i < k; i++) { CK(hipEventRecord(done[i], s[i])); CK(hipStreamWaitEvent(main_s, done[i], 0)); }
+      hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, main_s, d, W);
+      CK(hipEventRecord(t1, main_s));
+      CK(hipStreamSynchronize(main_s));
+      float ms; CK(hipEventElapsedTime(&ms, t0, t1));
+      if (r >= 3) sum += ms;
+    }
+    printf("big kernel on main, %d early side streams joined after it: avg %.1f us\n", k, sum / reps * 1000);
+  }
   // round trips: kernel -> D2H 32 B -> host -> H2D 64 B -> kernel
   for (int variant = 0; variant < 3; variant++) {
     float sum = 0; const int reps = 20;
