@@ -363,6 +363,29 @@ static F coset_vanishing_canonic(uint32_t log, CPoint<F> p) {
 struct Queries {
   std::vector<uint32_t> positions;
   uint32_t log_domain_size;
+  // Queries::generate: n_queries draws of log_domain_size bits, sorted and de-duplicated (BTreeSet order)
+  template <class Ch>
+  static Queries draw(Ch& ch, uint32_t n_queries, uint32_t log_domain_size) {
+    Queries q;
+    q.log_domain_size = log_domain_size;
+    std::vector<uint32_t>& s = q.positions;
+    s.reserve(n_queries);
+    const uint32_t mask = (1u << log_domain_size) - 1;
+    uint32_t cnt = 0;
+    bool done = false;
+    while (!done) {
+      auto b = ch.draw_random_bytes();
+      for (int k = 0; k < 8 && !done; k++) {
+        uint32_t w;
+        memcpy(&w, b.data() + 4 * k, 4);
+        s.push_back(w & mask);
+        if (++cnt == n_queries) done = true;
+      }
+    }
+    std::sort(s.begin(), s.end());
+    s.erase(std::unique(s.begin(), s.end()), s.end());
+    return q;
+  }
   Queries fold(uint32_t n) const {
     Queries q;
     q.log_domain_size = log_domain_size - n;
@@ -416,6 +439,46 @@ struct FriPhase {
   std::vector<std::unique_ptr<InnerLayer>> inner;
   void commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
               const std::function<void()>& while_gpu_busy);
+  // Decommitment of the FRI trees (first layer over the quotient columns, then one tree per inner layer): decommitment
+  // positions + witness evaluations of every layer are requested through the caller's GatherBatch (one gather launch for the
+  // whole proof), finish_decommit() distributes what came back.
+  std::vector<QGather> first_w, inner_w;
+  DecommitPlan first_plan;
+  std::vector<DecommitPlan> inner_plan;
+  void plan_decommit(const Queries& queries, const std::map<uint32_t, std::vector<uint32_t>>& qpos, const std::vector<ColumnSet>& quotients,
+                     const std::vector<uint32_t>& q_logs, GatherBatch& gb) {
+    std::map<uint32_t, std::vector<uint32_t>> first_dpos;
+    for (size_t k = 0; k < quotients.size(); k++) {
+      const uint32_t* c4[4] = {quotients[k].ptrs[0], quotients[k].ptrs[1], quotients[k].ptrs[2], quotients[k].ptrs[3]};
+      std::vector<uint32_t> pos;
+      first_w.push_back(plan_fri_positions(c4, qpos.at(q_logs[k]), pos, gb));
+      first_dpos[q_logs[k]] = std::move(pos);
+    }
+    first_plan = first_tree.plan_decommit(first_dpos, gb);
+    Queries lq = queries.fold(1);
+    for (auto& il : inner) {
+      const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
+      std::vector<uint32_t> pos;
+      inner_w.push_back(plan_fri_positions(c4, lq.positions, pos, gb));
+      inner_plan.push_back(il->tree.plan_decommit(il->log, pos, gb));
+      lq = lq.fold(1);
+    }
+  }
+  void finish_decommit(const GatherBatch& gb, ProofData& pf) const {
+    for (auto& g : first_w) finish_gather_q(g, gb, pf.fri_first.fri_witness);
+    {
+      std::vector<uint32_t> qv;
+      MerkleTree::finish_decommit(first_plan, gb, qv, pf.fri_first.decommitment);
+    }
+    for (size_t i = 0; i < inner.size(); i++) {
+      FriLayerProofData lp;
+      finish_gather_q(inner_w[i], gb, lp.fri_witness);
+      std::vector<uint32_t> qv;
+      MerkleTree::finish_decommit(inner_plan[i], gb, qv, lp.decommitment);
+      lp.commitment = inner[i]->root;
+      pf.fri_inner.push_back(std::move(lp));
+    }
+  }
 };
 void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
                       const std::function<void()>& while_gpu_busy) {
@@ -611,6 +674,77 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
   }
 }
 
+// ---- transcript steps shared by the single-GPU and the sharded prover ------------------------------------------------------
+// PcsConfig::mix_into + PublicData::mix_into (prover.rs:33-36, 62-66)
+static void mix_config_and_public_data(Channel& ch, const cm_pcs_config& cfg, const PublicData& d) {
+  ch.mix_u64(cfg.pow_bits);
+  ch.mix_u64(cfg.log_blowup_factor);
+  ch.mix_u64(cfg.n_queries);
+  ch.mix_u64(cfg.log_last_layer_degree_bound);
+  uint32_t w[7] = {d.initial_pc, d.initial_fp, d.final_pc, d.final_fp, d.clock, d.initial_root, d.final_root};
+  ch.mix_u32s(w, 7);
+  uint32_t lens[3] = {(uint32_t)d.program.size(), (uint32_t)d.input.size(), (uint32_t)d.output.size()};
+  ch.mix_u32s(lens, 3);
+  for (const auto* v : {&d.program, &d.input, &d.output}) {
+    std::vector<uint32_t> words;
+    for (auto& e : *v) if (e.present) { words.push_back(e.addr); for (int k = 0; k < 4; k++) words.push_back(e.value[k]); words.push_back(e.clock); }
+    ch.mix_u32s(words.data(), words.size());
+  }
+}
+// Relations::draw (prover.rs:94): (z, alpha) per relation, alpha powers for the device
+static void draw_relations(Channel& ch, HostRelations& hrel, DevRelations& drel_h) {
+  for (int r = 0; r < air::N_RELATIONS; r++) {
+    QM31 z, alpha;
+    ch.draw_two_felts(z, alpha);
+    hrel.z[r] = z;
+    QM31 cur(M31(1));
+    for (int i = 0; i < air::MAX_REL_SIZE; i++) { hrel.alpha_pow[r][i] = cur; cur = cur * alpha; }
+    z.to_u32(drel_h.z[r]);
+    for (int i = 0; i < air::MAX_REL_SIZE; i++) hrel.alpha_pow[r][i].to_u32(drel_h.alpha_pow[r][i]);
+  }
+}
+// random coefficient of the composition polynomial: powers[g] = rho^(total - 1 - g), uploaded as words
+static void draw_constraint_powers(Channel& ch, std::vector<QM31>& powers, DevBuf& d_powers, hipStream_t st) {
+  QM31 random_coeff = ch.draw_felt();
+  QM31 cur(M31(1));
+  const size_t total = powers.size();
+  for (size_t g = total; g-- > 0;) { powers[g] = cur; cur = cur * random_coeff; }
+  std::vector<uint32_t> powers_w(4 * total);
+  for (size_t g = 0; g < total; g++) powers[g].to_u32(&powers_w[4 * g]);
+  stage_upload(d_powers.p, powers_w.data(), powers_w.size() * 4, st);
+}
+
+// Sanity check of stwo `prove`: the composition polynomial's OODS value equals the constraints evaluated on the sampled mask
+// values (host-only work; both provers run it while the GPU is busy with the quotient / FRI kernels).
+static void check_composition_at_oods(const ProofData& pf, const std::vector<size_t>& tr0, const std::vector<size_t>& it0, const uint32_t* clog,
+                                      const HostRelations& hrel, const std::vector<QM31>& powers, const std::vector<size_t>& coff,
+                                      const CPoint<QM31>& oods) {
+  QM31 c4[4] = {pf.sampled_values[3][0][0], pf.sampled_values[3][1][0], pf.sampled_values[3][2][0], pf.sampled_values[3][3][0]};
+  QM31 comp = combine_ef(c4);
+  QM31 ppv[air::N_PREPROC];
+  for (int i = 0; i < air::N_PREPROC; i++) ppv[i] = pf.sampled_values[0][i][0];
+  QM31 sum;
+  for (int c = 0; c < air::N_COMPONENTS; c++) {
+    const air::ComponentInfo& info = air::component_info(c);
+    std::vector<QM31> tr, it;
+    for (int k = 0; k < info.n_trace; k++) tr.push_back(pf.sampled_values[1][tr0[c] + k][0]);
+    for (int k = 0; k < info.n_interaction; k++) for (auto& s : pf.sampled_values[2][it0[c] + k]) it.push_back(s);
+    QM31 shift = pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]));
+    QM31 num = point_eval(c, tr.data(), it.data(), ppv, hrel, &powers[coff[c]], info.n_base_constraints, shift);
+    sum += num * inv(coset_vanishing_canonic<QM31>(clog[c], oods));
+  }
+  if (sum != comp) throw CmError(10, "ConstraintsNotSatisfied: composition polynomial does not match the constraints at the OODS point");
+}
+// the OODS point from one drawn felt t: ((1 - t^2) / (1 + t^2), 2t / (1 + t^2))
+static CPoint<QM31> draw_oods_point(Channel& ch) {
+  QM31 t = ch.draw_felt();
+  QM31 t2 = t * t;
+  QM31 iv = inv(t2 + M31(1));
+  CPoint<QM31> p;
+  p.x = (QM31(M31(1)) - t2) * iv;
+  p.y = (t + t) * iv;
+  return p;
+}
 // =========================================================================================================
 // CM_HOST_TRACE=1: host-side time between marks on stderr (where the GPU sits idle waiting for the host)
 struct HostTrace {
@@ -671,23 +805,8 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   }
 
   // ---- transcript setup (prover.rs:33-36, 62-66) ----
-  ch.mix_u64(cfg.pow_bits);
-  ch.mix_u64(cfg.log_blowup_factor);
-  ch.mix_u64(cfg.n_queries);
-  ch.mix_u64(cfg.log_last_layer_degree_bound);
   pf.public_data = din.public_data;
-  {
-    const PublicData& d = pf.public_data;
-    uint32_t w[7] = {d.initial_pc, d.initial_fp, d.final_pc, d.final_fp, d.clock, d.initial_root, d.final_root};
-    ch.mix_u32s(w, 7);
-    uint32_t lens[3] = {(uint32_t)d.program.size(), (uint32_t)d.input.size(), (uint32_t)d.output.size()};
-    ch.mix_u32s(lens, 3);
-    for (const auto* v : {&d.program, &d.input, &d.output}) {
-      std::vector<uint32_t> words;
-      for (auto& e : *v) if (e.present) { words.push_back(e.addr); for (int k = 0; k < 4; k++) words.push_back(e.value[k]); words.push_back(e.clock); }
-      ch.mix_u32s(words.data(), words.size());
-    }
-  }
+  mix_config_and_public_data(ch, cfg, pf.public_data);
   ht.mark("setup");
   P.tick("setup");
 
@@ -800,15 +919,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   ch.mix_u64(pf.interaction_pow);
   HostRelations hrel;
   DevRelations drel_h;
-  for (int r = 0; r < air::N_RELATIONS; r++) {
-    QM31 z, alpha;
-    ch.draw_two_felts(z, alpha);
-    hrel.z[r] = z;
-    QM31 cur(M31(1));
-    for (int i = 0; i < air::MAX_REL_SIZE; i++) { hrel.alpha_pow[r][i] = cur; cur = cur * alpha; }
-    z.to_u32(drel_h.z[r]);
-    for (int i = 0; i < air::MAX_REL_SIZE; i++) hrel.alpha_pow[r][i].to_u32(drel_h.alpha_pow[r][i]);
-  }
+  draw_relations(ch, hrel, drel_h);
   DevBuf drel(sizeof(DevRelations));
   stage_upload(drel.p, &drel_h, sizeof(DevRelations), st);
 
@@ -1005,14 +1116,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
     P.commit_finish(P.trees[2]);
     P.tick("interaction_commit");
     for (int t = 0; t < 3; t++) for (auto l : P.trees[t].coeffs.logs) pf.cells += 1ull << l;
-    {
-      QM31 random_coeff = ch.draw_felt();
-      QM31 cur(M31(1));
-      for (size_t g = total_constraints; g-- > 0;) { powers[g] = cur; cur = cur * random_coeff; }
-      std::vector<uint32_t> powers_w(4 * total_constraints);
-      for (size_t g = 0; g < total_constraints; g++) powers[g].to_u32(&powers_w[4 * g]);
-      stage_upload(d_powers.p, powers_w.data(), powers_w.size() * 4, st);
-    }
+    draw_constraint_powers(ch, powers, d_powers, st);
     KProfRegion kreg("k_constraints(region)", st);
     Fork fk(st);
     launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
@@ -1122,14 +1226,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
 
   ht.mark("(composition commit done)");
   // ---- OODS sampling ----
-  CPoint<QM31> oods;
-  {
-    QM31 t = ch.draw_felt();
-    QM31 t2 = t * t;
-    QM31 iv = inv(t2 + M31(1));
-    oods.x = (QM31(M31(1)) - t2) * iv;
-    oods.y = (t + t) * iv;
-  }
+  const CPoint<QM31> oods = draw_oods_point(ch);
   ht.mark("oods: point drawn");
   std::map<uint32_t, CPoint<QM31>> prev_points;
   {
@@ -1266,29 +1363,8 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   // ---- FRI commit (FriPhase::commit) ----
   FriPhase fri;
   fri.commit(P, cfg, quotients, q_logs, pf, [&] {
-    // sanity check (stwo prove): composition OODS value == constraints at the sampled mask values.  Host-only
-    // work, so it runs here, while the GPU is busy with the (already enqueued) quotient and FRI kernels.
-    {
-      QM31 c4[4] = {pf.sampled_values[3][0][0], pf.sampled_values[3][1][0], pf.sampled_values[3][2][0], pf.sampled_values[3][3][0]};
-      QM31 comp = combine_ef(c4);
-      QM31 ppv[air::N_PREPROC];
-      for (int i = 0; i < air::N_PREPROC; i++) ppv[i] = pf.sampled_values[0][i][0];
-      QM31 sum;
-      for (int c = 0; c < air::N_COMPONENTS; c++) {
-        const air::ComponentInfo& info = air::component_info(c);
-        std::vector<QM31> tr, it;
-        for (int k = 0; k < info.n_trace; k++) tr.push_back(pf.sampled_values[1][tr0[c] + k][0]);
-        for (int k = 0; k < info.n_interaction; k++) for (auto& s : pf.sampled_values[2][it0[c] + k]) it.push_back(s);
-        QM31 shift = pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]));
-        QM31 num = point_eval(c, tr.data(), it.data(), ppv, hrel, &powers[coff[c]], info.n_base_constraints, shift);
-        sum += num * inv(coset_vanishing_canonic<QM31>(clog[c], oods));
-      }
-      if (sum != comp) throw CmError(10, "ConstraintsNotSatisfied: composition polynomial does not match the constraints at the OODS point");
-    }
-  
-  
+    check_composition_at_oods(pf, tr0, it0, clog, hrel, powers, coff, oods);
   });
-  MerkleTree& first_tree = fri.first_tree;
   auto& inner = fri.inner;
   P.tick("fri_commit");
   pf.proof_of_work = grind_gpu(ch.digest.data(), cfg.pow_bits, st);
@@ -1297,25 +1373,7 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
   ht.mark("pow done");
 
   // ---- queries + decommitment ----
-  Queries queries;
-  {
-    std::vector<uint32_t>& s = queries.positions;
-    s.reserve(cfg.n_queries);
-    uint32_t cnt = 0, mask = (1u << q_logs[0]) - 1;
-    bool done = false;
-    while (!done) {
-      hostch::Hash32 b = ch.draw_random_bytes();
-      for (int k = 0; k < 8 && !done; k++) {
-        uint32_t w;
-        memcpy(&w, b.data() + 4 * k, 4);
-        s.push_back(w & mask);
-        if (++cnt == cfg.n_queries) done = true;
-      }
-    }
-    std::sort(s.begin(), s.end());                       // BTreeSet order: sorted, unique
-    s.erase(std::unique(s.begin(), s.end()), s.end());
-    queries.log_domain_size = q_logs[0];
-  }
+  Queries queries = Queries::draw(ch, cfg.n_queries, q_logs[0]);
   ht.mark("decommit: queries drawn");
   std::map<uint32_t, std::vector<uint32_t>> qpos;
   for (auto l : q_logs) qpos[l] = queries.fold(queries.log_domain_size - l).positions;
@@ -1329,48 +1387,14 @@ ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
       gb.word_addrs.reserve((size_t)cfg.n_queries * 8 * (inner.size() + 1));
       gb.runs.reserve((size_t)cfg.n_queries * 4 * (q_logs[0] + 2));
     }
-    std::vector<QGather> first_w;
-    std::map<uint32_t, std::vector<uint32_t>> first_dpos;
-    for (size_t k = 0; k < quotients.size(); k++) {
-      const uint32_t* c4[4] = {quotients[k].ptrs[0], quotients[k].ptrs[1], quotients[k].ptrs[2], quotients[k].ptrs[3]};
-      std::vector<uint32_t> pos;
-      first_w.push_back(plan_fri_positions(c4, qpos[q_logs[k]], pos, gb));
-      first_dpos[q_logs[k]] = pos;
-    }
-    ht.mark("decommit: first positions");
-    DecommitPlan first_plan = first_tree.plan_decommit(first_dpos, gb);
-    ht.mark("decommit: first tree plan");
-    std::vector<QGather> inner_w;
-    std::vector<DecommitPlan> inner_plan;
-    {
-      Queries lq = queries.fold(1);
-      for (auto& il : inner) {
-        const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
-        std::vector<uint32_t> pos;
-        inner_w.push_back(plan_fri_positions(c4, lq.positions, pos, gb));
-        inner_plan.push_back(il->tree.plan_decommit(il->log, pos, gb));
-        lq = lq.fold(1);
-      }
-    }
+    fri.plan_decommit(queries, qpos, quotients, q_logs, gb);
     DecommitPlan tree_plan[4];
     ht.mark("decommit: fri plans");
     for (int t = 0; t < 4; t++) tree_plan[t] = P.trees[t].merkle.plan_decommit(qpos, gb);
     ht.mark("decommit: tree plans");
     gb.run(st);
     ht.mark("decommit: gather run (upload+kernel+d2h)");
-    for (auto& g : first_w) finish_gather_q(g, gb, pf.fri_first.fri_witness);
-    {
-      std::vector<uint32_t> qv;
-      MerkleTree::finish_decommit(first_plan, gb, qv, pf.fri_first.decommitment);
-    }
-    for (size_t i = 0; i < inner.size(); i++) {
-      FriLayerProofData lp;
-      finish_gather_q(inner_w[i], gb, lp.fri_witness);
-      std::vector<uint32_t> qv;
-      MerkleTree::finish_decommit(inner_plan[i], gb, qv, lp.decommitment);
-      lp.commitment = inner[i]->root;
-      pf.fri_inner.push_back(std::move(lp));
-    }
+    fri.finish_decommit(gb, pf);
     pf.decommitments.resize(4);
     pf.queried_values.resize(4);
     for (int t = 0; t < 4; t++) {
