@@ -757,668 +757,724 @@ struct HostTrace {
     t = n;
   }
 };
-ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
+// One segment proof on one GPU: the phases of prove_cairo_m (prover.rs:23-147) in transcript order.  Each phase enqueues its
+// kernels and returns at the next point where the transcript needs a device result; what crosses a phase boundary is a member.
+struct SegmentProver {
+  const DeviceInput& din;
+  const cm_prover_input& in;
+  const cm_pcs_config cfg;
+  std::unique_ptr<ProofData> out;
+  ProofData& pf;
   HostTrace ht;
-  const cm_prover_input& in = din.meta;
-  std::unique_ptr<ProofData> out(new ProofData());
-  ProofData& pf = *out;
-  pf.config = cfg;
-  bind_thread_to_library_device();
   Prover P;
-  P.cfg = cfg;
-  P.st = thread_main_stream();
-  hipStream_t st = P.st;
-  P.start();
-  auto t_start = P.t0;
-  Channel& ch = P.ch;
-
-  // ---- component log sizes (known from the input lengths) ----
-  uint32_t clog[air::N_COMPONENTS];
-  uint64_t nrows[air::N_COMPONENTS];
-  for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++) nrows[c] = in.n_bundles[c];
-  nrows[air::C_MEMORY] = in.n_initial_memory + in.n_final_memory;
-  nrows[air::C_MERKLE] = in.n_initial_tree + in.n_final_tree;
-  nrows[air::C_CLOCK_UPDATE] = in.n_clock_updates;
-  nrows[air::C_POSEIDON2] = in.n_initial_tree + in.n_final_tree;
-  for (int c = 0; c <= air::C_POSEIDON2; c++) clog[c] = log_size_for(nrows[c]);
-  clog[air::C_RC8] = 8; clog[air::C_RC16] = 16; clog[air::C_RC20] = 20; clog[air::C_BITWISE] = 18;
-  uint32_t max_log = 0;
-  for (int c = 0; c < air::N_COMPONENTS; c++) max_log = std::max(max_log, clog[c]);
-  for (int c = 0; c < air::N_COMPONENTS; c++) CM_CHECK(clog[c] <= 26, "component too large");
-  // launch orders: components by descending size (stable)
-  std::vector<int> by_size, by_size_all;
-  for (int c = 0; c < air::N_COMPONENTS; c++) { by_size_all.push_back(c); if (c < air::N_OPCODE_COMPONENTS) by_size.push_back(c); }
-  auto bigger = [&](int x, int y) { return clog[x] > clog[y]; };
-  std::stable_sort(by_size.begin(), by_size.end(), bigger);
-  std::stable_sort(by_size_all.begin(), by_size_all.end(), bigger);
-  const uint32_t comp_log = max_log + 1;
-  CM_CHECK(cfg.n_queries >= 1 && cfg.n_queries <= 4096, "PcsConfig: n_queries must be in 1..4096");
-  CM_CHECK(cfg.pow_bits <= 64, "PcsConfig: pow_bits must be at most 64");
-  CM_CHECK(cfg.log_last_layer_degree_bound <= max_log, "PcsConfig: log_last_layer_degree_bound exceeds the largest trace column");
+  hipStream_t st;
+  Channel& ch;
+  uint32_t clog[air::N_COMPONENTS];          // log2 rows of every component
+  uint32_t max_log = 0, comp_log = 0;        // largest component; composition polynomial = max_log + 1
+  std::vector<int> by_size, by_size_all;     // launch orders: opcode components / all components by descending size
   ProofTwiddles own_tw;
   std::unique_ptr<Fork> tw_fork;
-  if (tw_cache_enabled()) P.tw = cached_twiddles(comp_log + cfg.log_blowup_factor, st);
-  else {
-    tw_fork.reset(new Fork(st));
-    own_tw.build(comp_log + cfg.log_blowup_factor, tw_fork->stream(Fork::N - 1));   // joined before the first transform
-    P.tw = &own_tw.t;
-  }
-
-  // ---- transcript setup (prover.rs:33-36, 62-66) ----
-  pf.public_data = din.public_data;
-  mix_config_and_public_data(ch, cfg, pf.public_data);
-  ht.mark("setup");
-  P.tick("setup");
-
-  // ---- tree 0: preprocessed trace (prover.rs:70-73) ----
-  ColumnSet pp_evals;
-  std::unique_ptr<Fork> pp_fork;
-  bool build_tree0 = false;
-  if (pp_cache_enabled() && tl_pp_cache.valid && tl_pp_cache.log_blowup == cfg.log_blowup_factor) {
-    P.trees[0] = std::move(tl_pp_cache.tree);  // both handed back at the end of the proof
-    pp_evals = std::move(tl_pp_cache.evals);
-    tl_pp_cache.valid = false;
-    ch.mix_root(P.trees[0].root);
-  } else {
-    std::vector<uint32_t> logs(air::PREPROC_LOG, air::PREPROC_LOG + air::N_PREPROC);
-    pp_evals.alloc(logs, st);
-    for (int i = 0; i < air::N_PREPROC; i++) launch_preproc(i, logs[i], pp_evals.ptrs[i], st);
-    build_tree0 = true;   // enqueued on a side stream right after the trace-generation launches (below)
-  }
-  ht.mark("preprocessed enqueued");
-  P.tick("preprocessed");
-  ht.mark("preprocessed gpu done");
-
-  // ---- tree 1: execution trace (prover.rs:77-82; Claim::write_trace) ----
-  std::vector<size_t> tr0(air::N_COMPONENTS), it0(air::N_COMPONENTS);
-  ColumnSet tr_evals;
-  {
-    std::vector<uint32_t> logs;
-    for (int c = 0; c < air::N_COMPONENTS; c++) {
-      tr0[c] = logs.size();
-      for (int k = 0; k < air::component_info(c).n_trace; k++) logs.push_back(clog[c]);
-    }
-    tr_evals.alloc(logs, st);
-  }
-  DevBuf flag(4);   // range-check / bitwise lookup out of range: read back with the tree-1 root (no round trip of its own)
-  uint32_t* flag_host = pinned_words();
-  {
-    // multiplicity columns = histograms over every lookup of every opcode component (components/mod.rs:139-160)
-    CM_HIP(hipMemsetAsync(flag.p, 0, 4, st));
-    HistPtrs h;
-    h.rc8 = tr_evals.ptrs[tr0[air::C_RC8]]; h.rc16 = tr_evals.ptrs[tr0[air::C_RC16]];
-    h.rc20 = tr_evals.ptrs[tr0[air::C_RC20]]; h.bitwise = tr_evals.ptrs[tr0[air::C_BITWISE]];
-    h.error_flag = flag.u32();
-    if (h.rc16 == h.rc8 + (1u << 8) && h.rc20 == h.rc16 + (1u << 16) && h.bitwise == h.rc20 + (1u << 20)) {
-      // the four multiplicity columns are adjacent in the trace arena: one memset
-      CM_HIP(hipMemsetAsync(h.rc8, 0, 4 * ((size_t)(1u << 8) + (1u << 16) + (1u << 20) + (1u << 18)), st));
-    } else {
-      CM_HIP(hipMemsetAsync(h.rc8, 0, 4u << 8, st));
-      CM_HIP(hipMemsetAsync(h.rc16, 0, 4u << 16, st));
-      CM_HIP(hipMemsetAsync(h.rc20, 0, 4u << 20, st));
-      CM_HIP(hipMemsetAsync(h.bitwise, 0, 4u << 18, st));
-    }
-    // small opcode components (idle ones are 16 padding rows): trace + histogram of all of them in ONE launch
-    std::vector<SmallTraceJob> small_trace;
-    for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++)
-      if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch())
-        small_trace.push_back(SmallTraceJob{din.bundles[c].p, (uint32_t)in.n_bundles[c], tr_evals.dev(tr0[c]), clog[c], c});
-    DevBuf d_small_trace = upload(small_trace, st);
-    // components are independent: fork over side streams (trace then histogram of one component stay ordered)
-    KProfRegion kreg("k_trace_gen(region)", st);
-    Fork fk(st);
-    // large components first: their kernels keep the GPU busy while the host issues the ~40 launches of the idle
-    // ones (the host launch rate, not the GPU, bounds this region otherwise); histogram adds commute
-    // the batched small components first: ~100 us of pure latency on a handful of CUs, hidden under the large kernels
-    // (launched last it ran alone at the end of the region)
-    launch_trace_hist_small(d_small_trace.as<SmallTraceJob>(), (uint32_t)small_trace.size(), din.data_accesses.p, h, fk.stream(Fork::N - 2));
-    int spos = 0;
-    for (int pos = 0; pos < air::N_OPCODE_COMPONENTS; pos++) {
-      const int c = by_size[pos];
-      if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
-      hipStream_t sc = fk.stream(spos++ % (Fork::N - 2));
-      launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
-      launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, sc);
-    }
-    launch_memory_trace(din.init_mem.p, (uint32_t)in.n_initial_memory, din.fin_mem.p, (uint32_t)in.n_final_memory, in.initial_root,
-                        in.final_root, clog[air::C_MEMORY], tr_evals.dev(tr0[air::C_MEMORY]), fk.stream(air::C_MEMORY));
-    launch_merkle_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree, in.initial_root,
-                        in.final_root, clog[air::C_MERKLE], tr_evals.dev(tr0[air::C_MERKLE]), fk.stream(air::C_MERKLE));
-    launch_clock_update_trace(din.clock_updates.p, (uint32_t)in.n_clock_updates, clog[air::C_CLOCK_UPDATE],
-                              tr_evals.dev(tr0[air::C_CLOCK_UPDATE]), fk.stream(air::C_CLOCK_UPDATE));
-    launch_poseidon2_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree,
-                           clog[air::C_POSEIDON2], tr_evals.dev(tr0[air::C_POSEIDON2]), fk.stream(air::C_POSEIDON2));
-    fk.join();
-    kreg.close();
-    flag_host[0] = 0xffffffffu;
-    CM_HIP(hipMemcpyAsync(flag_host, flag.p, 4, hipMemcpyDeviceToHost, st));
-  }
-  if (tw_fork) tw_fork->join();   // the proof's twiddle tables are complete from here on
-  if (build_tree0) {
-    // tree 0 (a chain of ~30 small launches) is built on a side stream while the transforms and hashes of tree 1 keep
-    // the GPU busy; its root comes back together with the root of tree 1.  Forked from the stream position after the
-    // trace-generation launches so that its chain does not queue in front of them.
-    pp_fork.reset(new Fork(st));
-    P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
-  }
-  P.tick("trace_gen");
-  P.commit_enqueue(P.trees[1], &tr_evals, false, st);
-  if (pp_fork) pp_fork->join();   // tree 0 (a chain of ~30 small launches) has been running next to all of the above
-  // ONE round trip: root of tree 0 (when it was built in this proof), root of tree 1, the range-check flag
-  if (pp_fork) CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT0, P.trees[0].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, st));
-  P.trees[1].merkle.root(P.trees[1].root.data(), st);
-  if (pp_fork) memcpy(P.trees[0].root.data(), pinned_words() + PIN_ROOT0, 32);
-  if (pp_fork) ch.mix_root(P.trees[0].root);   // transcript order (prover.rs:70-82): root 0, claim, root 1
-  for (int c = 0; c < air::N_COMPONENTS; c++) { pf.claim_log_sizes.push_back(clog[c]); ch.mix_u64(clog[c]); }
-  ch.mix_root(P.trees[1].root);
-  CM_CHECK(flag_host[0] == 0, "trace generation: a range-check / bitwise lookup value is out of range");
-  P.tick("trace_commit");
-
-  // ---- interaction PoW + relations (prover.rs:90-94) ----
-  pf.interaction_pow = grind_gpu(ch.digest.data(), 2, st);
-  ch.mix_u64(pf.interaction_pow);
+  ColumnSet pp_evals, tr_evals;              // preprocessed / execution-trace evaluations (trace domain)
+  std::vector<size_t> tr0, it0;              // first column of every component in trees 1 / 2
   HostRelations hrel;
-  DevRelations drel_h;
-  draw_relations(ch, hrel, drel_h);
-  DevBuf drel(sizeof(DevRelations));
-  stage_upload(drel.p, &drel_h, sizeof(DevRelations), st);
-
-  // ---- tree 2: interaction trace (prover.rs:96-102) ----
-  hipEvent_t sums_ready = nullptr;
-  ColumnSet it_evals;
-  {
-    std::vector<uint32_t> logs;
-    for (int c = 0; c < air::N_COMPONENTS; c++) {
-      it0[c] = logs.size();
-      for (int k = 0; k < air::component_info(c).n_interaction; k++) logs.push_back(clog[c]);
-    }
-    it_evals.alloc(logs, st);
-  }
-  {
-    DevBuf d_sums(air::N_COMPONENTS * 16);
-    std::vector<LogupTailJob> jobs(air::N_COMPONENTS);
-    // small components (idle opcode components = 16 padding rows, the tiny builtins): ONE launch for all of them
-    std::vector<SmallLogupJob> small_jobs;
-    uint32_t small_max_log = 0;
-    for (int c = 0; c < air::N_COMPONENTS; c++)
-      if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) {
-        small_jobs.push_back(SmallLogupJob{(const uint32_t* const*)tr_evals.dev(tr0[c]), it_evals.dev(it0[c]), clog[c], c});
-        small_max_log = std::max(small_max_log, clog[c]);
-      }
-    DevBuf d_small = upload(small_jobs, st);
-    KProfRegion kreg("k_logup(region)", st);
-    Fork fk(st);
-    launch_logup_small(d_small.as<SmallLogupJob>(), (uint32_t)small_jobs.size(), small_max_log, (const uint32_t* const*)pp_evals.dev(),
-                       drel.as<DevRelations>(), fk.stream(Fork::N - 1));   // first: latency-bound, hidden under the large kernels
-    int spos = 0;
-    for (int pos = 0; pos < air::N_COMPONENTS; pos++) {   // large components first (see trace generation)
-      const int c = by_size_all[pos];
-      const air::ComponentInfo& info = air::component_info(c);
-      for (int k = 0; k < 4; k++) jobs[c].col[k] = it_evals.ptrs[it0[c] + info.n_interaction - 4 + k];
-      jobs[c].log_size = clog[c];
-      if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
-      launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
-                   drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos++ % (Fork::N - 1)));
-    }
-    fk.join();
-    kreg.close();
-    logup_finalize_all(jobs, d_sums.u32(), st);
-    static_assert(PIN_SUMS + air::N_COMPONENTS * 4 <= PIN_ALPHAS, "pinned slot layout");
-    const uint32_t* sums = pinned_words() + PIN_SUMS;
-    CM_HIP(hipMemcpyAsync((void*)sums, d_sums.p, air::N_COMPONENTS * 16, hipMemcpyDeviceToHost, st));
-    // the host only waits for THIS copy (an event), after the tree-2 transforms and hashes have been enqueued behind it:
-    // no GPU idle time while the host reads and mixes the 34 sums
-    static thread_local hipEvent_t ev_sums = nullptr;
-    if (!ev_sums) CM_HIP(hipEventCreateWithFlags(&ev_sums, hipEventDisableTiming));
-    CM_HIP(hipEventRecord(ev_sums, st));
-    sums_ready = ev_sums;
-  }
-  P.tick("interaction_gen");
-  // interpolate in place: coeffs alias the evaluation buffer
-  {
-    CommittedTree& t = P.trees[2];
-    t.coeffs = std::move(it_evals);
-    {
-      std::vector<uint32_t*> table;
-      struct Grp { uint32_t log, n; size_t off; };
-      std::vector<Grp> grps;
-      for (auto& kv : by_log(t.coeffs.logs)) {
-        grps.push_back(Grp{kv.first, (uint32_t)kv.second.size(), table.size()});
-        for (auto i : kv.second) table.push_back(t.coeffs.ptrs[i]);
-      }
-      DevBuf d_table = upload(table, st);
-      for (auto& g : grps) interpolate(d_table.as<uint32_t*>() + g.off, g.n, g.log, *P.tw, st);
-    }
-    P.commit_enqueue(t, nullptr, true, st);
-  }
-  {
-    CM_HIP(hipEventSynchronize(sums_ready));
-    const uint32_t* sums = pinned_words() + PIN_SUMS;
-    for (int c = 0; c < air::N_COMPONENTS; c++) pf.claimed_sums.push_back(QM31::from_u32(sums + 4 * c));
-    for (auto& cs : pf.claimed_sums) ch.mix_felts(&cs, 1);
-  }
-  tr_evals.buf.release();
-  // ---- stwo prove: composition polynomial.  Everything that does not depend on the random coefficient (accumulators,
-  // slots, per-component arguments, their uploads and memsets) is prepared and enqueued here, behind the tree-2 kernels;
-  // the root is read back, the coefficient drawn and its powers uploaded right before the launches. ----
-  size_t total_constraints = 0;
-  std::vector<size_t> coff(air::N_COMPONENTS);
-  for (int c = 0; c < air::N_COMPONENTS; c++) { coff[c] = total_constraints; total_constraints += air::component_info(c).n_constraints; }
-  std::vector<QM31> powers(total_constraints);
-  DevBuf d_powers(16 * total_constraints);
-  // accumulators: 4 columns per evaluation log.  The top size gets its own ColumnSet (it becomes the coefficient
-  // set of tree 3), all smaller sizes share one — two pointer-table uploads and two memsets instead of one pair
-  // per size.
-  struct AccRef { ColumnSet* set; size_t first; uint32_t* const* dev() const { return set->dev(first); } };
-  std::map<uint32_t, AccRef> accs;  // evaluation log -> its 4 accumulator columns
-  std::map<uint32_t, std::vector<int>> cgroups;
-  for (int c = 0; c < air::N_COMPONENTS; c++) cgroups[clog[c] + 1].push_back(c);
-  ColumnSet acc_top, acc_rest;
-  {
-    std::vector<uint32_t> rest_logs;
-    for (auto& kv : cgroups)
-      if (kv.first != comp_log) { accs[kv.first] = AccRef{&acc_rest, rest_logs.size()}; rest_logs.insert(rest_logs.end(), 4, kv.first); }
-    CM_CHECK(cgroups.count(comp_log), "composition polynomial log size mismatch");
-    accs[comp_log] = AccRef{&acc_top, 0};
-    acc_top.alloc(std::vector<uint32_t>(4, comp_log), st);
-    CM_HIP(hipMemsetAsync(acc_top.buf.p, 0, acc_top.buf.bytes, st));
-    if (!rest_logs.empty()) {
-      acc_rest.alloc(rest_logs, st);
-      CM_HIP(hipMemsetAsync(acc_rest.buf.p, 0, acc_rest.buf.bytes, st));
-    }
-  }
-  // The constraints are evaluated on CanonicCoset(log + 1).  With log_blowup_factor = 1 (REGULAR_96_BITS) that is the
-  // committed LDE domain and the kernels read the committed columns; with a larger blowup every polynomial is evaluated
-  // on its (log + 1) domain separately (Stwo does the same: `poly.evaluate(eval_domain)`), at the cost of one more forward
-  // transform per column and its memory.
-  CM_CHECK(cfg.log_blowup_factor >= 1 && cfg.log_blowup_factor <= 4, "PcsConfig: log_blowup_factor must be in 1..4");
-  ColumnSet cdom[3];   // evaluation-domain copies of trees 0..2 (only when log_blowup_factor > 1)
-  if (cfg.log_blowup_factor > 1) {
-    for (int t = 0; t < 3; t++) {
-      std::vector<uint32_t> logs(P.trees[t].coeffs.logs);
-      for (auto& l : logs) l += 1;
-      cdom[t].alloc(logs, st);
-      std::vector<const uint32_t*> table;
-      struct Grp { uint32_t log, n; size_t off; };
-      std::vector<Grp> grps;
-      for (auto& kv : by_log(P.trees[t].coeffs.logs)) {
-        grps.push_back(Grp{kv.first, (uint32_t)kv.second.size(), table.size()});
-        for (auto i : kv.second) table.push_back(P.trees[t].coeffs.ptrs[i]);
-        for (auto i : kv.second) table.push_back(cdom[t].ptrs[i]);
-      }
-      DevBuf d_table = upload(table, st);
-      const uint32_t** dt = d_table.as<const uint32_t*>();
-      for (auto& g : grps) evaluate((const uint32_t* const*)(dt + g.off), (uint32_t* const*)(dt + g.off + g.n), g.n, g.log, g.log + 1, *P.tw, st);
-      CM_HIP(hipStreamSynchronize(st));   // d_table is a temporary
-    }
-  }
-  auto cdom_cols = [&](int t, size_t first) -> const uint32_t* const* {
-    return (const uint32_t* const*)(cfg.log_blowup_factor > 1 ? cdom[t].dev(first) : P.trees[t].lde.dev(first));
-  };
-  {
-    // Components are independent except for the shared per-size accumulator.  Small sizes (many idle
-    // components of 2^4 rows, each a latency-bound launch) get a private zeroed accumulator slot per
-    // component and run concurrently on side streams; the slots are summed afterwards (field addition is
-    // exact, so the order is irrelevant).  Large sizes keep the shared accumulator and one stream per size.
-    constexpr uint32_t SLOT_MAX_LOG = 15;
-    struct SlotGroup { uint32_t el; uint32_t n; size_t off_words; size_t tab0; };
-    std::vector<SlotGroup> sgroups;
-    std::vector<int> slot_of(air::N_COMPONENTS, -1);
-    std::vector<uint32_t*> slot_tab;
-    size_t slot_words = 0;
-    for (auto& kv : cgroups)
-      if (kv.second.size() > 1 && kv.first <= SLOT_MAX_LOG) {
-        SlotGroup g{kv.first, (uint32_t)kv.second.size(), slot_words, slot_tab.size()};
-        for (size_t k = 0; k < kv.second.size(); k++) slot_of[kv.second[k]] = (int)(slot_tab.size() / 4 + k);
-        slot_tab.resize(slot_tab.size() + 4 * kv.second.size());
-        slot_words += (size_t)4 * kv.second.size() << kv.first;
-        sgroups.push_back(g);
-      }
-    DevBuf slots(slot_words * 4), d_slot_tab;
-    if (slot_words) {
-      CM_HIP(hipMemsetAsync(slots.p, 0, slot_words * 4, st));
-      for (auto& g : sgroups)
-        for (uint32_t k = 0; k < 4 * g.n; k++) slot_tab[g.tab0 + k] = slots.u32() + g.off_words + ((size_t)k << g.el);
-      d_slot_tab = upload(slot_tab, st);
-    }
-    // arguments of every component first: the small ones (<= 2^SMALL_COMPONENT_MAX_LOG rows) go to ONE batched launch
-    // whose argument array has to be uploaded before the fork
-    std::vector<ConstraintArgs> cargs(air::N_COMPONENTS);
-    std::vector<ConstraintArgs> small_args;
-    std::vector<int> small_cids;
-    uint32_t small_max_log = 0;
-    for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it) {
-      for (int c : it->second) {
-        const air::ComponentInfo& info = air::component_info(c);
-        ConstraintArgs& a = cargs[c];
-        a.tr = cdom_cols(1, tr0[c]);
-        a.it = cdom_cols(2, it0[c]);
-        a.pp = cdom_cols(0, 0);
-        a.rels = drel.as<DevRelations>();
-        a.coeff = d_powers.u32() + 4 * coff[c];
-        a.acc = slot_of[c] >= 0 ? d_slot_tab.as<uint32_t*>() + 4 * slot_of[c] : accs.at(it->first).dev();
-        a.log_size = clog[c];
-        a.n_base = info.n_base_constraints;
-        (pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]))).to_u32(a.cumsum_shift);
-        for (uint32_t k = 0; k < 2; k++) {
-          CPoint<M31> p = point_at_index(domain_index_at(clog[c] + 1, k));
-          a.denom_inv[k] = inv(coset_vanishing_canonic<M31>(clog[c], p)).v;
-        }
-        // a small component either owns a private slot or is alone in its size group: no accumulator is shared inside the batch
-        if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch() && (slot_of[c] >= 0 || it->second.size() == 1)) {
-          small_args.push_back(a);
-          small_cids.push_back(c);
-          small_max_log = std::max(small_max_log, clog[c]);
-        }
-      }
-    }
-    DevBuf d_small_args = upload(small_args, st), d_small_cids = upload(small_cids, st);
-    P.commit_finish(P.trees[2]);
-    P.tick("interaction_commit");
-    for (int t = 0; t < 3; t++) for (auto l : P.trees[t].coeffs.logs) pf.cells += 1ull << l;
-    draw_constraint_powers(ch, powers, d_powers, st);
-    KProfRegion kreg("k_constraints(region)", st);
-    Fork fk(st);
-    launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
-                             fk.stream(7));   // first: latency-bound, hidden under the large kernels
-    int gi = 0, small_rr = 0;
-    // large groups first (descending size) so the long kernels start early
-    for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it, ++gi) {
-      for (int c : it->second) {
-        if (std::find(small_cids.begin(), small_cids.end(), c) != small_cids.end()) continue;
-        hipStream_t sc = slot_of[c] >= 0 ? fk.stream(4 + (small_rr++ % 3)) : fk.stream(gi % 4);
-        launch_constraints(c, cargs[c], sc);
-      }
-    }
-    fk.join();
-    kreg.close();
-    for (auto& g : sgroups) sum_slots(accs.at(g.el).dev(), slots.u32() + g.off_words, g.n, g.el, st);
-  }
-  P.tick("constraints");
-  // DomainEvaluationAccumulator::finalize.  Stwo walks the sizes upward: interpolate(vals_l + evaluate_l(cur)).
-  // Interpolation is linear and interpolate_l(evaluate_l(cur)) is cur zero-padded (coefficient bases nest),
-  // so the same coefficients come from interpolating every accumulator at its OWN size (independent, on side
-  // streams) and adding the zero-padded coefficient vectors — field arithmetic is exact, the result is
-  // bit-identical, and the extend/add chain over the large domains disappears.
-  {
-    CommittedTree& t = P.trees[3];
-    {
-      Fork fk(st);
-      int k = 0;
-      for (auto it = accs.rbegin(); it != accs.rend(); ++it, ++k) interpolate(it->second.dev(), 4, it->first, *P.tw, fk.stream(k));
-      fk.join();
-    }
-    {
-      AddColumnsSrc as;
-      as.n = 0;
-      for (auto& kv : accs)
-        if (kv.first != comp_log) {
-          CM_CHECK(as.n < 28, "composition: too many accumulator sizes");
-          as.log[as.n] = kv.first;
-          as.src[as.n++] = (const uint32_t* const*)kv.second.dev();
-        }
-      add_columns_multi(acc_top.dev(), as, 4, st);
-    }
-    t.coeffs = std::move(acc_top);
-    P.commit_enqueue(t, nullptr, true, st);
-  }
-  // Sampling jobs = (log size, point): every column at the OODS point, plus the previous-row mask
-  // (oods - trace_step(log)) of each component's last LogUp column group.  All jobs share one pointer-table
-  // upload, one scratch buffer and ONE device->host copy of the results.  Everything but the points themselves is
-  // built (and uploaded) here, while tree 3 is being committed; the points follow once its root is in the transcript.
+  DevBuf drel;                               // DevRelations
+  std::vector<size_t> coff;                  // first constraint of every component
+  std::vector<QM31> powers;                  // random-coefficient powers, one per constraint
+  DevBuf d_powers;
+  CPoint<QM31> oods;
+  DevBuf d_oods_table, d_oods_out, d_qblob;  // sampling pointer table, sampled values, DEEP-quotient plan
+  size_t o_qjobs = 0, n_qjobs = 0;
+  std::vector<uint32_t> q_logs;
+  std::vector<ColumnSet> quotients;
+  FriPhase fri;
   struct ORef { int t; uint32_t c; bool prev; };
   struct OJob { uint32_t log; bool prev; CPoint<QM31> pt; std::vector<ORef> refs; size_t off = 0, out_off = 0; };
-  std::vector<OJob> ojobs;
-  {
-    std::map<uint32_t, std::vector<ORef>> groups;
-    for (int t = 0; t < 4; t++)
-      for (uint32_t c = 0; c < P.trees[t].coeffs.size(); c++) groups[P.trees[t].coeffs.logs[c]].push_back({t, c, false});
-    for (auto& kv : groups) ojobs.push_back(OJob{kv.first, false, {}, kv.second});
-    std::map<uint32_t, std::vector<ORef>> pgroups;
-    for (int c = 0; c < air::N_COMPONENTS; c++) {
-      int ni = air::component_info(c).n_interaction;
-      for (int k = ni - 4; k < ni; k++) pgroups[clog[c]].push_back({2, (uint32_t)(it0[c] + k), true});
-    }
-    for (auto& kv : pgroups) ojobs.push_back(OJob{kv.first, true, {}, kv.second});
-  }
-  size_t n_oods_out = 0;
-  DevBuf d_oods_table, d_oods_out;
-  {
-    std::vector<const uint32_t*> table;
-    for (auto& j : ojobs) {
-      j.off = table.size();
-      j.out_off = n_oods_out;
-      for (auto& r : j.refs) table.push_back(P.trees[r.t].coeffs.ptrs[r.c]);
-      n_oods_out += j.refs.size();
-    }
-    d_oods_table = upload(table, st);
-    d_oods_out.alloc(n_oods_out * 16);
-  }
-  // where the sampled value of (tree, column) lands in d_oods_out: the DEEP-quotient coefficients are computed on the
-  // device straight from there (k_quotient_coeffs)
-  std::vector<std::vector<uint32_t>> sidx_cur(4), sidx_prev(4);
-  for (int t = 0; t < 4; t++) { sidx_cur[t].assign(P.trees[t].coeffs.size(), 0); sidx_prev[t].assign(P.trees[t].coeffs.size(), 0); }
-  for (auto& j : ojobs)
-    for (size_t i = 0; i < j.refs.size(); i++)
-      (j.refs[i].prev ? sidx_prev : sidx_cur)[j.refs[i].t][j.refs[i].c] = (uint32_t)(j.out_off + i);
-  pf.sampled_values.resize(4);
-  for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
-  P.commit_finish(P.trees[3]);
-  P.tick("composition_commit");
-
-  // host side of compute_fri_quotients for every size group, packed into ONE upload:
-  // [column pointers | out pointers | col_index | coef_c | batches] per group, 16-byte aligned
   struct QRef { int t; uint32_t c; };
   struct QEntry { uint32_t col; uint32_t sidx; };   // column of the group, index of its sampled value in d_oods_out
   struct QBatch { CPoint<QM31> pt; std::vector<QEntry> entries; };
   struct QGroup { uint32_t log = 0; std::vector<const uint32_t*> cols; std::vector<QBatch> batches; ColumnSet out;
                   size_t o_cols = 0, o_out = 0, o_ci = 0, o_cc = 0, o_qb = 0, o_sidx = 0; };
-  DevBuf d_qblob;
-  size_t o_qjobs = 0, n_qjobs = 0;
-  std::vector<QGroup> qg;
-  std::vector<uint8_t> qblob;
-  auto qput = [&](const void* ptr, size_t bytes) {
-    size_t o = (qblob.size() + 15) & ~(size_t)15;
-    qblob.resize(o + bytes);
-    if (bytes && ptr) memcpy(qblob.data() + o, ptr, bytes);
-    return o;
-  };
+  std::vector<QGroup> qg;                    // DEEP-quotient size groups
+  SegmentProver(const DeviceInput& din_, const cm_pcs_config& cfg_)
+      : din(din_), in(din_.meta), cfg(cfg_), out(new ProofData()), pf(*out), st(nullptr), ch(P.ch) {
+    pf.config = cfg;
+    bind_thread_to_library_device();
+    P.cfg = cfg;
+    P.st = thread_main_stream();
+    st = P.st;
+    P.start();
+  }
+  ProofData* run() {
+    setup();
+    trace_commit();
+    interaction();
+    composition();
+    oods_sampling();
+    deep_quotients();
+    fri_and_pow();
+    decommit();
 
-  ht.mark("(composition commit done)");
-  // ---- OODS sampling ----
-  const CPoint<QM31> oods = draw_oods_point(ch);
-  ht.mark("oods: point drawn");
-  std::map<uint32_t, CPoint<QM31>> prev_points;
-  {
-    std::vector<OJob>& jobs = ojobs;
-    const size_t n_out = n_oods_out;
-    DevBuf& dout = d_oods_out;
+    P.finish();
+    pf.phase_ms = P.phase_ms;
+    pf.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - P.t0).count();
+    pf.steps = 0;
+    for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) pf.steps += in.n_bundles[i];
+    if (pp_cache_enabled()) {
+      tl_pp_cache.tree = std::move(P.trees[0]);
+      tl_pp_cache.evals = std::move(pp_evals);
+      tl_pp_cache.log_blowup = cfg.log_blowup_factor;
+      tl_pp_cache.valid = true;
+    } else if (tl_pp_cache.valid) {
+      tl_pp_cache = PreprocessedCache();  // switched off: give the buffers back to the pool
+    }
+    return out.release();
+    return out.release();
+  }
+
+  // component sizes, twiddles (side stream), transcript setup (prover.rs:33-66)
+  void setup() {
+    // ---- component log sizes (known from the input lengths) ----
+    uint64_t nrows[air::N_COMPONENTS];
+    for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++) nrows[c] = in.n_bundles[c];
+    nrows[air::C_MEMORY] = in.n_initial_memory + in.n_final_memory;
+    nrows[air::C_MERKLE] = in.n_initial_tree + in.n_final_tree;
+    nrows[air::C_CLOCK_UPDATE] = in.n_clock_updates;
+    nrows[air::C_POSEIDON2] = in.n_initial_tree + in.n_final_tree;
+    for (int c = 0; c <= air::C_POSEIDON2; c++) clog[c] = log_size_for(nrows[c]);
+    clog[air::C_RC8] = 8; clog[air::C_RC16] = 16; clog[air::C_RC20] = 20; clog[air::C_BITWISE] = 18;
+    max_log = 0;
+    for (int c = 0; c < air::N_COMPONENTS; c++) max_log = std::max(max_log, clog[c]);
+    for (int c = 0; c < air::N_COMPONENTS; c++) CM_CHECK(clog[c] <= 26, "component too large");
+    // launch orders: components by descending size (stable)
+    for (int c = 0; c < air::N_COMPONENTS; c++) { by_size_all.push_back(c); if (c < air::N_OPCODE_COMPONENTS) by_size.push_back(c); }
+    auto bigger = [&](int x, int y) { return clog[x] > clog[y]; };
+    std::stable_sort(by_size.begin(), by_size.end(), bigger);
+    std::stable_sort(by_size_all.begin(), by_size_all.end(), bigger);
+    comp_log = max_log + 1;
+    CM_CHECK(cfg.n_queries >= 1 && cfg.n_queries <= 4096, "PcsConfig: n_queries must be in 1..4096");
+    CM_CHECK(cfg.pow_bits <= 64, "PcsConfig: pow_bits must be at most 64");
+    CM_CHECK(cfg.log_last_layer_degree_bound <= max_log, "PcsConfig: log_last_layer_degree_bound exceeds the largest trace column");
+    if (tw_cache_enabled()) P.tw = cached_twiddles(comp_log + cfg.log_blowup_factor, st);
+    else {
+      tw_fork.reset(new Fork(st));
+      own_tw.build(comp_log + cfg.log_blowup_factor, tw_fork->stream(Fork::N - 1));   // joined before the first transform
+      P.tw = &own_tw.t;
+    }
+
+    // ---- transcript setup (prover.rs:33-36, 62-66) ----
+    pf.public_data = din.public_data;
+    mix_config_and_public_data(ch, cfg, pf.public_data);
+    ht.mark("setup");
+    P.tick("setup");
+
+  }
+
+  // tree 0 (preprocessed, on a side stream) and tree 1: execution trace of every component + commitment (prover.rs:70-82)
+  void trace_commit() {
+    // ---- tree 0: preprocessed trace (prover.rs:70-73) ----
+    std::unique_ptr<Fork> pp_fork;
+    bool build_tree0 = false;
+    if (pp_cache_enabled() && tl_pp_cache.valid && tl_pp_cache.log_blowup == cfg.log_blowup_factor) {
+      P.trees[0] = std::move(tl_pp_cache.tree);  // both handed back at the end of the proof
+      pp_evals = std::move(tl_pp_cache.evals);
+      tl_pp_cache.valid = false;
+      ch.mix_root(P.trees[0].root);
+    } else {
+      std::vector<uint32_t> logs(air::PREPROC_LOG, air::PREPROC_LOG + air::N_PREPROC);
+      pp_evals.alloc(logs, st);
+      for (int i = 0; i < air::N_PREPROC; i++) launch_preproc(i, logs[i], pp_evals.ptrs[i], st);
+      build_tree0 = true;   // enqueued on a side stream right after the trace-generation launches (below)
+    }
+    ht.mark("preprocessed enqueued");
+    P.tick("preprocessed");
+    ht.mark("preprocessed gpu done");
+
+    // ---- tree 1: execution trace (prover.rs:77-82; Claim::write_trace) ----
+    tr0.assign(air::N_COMPONENTS, 0);
+    it0.assign(air::N_COMPONENTS, 0);
     {
-      std::vector<EapJob> ej;
-      for (auto& j : jobs) {
-        j.pt = oods;
-        if (j.prev) {
-          CPoint<M31> step = point_at_index(subgroup_gen_index(j.log));
-          CPoint<QM31> neg{QM31(step.x), QM31(-step.y)};
-          j.pt = cadd(oods, neg);
-          prev_points[j.log] = j.pt;
-        }
-        ej.push_back(EapJob{j.log, (uint32_t)j.refs.size(), d_oods_table.as<const uint32_t*>() + j.off, j.pt.x, j.pt.y,
-                            dout.u32() + 4 * j.out_off});
+      std::vector<uint32_t> logs;
+      for (int c = 0; c < air::N_COMPONENTS; c++) {
+        tr0[c] = logs.size();
+        for (int k = 0; k < air::component_info(c).n_trace; k++) logs.push_back(clog[c]);
       }
-      eval_at_point_multi(ej, st);
+      tr_evals.alloc(logs, st);
     }
-    const uint32_t* w = (const uint32_t*)stage_download_async(dout.p, n_out * 16, st);   // read after the sync below
-    ht.mark("oods: enqueued");
-    // ---- while the evaluation kernels run: everything about the sampled values and the DEEP quotients
-    // (compute_fri_quotients) that does not depend on the values themselves ----
-    for (auto& j : jobs)
-      for (auto& r : j.refs) pf.sampled_values[r.t][r.c].push_back(QM31());   // mask order [-1, 0]: sized now, filled below
-    size_t n_samples = 0;
-    for (auto& t : pf.sampled_values) for (auto& c : t) n_samples += c.size();
-    std::map<uint32_t, std::vector<QRef>, std::greater<uint32_t>> qgroups;  // LDE log -> columns (tree-major order)
-    for (int t = 0; t < 4; t++)
-      for (uint32_t c = 0; c < P.trees[t].lde.size(); c++) qgroups[P.trees[t].lde.logs[c]].push_back({t, c});
-    for (auto& kv : qgroups) {
-      QGroup g;
-      g.log = kv.first;
-      for (uint32_t i = 0; i < kv.second.size(); i++) {
-        const QRef& r = kv.second[i];
-        g.cols.push_back(P.trees[r.t].lde.ptrs[r.c]);
-        const size_t ns = pf.sampled_values[r.t][r.c].size();
-        for (size_t k = 0; k < ns; k++) {
-          // sample points: [oods] or [prev, oods]
-          CPoint<QM31> pt = (ns == 2 && k == 0) ? prev_points[P.trees[r.t].coeffs.logs[r.c]] : oods;
-          size_t bi = 0;
-          for (; bi < g.batches.size(); bi++) if (g.batches[bi].pt.x == pt.x && g.batches[bi].pt.y == pt.y) break;
-          if (bi == g.batches.size()) g.batches.push_back(QBatch{pt, {}});
-          g.batches[bi].entries.push_back(QEntry{i, (ns == 2 && k == 0) ? sidx_prev[r.t][r.c] : sidx_cur[r.t][r.c]});
-        }
+    DevBuf flag(4);   // range-check / bitwise lookup out of range: read back with the tree-1 root (no round trip of its own)
+    uint32_t* flag_host = pinned_words();
+    {
+      // multiplicity columns = histograms over every lookup of every opcode component (components/mod.rs:139-160)
+      CM_HIP(hipMemsetAsync(flag.p, 0, 4, st));
+      HistPtrs h;
+      h.rc8 = tr_evals.ptrs[tr0[air::C_RC8]]; h.rc16 = tr_evals.ptrs[tr0[air::C_RC16]];
+      h.rc20 = tr_evals.ptrs[tr0[air::C_RC20]]; h.bitwise = tr_evals.ptrs[tr0[air::C_BITWISE]];
+      h.error_flag = flag.u32();
+      if (h.rc16 == h.rc8 + (1u << 8) && h.rc20 == h.rc16 + (1u << 16) && h.bitwise == h.rc20 + (1u << 20)) {
+        // the four multiplicity columns are adjacent in the trace arena: one memset
+        CM_HIP(hipMemsetAsync(h.rc8, 0, 4 * ((size_t)(1u << 8) + (1u << 16) + (1u << 20) + (1u << 18)), st));
+      } else {
+        CM_HIP(hipMemsetAsync(h.rc8, 0, 4u << 8, st));
+        CM_HIP(hipMemsetAsync(h.rc16, 0, 4u << 16, st));
+        CM_HIP(hipMemsetAsync(h.rc20, 0, 4u << 20, st));
+        CM_HIP(hipMemsetAsync(h.bitwise, 0, 4u << 18, st));
       }
-      size_t n_entries = 0;
-      for (auto& bt : g.batches) n_entries += bt.entries.size();
-      g.out.alloc(std::vector<uint32_t>(4, g.log), st, false);
-      g.o_cols = qput(g.cols.data(), g.cols.size() * sizeof(void*));
-      g.o_out = qput(g.out.ptrs.data(), 4 * sizeof(void*));
+      // small opcode components (idle ones are 16 padding rows): trace + histogram of all of them in ONE launch
+      std::vector<SmallTraceJob> small_trace;
+      for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++)
+        if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch())
+          small_trace.push_back(SmallTraceJob{din.bundles[c].p, (uint32_t)in.n_bundles[c], tr_evals.dev(tr0[c]), clog[c], c});
+      DevBuf d_small_trace = upload(small_trace, st);
+      // components are independent: fork over side streams (trace then histogram of one component stay ordered)
+      KProfRegion kreg("k_trace_gen(region)", st);
+      Fork fk(st);
+      // large components first: their kernels keep the GPU busy while the host issues the ~40 launches of the idle
+      // ones (the host launch rate, not the GPU, bounds this region otherwise); histogram adds commute
+      // the batched small components first: ~100 us of pure latency on a handful of CUs, hidden under the large kernels
+      // (launched last it ran alone at the end of the region)
+      launch_trace_hist_small(d_small_trace.as<SmallTraceJob>(), (uint32_t)small_trace.size(), din.data_accesses.p, h, fk.stream(Fork::N - 2));
+      int spos = 0;
+      for (int pos = 0; pos < air::N_OPCODE_COMPONENTS; pos++) {
+        const int c = by_size[pos];
+        if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
+        hipStream_t sc = fk.stream(spos++ % (Fork::N - 2));
+        launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
+        launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, sc);
+      }
+      launch_memory_trace(din.init_mem.p, (uint32_t)in.n_initial_memory, din.fin_mem.p, (uint32_t)in.n_final_memory, in.initial_root,
+                          in.final_root, clog[air::C_MEMORY], tr_evals.dev(tr0[air::C_MEMORY]), fk.stream(air::C_MEMORY));
+      launch_merkle_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree, in.initial_root,
+                          in.final_root, clog[air::C_MERKLE], tr_evals.dev(tr0[air::C_MERKLE]), fk.stream(air::C_MERKLE));
+      launch_clock_update_trace(din.clock_updates.p, (uint32_t)in.n_clock_updates, clog[air::C_CLOCK_UPDATE],
+                                tr_evals.dev(tr0[air::C_CLOCK_UPDATE]), fk.stream(air::C_CLOCK_UPDATE));
+      launch_poseidon2_trace(din.init_tree.p, (uint32_t)in.n_initial_tree, din.fin_tree.p, (uint32_t)in.n_final_tree,
+                             clog[air::C_POSEIDON2], tr_evals.dev(tr0[air::C_POSEIDON2]), fk.stream(air::C_POSEIDON2));
+      fk.join();
+      kreg.close();
+      flag_host[0] = 0xffffffffu;
+      CM_HIP(hipMemcpyAsync(flag_host, flag.p, 4, hipMemcpyDeviceToHost, st));
+    }
+    if (tw_fork) tw_fork->join();   // the proof's twiddle tables are complete from here on
+    if (build_tree0) {
+      // tree 0 (a chain of ~30 small launches) is built on a side stream while the transforms and hashes of tree 1 keep
+      // the GPU busy; its root comes back together with the root of tree 1.  Forked from the stream position after the
+      // trace-generation launches so that its chain does not queue in front of them.
+      pp_fork.reset(new Fork(st));
+      P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
+    }
+    P.tick("trace_gen");
+    P.commit_enqueue(P.trees[1], &tr_evals, false, st);
+    if (pp_fork) pp_fork->join();   // tree 0 (a chain of ~30 small launches) has been running next to all of the above
+    // ONE round trip: root of tree 0 (when it was built in this proof), root of tree 1, the range-check flag
+    if (pp_fork) CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT0, P.trees[0].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, st));
+    P.trees[1].merkle.root(P.trees[1].root.data(), st);
+    if (pp_fork) memcpy(P.trees[0].root.data(), pinned_words() + PIN_ROOT0, 32);
+    if (pp_fork) ch.mix_root(P.trees[0].root);   // transcript order (prover.rs:70-82): root 0, claim, root 1
+    for (int c = 0; c < air::N_COMPONENTS; c++) { pf.claim_log_sizes.push_back(clog[c]); ch.mix_u64(clog[c]); }
+    ch.mix_root(P.trees[1].root);
+    CM_CHECK(flag_host[0] == 0, "trace generation: a range-check / bitwise lookup value is out of range");
+    P.tick("trace_commit");
+
+  }
+
+  // interaction PoW, relation draws, tree 2: LogUp columns + commitment enqueue, claimed sums (prover.rs:90-102)
+  void interaction() {
+    // ---- interaction PoW + relations (prover.rs:90-94) ----
+    pf.interaction_pow = grind_gpu(ch.digest.data(), 2, st);
+    ch.mix_u64(pf.interaction_pow);
+    DevRelations drel_h;
+    draw_relations(ch, hrel, drel_h);
+    drel.alloc(sizeof(DevRelations));
+    stage_upload(drel.p, &drel_h, sizeof(DevRelations), st);
+
+    // ---- tree 2: interaction trace (prover.rs:96-102) ----
+    hipEvent_t sums_ready = nullptr;
+    ColumnSet it_evals;
+    {
+      std::vector<uint32_t> logs;
+      for (int c = 0; c < air::N_COMPONENTS; c++) {
+        it0[c] = logs.size();
+        for (int k = 0; k < air::component_info(c).n_interaction; k++) logs.push_back(clog[c]);
+      }
+      it_evals.alloc(logs, st);
+    }
+    {
+      DevBuf d_sums(air::N_COMPONENTS * 16);
+      std::vector<LogupTailJob> jobs(air::N_COMPONENTS);
+      // small components (idle opcode components = 16 padding rows, the tiny builtins): ONE launch for all of them
+      std::vector<SmallLogupJob> small_jobs;
+      uint32_t small_max_log = 0;
+      for (int c = 0; c < air::N_COMPONENTS; c++)
+        if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) {
+          small_jobs.push_back(SmallLogupJob{(const uint32_t* const*)tr_evals.dev(tr0[c]), it_evals.dev(it0[c]), clog[c], c});
+          small_max_log = std::max(small_max_log, clog[c]);
+        }
+      DevBuf d_small = upload(small_jobs, st);
+      KProfRegion kreg("k_logup(region)", st);
+      Fork fk(st);
+      launch_logup_small(d_small.as<SmallLogupJob>(), (uint32_t)small_jobs.size(), small_max_log, (const uint32_t* const*)pp_evals.dev(),
+                         drel.as<DevRelations>(), fk.stream(Fork::N - 1));   // first: latency-bound, hidden under the large kernels
+      int spos = 0;
+      for (int pos = 0; pos < air::N_COMPONENTS; pos++) {   // large components first (see trace generation)
+        const int c = by_size_all[pos];
+        const air::ComponentInfo& info = air::component_info(c);
+        for (int k = 0; k < 4; k++) jobs[c].col[k] = it_evals.ptrs[it0[c] + info.n_interaction - 4 + k];
+        jobs[c].log_size = clog[c];
+        if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
+        launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
+                     drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos++ % (Fork::N - 1)));
+      }
+      fk.join();
+      kreg.close();
+      logup_finalize_all(jobs, d_sums.u32(), st);
+      static_assert(PIN_SUMS + air::N_COMPONENTS * 4 <= PIN_ALPHAS, "pinned slot layout");
+      const uint32_t* sums = pinned_words() + PIN_SUMS;
+      CM_HIP(hipMemcpyAsync((void*)sums, d_sums.p, air::N_COMPONENTS * 16, hipMemcpyDeviceToHost, st));
+      // the host only waits for THIS copy (an event), after the tree-2 transforms and hashes have been enqueued behind it:
+      // no GPU idle time while the host reads and mixes the 34 sums
+      static thread_local hipEvent_t ev_sums = nullptr;
+      if (!ev_sums) CM_HIP(hipEventCreateWithFlags(&ev_sums, hipEventDisableTiming));
+      CM_HIP(hipEventRecord(ev_sums, st));
+      sums_ready = ev_sums;
+    }
+    P.tick("interaction_gen");
+    // interpolate in place: coeffs alias the evaluation buffer
+    {
+      CommittedTree& t = P.trees[2];
+      t.coeffs = std::move(it_evals);
       {
-        std::vector<uint32_t> ci, si;
-        std::vector<QuotientBatch> qb(g.batches.size());
-        for (size_t bi = 0; bi < g.batches.size(); bi++) {
-          memset(&qb[bi], 0, sizeof(QuotientBatch));
-          qb[bi].begin = (uint32_t)ci.size();
-          for (auto& en : g.batches[bi].entries) { ci.push_back(en.col); si.push_back(en.sidx); }
-          qb[bi].end = (uint32_t)ci.size();
-          g.batches[bi].pt.x.to_u32(qb[bi].point);   // words = (Pr.x, Pi.x): QM31 = (a.a, a.b, b.a, b.b)
-          g.batches[bi].pt.y.to_u32(qb[bi].point + 4);
+        std::vector<uint32_t*> table;
+        struct Grp { uint32_t log, n; size_t off; };
+        std::vector<Grp> grps;
+        for (auto& kv : by_log(t.coeffs.logs)) {
+          grps.push_back(Grp{kv.first, (uint32_t)kv.second.size(), table.size()});
+          for (auto i : kv.second) table.push_back(t.coeffs.ptrs[i]);
         }
-        g.o_ci = qput(ci.data(), ci.size() * 4);
-        g.o_sidx = qput(si.data(), si.size() * 4);
-        g.o_cc = qput(nullptr, n_entries * 16);            // filled by k_quotient_coeffs
-        g.o_qb = qput(qb.data(), qb.size() * sizeof(QuotientBatch));   // sums / batch coefficient filled on the device
+        DevBuf d_table = upload(table, st);
+        for (auto& g : grps) interpolate(d_table.as<uint32_t*>() + g.off, g.n, g.log, *P.tw, st);
       }
-      n_qjobs += g.batches.size();
-      qg.push_back(std::move(g));
+      P.commit_enqueue(t, nullptr, true, st);
     }
-    {  // the whole plan goes to the device now, behind the OODS kernels; only the random coefficient is still missing
-      o_qjobs = qput(nullptr, n_qjobs * sizeof(QuotientCoefJob));
-      d_qblob.alloc(qblob.size());
-      uint8_t* base = d_qblob.as<uint8_t>();
-      QuotientCoefJob* qj = (QuotientCoefJob*)(qblob.data() + o_qjobs);
-      size_t k = 0;
-      for (auto& g : qg)
-        for (size_t bi = 0; bi < g.batches.size(); bi++, k++) {
-          qj[k].qb = (QuotientBatch*)(base + g.o_qb) + bi;
-          qj[k].coef_c = (uint32_t*)(base + g.o_cc);
-          qj[k].sample_idx = (const uint32_t*)(base + g.o_sidx);
+    {
+      CM_HIP(hipEventSynchronize(sums_ready));
+      const uint32_t* sums = pinned_words() + PIN_SUMS;
+      for (int c = 0; c < air::N_COMPONENTS; c++) pf.claimed_sums.push_back(QM31::from_u32(sums + 4 * c));
+      for (auto& cs : pf.claimed_sums) ch.mix_felts(&cs, 1);
+    }
+    tr_evals.buf.release();
+  }
+
+  // stwo prove: constraint quotients of all components -> composition polynomial, tree 3 enqueued
+  void composition() {
+    // ---- stwo prove: composition polynomial.  Everything that does not depend on the random coefficient (accumulators,
+    // slots, per-component arguments, their uploads and memsets) is prepared and enqueued here, behind the tree-2 kernels;
+    // the root is read back, the coefficient drawn and its powers uploaded right before the launches. ----
+    size_t total_constraints = 0;
+    coff.assign(air::N_COMPONENTS, 0);
+    for (int c = 0; c < air::N_COMPONENTS; c++) { coff[c] = total_constraints; total_constraints += air::component_info(c).n_constraints; }
+    powers.assign(total_constraints, QM31());
+    d_powers.alloc(16 * total_constraints);
+    // accumulators: 4 columns per evaluation log.  The top size gets its own ColumnSet (it becomes the coefficient
+    // set of tree 3), all smaller sizes share one — two pointer-table uploads and two memsets instead of one pair
+    // per size.
+    struct AccRef { ColumnSet* set; size_t first; uint32_t* const* dev() const { return set->dev(first); } };
+    std::map<uint32_t, AccRef> accs;  // evaluation log -> its 4 accumulator columns
+    std::map<uint32_t, std::vector<int>> cgroups;
+    for (int c = 0; c < air::N_COMPONENTS; c++) cgroups[clog[c] + 1].push_back(c);
+    ColumnSet acc_top, acc_rest;
+    {
+      std::vector<uint32_t> rest_logs;
+      for (auto& kv : cgroups)
+        if (kv.first != comp_log) { accs[kv.first] = AccRef{&acc_rest, rest_logs.size()}; rest_logs.insert(rest_logs.end(), 4, kv.first); }
+      CM_CHECK(cgroups.count(comp_log), "composition polynomial log size mismatch");
+      accs[comp_log] = AccRef{&acc_top, 0};
+      acc_top.alloc(std::vector<uint32_t>(4, comp_log), st);
+      CM_HIP(hipMemsetAsync(acc_top.buf.p, 0, acc_top.buf.bytes, st));
+      if (!rest_logs.empty()) {
+        acc_rest.alloc(rest_logs, st);
+        CM_HIP(hipMemsetAsync(acc_rest.buf.p, 0, acc_rest.buf.bytes, st));
+      }
+    }
+    // The constraints are evaluated on CanonicCoset(log + 1).  With log_blowup_factor = 1 (REGULAR_96_BITS) that is the
+    // committed LDE domain and the kernels read the committed columns; with a larger blowup every polynomial is evaluated
+    // on its (log + 1) domain separately (Stwo does the same: `poly.evaluate(eval_domain)`), at the cost of one more forward
+    // transform per column and its memory.
+    CM_CHECK(cfg.log_blowup_factor >= 1 && cfg.log_blowup_factor <= 4, "PcsConfig: log_blowup_factor must be in 1..4");
+    ColumnSet cdom[3];   // evaluation-domain copies of trees 0..2 (only when log_blowup_factor > 1)
+    if (cfg.log_blowup_factor > 1) {
+      for (int t = 0; t < 3; t++) {
+        std::vector<uint32_t> logs(P.trees[t].coeffs.logs);
+        for (auto& l : logs) l += 1;
+        cdom[t].alloc(logs, st);
+        std::vector<const uint32_t*> table;
+        struct Grp { uint32_t log, n; size_t off; };
+        std::vector<Grp> grps;
+        for (auto& kv : by_log(P.trees[t].coeffs.logs)) {
+          grps.push_back(Grp{kv.first, (uint32_t)kv.second.size(), table.size()});
+          for (auto i : kv.second) table.push_back(P.trees[t].coeffs.ptrs[i]);
+          for (auto i : kv.second) table.push_back(cdom[t].ptrs[i]);
         }
-      stage_upload(d_qblob.p, qblob.data(), qblob.size(), st);
-    }
-    ht.mark("oods: overlapped quotient planning");
-    CM_HIP(hipStreamSynchronize(st));
-    ht.mark("oods: waited for gpu");
-    for (auto& j : jobs)
-      for (size_t i = 0; i < j.refs.size(); i++) {
-        auto& sv = pf.sampled_values[j.refs[i].t][j.refs[i].c];
-        (j.refs[i].prev ? sv.front() : sv.back()) = QM31::from_u32(&w[4 * (j.out_off + i)]);
+        DevBuf d_table = upload(table, st);
+        const uint32_t** dt = d_table.as<const uint32_t*>();
+        for (auto& g : grps) evaluate((const uint32_t* const*)(dt + g.off), (uint32_t* const*)(dt + g.off + g.n), g.n, g.log, g.log + 1, *P.tw, st);
+        CM_HIP(hipStreamSynchronize(st));   // d_table is a temporary
       }
-    std::vector<QM31> flat;
-    flat.reserve(n_samples);
-    for (auto& t : pf.sampled_values) for (auto& c : t) for (auto& sm : c) flat.push_back(sm);
-    ht.mark("oods: fill + flatten");
-    ch.mix_felts(flat.data(), flat.size());
-    ht.mark("oods: mix_felts");
-  }
-  P.tick("oods_sampling");
-  // ---- DEEP quotients (compute_fri_quotients): the value-dependent coefficients, one upload, the launches ----
-  QM31 qcoeff = ch.draw_felt();
-  std::vector<uint32_t> q_logs;
-  std::vector<ColumnSet> quotients;
-  {
-    // per-sample coefficients, batch sums and batch coefficients: one small kernel on the sampled values in HBM
-    quotient_coeffs((const QuotientCoefJob*)(d_qblob.as<uint8_t>() + o_qjobs), (uint32_t)n_qjobs, d_oods_out.u32(), qcoeff, st);
-    const uint8_t* base = d_qblob.as<uint8_t>();
-    // one kernel per size group, independent outputs: the small groups (latency-bound, ~140 us in a row) overlap the large
-    KProfRegion kregq("k_quotients", st);   // concurrent launches: timed as one interval
-    Fork fkq(st);
-    int qk = 0;
-    for (auto& g : qg) {
-      QuotientArgs a;
-      a.tw = view(*P.tw); a.log_size = g.log;
-      a.cols = (const uint32_t* const*)(base + g.o_cols);
-      a.out = (uint32_t* const*)(base + g.o_out);
-      a.col_index = (const uint32_t*)(base + g.o_ci);
-      a.coef_c = (const uint32_t*)(base + g.o_cc);
-      a.batches = (const QuotientBatch*)(base + g.o_qb);
-      a.n_batches = (uint32_t)g.batches.size();
-      launch_quotients(a, (double)g.cols.size(), fkq.stream(qk++));
-      q_logs.push_back(g.log);
-      quotients.push_back(std::move(g.out));
     }
-    fkq.join();
-    kregq.close();
+    auto cdom_cols = [&](int t, size_t first) -> const uint32_t* const* {
+      return (const uint32_t* const*)(cfg.log_blowup_factor > 1 ? cdom[t].dev(first) : P.trees[t].lde.dev(first));
+    };
+    {
+      // Components are independent except for the shared per-size accumulator.  Small sizes (many idle
+      // components of 2^4 rows, each a latency-bound launch) get a private zeroed accumulator slot per
+      // component and run concurrently on side streams; the slots are summed afterwards (field addition is
+      // exact, so the order is irrelevant).  Large sizes keep the shared accumulator and one stream per size.
+      constexpr uint32_t SLOT_MAX_LOG = 15;
+      struct SlotGroup { uint32_t el; uint32_t n; size_t off_words; size_t tab0; };
+      std::vector<SlotGroup> sgroups;
+      std::vector<int> slot_of(air::N_COMPONENTS, -1);
+      std::vector<uint32_t*> slot_tab;
+      size_t slot_words = 0;
+      for (auto& kv : cgroups)
+        if (kv.second.size() > 1 && kv.first <= SLOT_MAX_LOG) {
+          SlotGroup g{kv.first, (uint32_t)kv.second.size(), slot_words, slot_tab.size()};
+          for (size_t k = 0; k < kv.second.size(); k++) slot_of[kv.second[k]] = (int)(slot_tab.size() / 4 + k);
+          slot_tab.resize(slot_tab.size() + 4 * kv.second.size());
+          slot_words += (size_t)4 * kv.second.size() << kv.first;
+          sgroups.push_back(g);
+        }
+      DevBuf slots(slot_words * 4), d_slot_tab;
+      if (slot_words) {
+        CM_HIP(hipMemsetAsync(slots.p, 0, slot_words * 4, st));
+        for (auto& g : sgroups)
+          for (uint32_t k = 0; k < 4 * g.n; k++) slot_tab[g.tab0 + k] = slots.u32() + g.off_words + ((size_t)k << g.el);
+        d_slot_tab = upload(slot_tab, st);
+      }
+      // arguments of every component first: the small ones (<= 2^SMALL_COMPONENT_MAX_LOG rows) go to ONE batched launch
+      // whose argument array has to be uploaded before the fork
+      std::vector<ConstraintArgs> cargs(air::N_COMPONENTS);
+      std::vector<ConstraintArgs> small_args;
+      std::vector<int> small_cids;
+      uint32_t small_max_log = 0;
+      for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it) {
+        for (int c : it->second) {
+          const air::ComponentInfo& info = air::component_info(c);
+          ConstraintArgs& a = cargs[c];
+          a.tr = cdom_cols(1, tr0[c]);
+          a.it = cdom_cols(2, it0[c]);
+          a.pp = cdom_cols(0, 0);
+          a.rels = drel.as<DevRelations>();
+          a.coeff = d_powers.u32() + 4 * coff[c];
+          a.acc = slot_of[c] >= 0 ? d_slot_tab.as<uint32_t*>() + 4 * slot_of[c] : accs.at(it->first).dev();
+          a.log_size = clog[c];
+          a.n_base = info.n_base_constraints;
+          (pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]))).to_u32(a.cumsum_shift);
+          for (uint32_t k = 0; k < 2; k++) {
+            CPoint<M31> p = point_at_index(domain_index_at(clog[c] + 1, k));
+            a.denom_inv[k] = inv(coset_vanishing_canonic<M31>(clog[c], p)).v;
+          }
+          // a small component either owns a private slot or is alone in its size group: no accumulator is shared inside the batch
+          if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch() && (slot_of[c] >= 0 || it->second.size() == 1)) {
+            small_args.push_back(a);
+            small_cids.push_back(c);
+            small_max_log = std::max(small_max_log, clog[c]);
+          }
+        }
+      }
+      DevBuf d_small_args = upload(small_args, st), d_small_cids = upload(small_cids, st);
+      P.commit_finish(P.trees[2]);
+      P.tick("interaction_commit");
+      for (int t = 0; t < 3; t++) for (auto l : P.trees[t].coeffs.logs) pf.cells += 1ull << l;
+      draw_constraint_powers(ch, powers, d_powers, st);
+      KProfRegion kreg("k_constraints(region)", st);
+      Fork fk(st);
+      launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
+                               fk.stream(7));   // first: latency-bound, hidden under the large kernels
+      int gi = 0, small_rr = 0;
+      // large groups first (descending size) so the long kernels start early
+      for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it, ++gi) {
+        for (int c : it->second) {
+          if (std::find(small_cids.begin(), small_cids.end(), c) != small_cids.end()) continue;
+          hipStream_t sc = slot_of[c] >= 0 ? fk.stream(4 + (small_rr++ % 3)) : fk.stream(gi % 4);
+          launch_constraints(c, cargs[c], sc);
+        }
+      }
+      fk.join();
+      kreg.close();
+      for (auto& g : sgroups) sum_slots(accs.at(g.el).dev(), slots.u32() + g.off_words, g.n, g.el, st);
+    }
+    P.tick("constraints");
+    // DomainEvaluationAccumulator::finalize.  Stwo walks the sizes upward: interpolate(vals_l + evaluate_l(cur)).
+    // Interpolation is linear and interpolate_l(evaluate_l(cur)) is cur zero-padded (coefficient bases nest),
+    // so the same coefficients come from interpolating every accumulator at its OWN size (independent, on side
+    // streams) and adding the zero-padded coefficient vectors — field arithmetic is exact, the result is
+    // bit-identical, and the extend/add chain over the large domains disappears.
+    {
+      CommittedTree& t = P.trees[3];
+      {
+        Fork fk(st);
+        int k = 0;
+        for (auto it = accs.rbegin(); it != accs.rend(); ++it, ++k) interpolate(it->second.dev(), 4, it->first, *P.tw, fk.stream(k));
+        fk.join();
+      }
+      {
+        AddColumnsSrc as;
+        as.n = 0;
+        for (auto& kv : accs)
+          if (kv.first != comp_log) {
+            CM_CHECK(as.n < 28, "composition: too many accumulator sizes");
+            as.log[as.n] = kv.first;
+            as.src[as.n++] = (const uint32_t* const*)kv.second.dev();
+          }
+        add_columns_multi(acc_top.dev(), as, 4, st);
+      }
+      t.coeffs = std::move(acc_top);
+      P.commit_enqueue(t, nullptr, true, st);
+    }
   }
-  P.tick("quotients");
-  ht.mark("quotients: gpu done");
 
-  // ---- FRI commit (FriPhase::commit) ----
-  FriPhase fri;
-  fri.commit(P, cfg, quotients, q_logs, pf, [&] {
-    check_composition_at_oods(pf, tr0, it0, clog, hrel, powers, coff, oods);
-  });
-  auto& inner = fri.inner;
-  P.tick("fri_commit");
-  pf.proof_of_work = grind_gpu(ch.digest.data(), cfg.pow_bits, st);
-  ch.mix_u64(pf.proof_of_work);
-  P.tick("pow");
-  ht.mark("pow done");
+  // OODS point, mask values of every column (eval_at_point), DEEP-quotient plan built while the kernels run
+  void oods_sampling() {
+    // Sampling jobs = (log size, point): every column at the OODS point, plus the previous-row mask
+    // (oods - trace_step(log)) of each component's last LogUp column group.  All jobs share one pointer-table
+    // upload, one scratch buffer and ONE device->host copy of the results.  Everything but the points themselves is
+    // built (and uploaded) here, while tree 3 is being committed; the points follow once its root is in the transcript.
+    std::vector<OJob> ojobs;
+    {
+      std::map<uint32_t, std::vector<ORef>> groups;
+      for (int t = 0; t < 4; t++)
+        for (uint32_t c = 0; c < P.trees[t].coeffs.size(); c++) groups[P.trees[t].coeffs.logs[c]].push_back({t, c, false});
+      for (auto& kv : groups) ojobs.push_back(OJob{kv.first, false, {}, kv.second});
+      std::map<uint32_t, std::vector<ORef>> pgroups;
+      for (int c = 0; c < air::N_COMPONENTS; c++) {
+        int ni = air::component_info(c).n_interaction;
+        for (int k = ni - 4; k < ni; k++) pgroups[clog[c]].push_back({2, (uint32_t)(it0[c] + k), true});
+      }
+      for (auto& kv : pgroups) ojobs.push_back(OJob{kv.first, true, {}, kv.second});
+    }
+    size_t n_oods_out = 0;
+    {
+      std::vector<const uint32_t*> table;
+      for (auto& j : ojobs) {
+        j.off = table.size();
+        j.out_off = n_oods_out;
+        for (auto& r : j.refs) table.push_back(P.trees[r.t].coeffs.ptrs[r.c]);
+        n_oods_out += j.refs.size();
+      }
+      d_oods_table = upload(table, st);
+      d_oods_out.alloc(n_oods_out * 16);
+    }
+    // where the sampled value of (tree, column) lands in d_oods_out: the DEEP-quotient coefficients are computed on the
+    // device straight from there (k_quotient_coeffs)
+    std::vector<std::vector<uint32_t>> sidx_cur(4), sidx_prev(4);
+    for (int t = 0; t < 4; t++) { sidx_cur[t].assign(P.trees[t].coeffs.size(), 0); sidx_prev[t].assign(P.trees[t].coeffs.size(), 0); }
+    for (auto& j : ojobs)
+      for (size_t i = 0; i < j.refs.size(); i++)
+        (j.refs[i].prev ? sidx_prev : sidx_cur)[j.refs[i].t][j.refs[i].c] = (uint32_t)(j.out_off + i);
+    pf.sampled_values.resize(4);
+    for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
+    P.commit_finish(P.trees[3]);
+    P.tick("composition_commit");
 
-  // ---- queries + decommitment ----
-  Queries queries = Queries::draw(ch, cfg.n_queries, q_logs[0]);
-  ht.mark("decommit: queries drawn");
-  std::map<uint32_t, std::vector<uint32_t>> qpos;
-  for (auto l : q_logs) qpos[l] = queries.fold(queries.log_domain_size - l).positions;
-  ht.mark("decommit: qpos");
-  {
-    // One batched gather for every tree of the proof: FRI first layer, inner layers, the 4 commitment trees.
-    GatherBatch gb;
-    {  // ~ n_queries x tree depth x (2 siblings) per tree; growing these vectors dominated the planning time
-      const size_t per_tree = (size_t)cfg.n_queries * 2 * (q_logs[0] + 2);
-      gb.hash_addrs.reserve(per_tree * (inner.size() + 5));
-      gb.word_addrs.reserve((size_t)cfg.n_queries * 8 * (inner.size() + 1));
-      gb.runs.reserve((size_t)cfg.n_queries * 4 * (q_logs[0] + 2));
+    // host side of compute_fri_quotients for every size group, packed into ONE upload:
+    // [column pointers | out pointers | col_index | coef_c | batches] per group, 16-byte aligned
+    std::vector<uint8_t> qblob;
+    auto qput = [&](const void* ptr, size_t bytes) {
+      size_t o = (qblob.size() + 15) & ~(size_t)15;
+      qblob.resize(o + bytes);
+      if (bytes && ptr) memcpy(qblob.data() + o, ptr, bytes);
+      return o;
+    };
+
+    ht.mark("(composition commit done)");
+    // ---- OODS sampling ----
+    oods = draw_oods_point(ch);
+    ht.mark("oods: point drawn");
+    std::map<uint32_t, CPoint<QM31>> prev_points;
+    {
+      std::vector<OJob>& jobs = ojobs;
+      const size_t n_out = n_oods_out;
+      DevBuf& dout = d_oods_out;
+      {
+        std::vector<EapJob> ej;
+        for (auto& j : jobs) {
+          j.pt = oods;
+          if (j.prev) {
+            CPoint<M31> step = point_at_index(subgroup_gen_index(j.log));
+            CPoint<QM31> neg{QM31(step.x), QM31(-step.y)};
+            j.pt = cadd(oods, neg);
+            prev_points[j.log] = j.pt;
+          }
+          ej.push_back(EapJob{j.log, (uint32_t)j.refs.size(), d_oods_table.as<const uint32_t*>() + j.off, j.pt.x, j.pt.y,
+                              dout.u32() + 4 * j.out_off});
+        }
+        eval_at_point_multi(ej, st);
+      }
+      const uint32_t* w = (const uint32_t*)stage_download_async(dout.p, n_out * 16, st);   // read after the sync below
+      ht.mark("oods: enqueued");
+      // ---- while the evaluation kernels run: everything about the sampled values and the DEEP quotients
+      // (compute_fri_quotients) that does not depend on the values themselves ----
+      for (auto& j : jobs)
+        for (auto& r : j.refs) pf.sampled_values[r.t][r.c].push_back(QM31());   // mask order [-1, 0]: sized now, filled below
+      size_t n_samples = 0;
+      for (auto& t : pf.sampled_values) for (auto& c : t) n_samples += c.size();
+      std::map<uint32_t, std::vector<QRef>, std::greater<uint32_t>> qgroups;  // LDE log -> columns (tree-major order)
+      for (int t = 0; t < 4; t++)
+        for (uint32_t c = 0; c < P.trees[t].lde.size(); c++) qgroups[P.trees[t].lde.logs[c]].push_back({t, c});
+      for (auto& kv : qgroups) {
+        QGroup g;
+        g.log = kv.first;
+        for (uint32_t i = 0; i < kv.second.size(); i++) {
+          const QRef& r = kv.second[i];
+          g.cols.push_back(P.trees[r.t].lde.ptrs[r.c]);
+          const size_t ns = pf.sampled_values[r.t][r.c].size();
+          for (size_t k = 0; k < ns; k++) {
+            // sample points: [oods] or [prev, oods]
+            CPoint<QM31> pt = (ns == 2 && k == 0) ? prev_points[P.trees[r.t].coeffs.logs[r.c]] : oods;
+            size_t bi = 0;
+            for (; bi < g.batches.size(); bi++) if (g.batches[bi].pt.x == pt.x && g.batches[bi].pt.y == pt.y) break;
+            if (bi == g.batches.size()) g.batches.push_back(QBatch{pt, {}});
+            g.batches[bi].entries.push_back(QEntry{i, (ns == 2 && k == 0) ? sidx_prev[r.t][r.c] : sidx_cur[r.t][r.c]});
+          }
+        }
+        size_t n_entries = 0;
+        for (auto& bt : g.batches) n_entries += bt.entries.size();
+        g.out.alloc(std::vector<uint32_t>(4, g.log), st, false);
+        g.o_cols = qput(g.cols.data(), g.cols.size() * sizeof(void*));
+        g.o_out = qput(g.out.ptrs.data(), 4 * sizeof(void*));
+        {
+          std::vector<uint32_t> ci, si;
+          std::vector<QuotientBatch> qb(g.batches.size());
+          for (size_t bi = 0; bi < g.batches.size(); bi++) {
+            memset(&qb[bi], 0, sizeof(QuotientBatch));
+            qb[bi].begin = (uint32_t)ci.size();
+            for (auto& en : g.batches[bi].entries) { ci.push_back(en.col); si.push_back(en.sidx); }
+            qb[bi].end = (uint32_t)ci.size();
+            g.batches[bi].pt.x.to_u32(qb[bi].point);   // words = (Pr.x, Pi.x): QM31 = (a.a, a.b, b.a, b.b)
+            g.batches[bi].pt.y.to_u32(qb[bi].point + 4);
+          }
+          g.o_ci = qput(ci.data(), ci.size() * 4);
+          g.o_sidx = qput(si.data(), si.size() * 4);
+          g.o_cc = qput(nullptr, n_entries * 16);            // filled by k_quotient_coeffs
+          g.o_qb = qput(qb.data(), qb.size() * sizeof(QuotientBatch));   // sums / batch coefficient filled on the device
+        }
+        n_qjobs += g.batches.size();
+        qg.push_back(std::move(g));
+      }
+      {  // the whole plan goes to the device now, behind the OODS kernels; only the random coefficient is still missing
+        o_qjobs = qput(nullptr, n_qjobs * sizeof(QuotientCoefJob));
+        d_qblob.alloc(qblob.size());
+        uint8_t* base = d_qblob.as<uint8_t>();
+        QuotientCoefJob* qj = (QuotientCoefJob*)(qblob.data() + o_qjobs);
+        size_t k = 0;
+        for (auto& g : qg)
+          for (size_t bi = 0; bi < g.batches.size(); bi++, k++) {
+            qj[k].qb = (QuotientBatch*)(base + g.o_qb) + bi;
+            qj[k].coef_c = (uint32_t*)(base + g.o_cc);
+            qj[k].sample_idx = (const uint32_t*)(base + g.o_sidx);
+          }
+        stage_upload(d_qblob.p, qblob.data(), qblob.size(), st);
+      }
+      ht.mark("oods: overlapped quotient planning");
+      CM_HIP(hipStreamSynchronize(st));
+      ht.mark("oods: waited for gpu");
+      for (auto& j : jobs)
+        for (size_t i = 0; i < j.refs.size(); i++) {
+          auto& sv = pf.sampled_values[j.refs[i].t][j.refs[i].c];
+          (j.refs[i].prev ? sv.front() : sv.back()) = QM31::from_u32(&w[4 * (j.out_off + i)]);
+        }
+      std::vector<QM31> flat;
+      flat.reserve(n_samples);
+      for (auto& t : pf.sampled_values) for (auto& c : t) for (auto& sm : c) flat.push_back(sm);
+      ht.mark("oods: fill + flatten");
+      ch.mix_felts(flat.data(), flat.size());
+      ht.mark("oods: mix_felts");
     }
-    fri.plan_decommit(queries, qpos, quotients, q_logs, gb);
-    DecommitPlan tree_plan[4];
-    ht.mark("decommit: fri plans");
-    for (int t = 0; t < 4; t++) tree_plan[t] = P.trees[t].merkle.plan_decommit(qpos, gb);
-    ht.mark("decommit: tree plans");
-    gb.run(st);
-    ht.mark("decommit: gather run (upload+kernel+d2h)");
-    fri.finish_decommit(gb, pf);
-    pf.decommitments.resize(4);
-    pf.queried_values.resize(4);
-    for (int t = 0; t < 4; t++) {
-      MerkleTree::finish_decommit(tree_plan[t], gb, pf.queried_values[t], pf.decommitments[t]);
-      pf.commitments.push_back(P.trees[t].root);
+    P.tick("oods_sampling");
+  }
+
+  // compute_fri_quotients: one launch per size group
+  void deep_quotients() {
+    // ---- DEEP quotients (compute_fri_quotients): the value-dependent coefficients, one upload, the launches ----
+    QM31 qcoeff = ch.draw_felt();
+    {
+      // per-sample coefficients, batch sums and batch coefficients: one small kernel on the sampled values in HBM
+      quotient_coeffs((const QuotientCoefJob*)(d_qblob.as<uint8_t>() + o_qjobs), (uint32_t)n_qjobs, d_oods_out.u32(), qcoeff, st);
+      const uint8_t* base = d_qblob.as<uint8_t>();
+      // one kernel per size group, independent outputs: the small groups (latency-bound, ~140 us in a row) overlap the large
+      KProfRegion kregq("k_quotients", st);   // concurrent launches: timed as one interval
+      Fork fkq(st);
+      int qk = 0;
+      for (auto& g : qg) {
+        QuotientArgs a;
+        a.tw = view(*P.tw); a.log_size = g.log;
+        a.cols = (const uint32_t* const*)(base + g.o_cols);
+        a.out = (uint32_t* const*)(base + g.o_out);
+        a.col_index = (const uint32_t*)(base + g.o_ci);
+        a.coef_c = (const uint32_t*)(base + g.o_cc);
+        a.batches = (const QuotientBatch*)(base + g.o_qb);
+        a.n_batches = (uint32_t)g.batches.size();
+        launch_quotients(a, (double)g.cols.size(), fkq.stream(qk++));
+        q_logs.push_back(g.log);
+        quotients.push_back(std::move(g.out));
+      }
+      fkq.join();
+      kregq.close();
     }
+    P.tick("quotients");
+    ht.mark("quotients: gpu done");
+
   }
-  ht.mark("decommit: finish");
-  P.tick("decommit");
-  P.finish();
-  pf.phase_ms = P.phase_ms;
-  pf.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-  pf.steps = 0;
-  for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) pf.steps += in.n_bundles[i];
-  if (pp_cache_enabled()) {
-    tl_pp_cache.tree = std::move(P.trees[0]);
-    tl_pp_cache.evals = std::move(pp_evals);
-    tl_pp_cache.log_blowup = cfg.log_blowup_factor;
-    tl_pp_cache.valid = true;
-  } else if (tl_pp_cache.valid) {
-    tl_pp_cache = PreprocessedCache();  // switched off: give the buffers back to the pool
+
+  // FRI commit phase (FriPhase) and proof of work
+  void fri_and_pow() {
+    // ---- FRI commit (FriPhase::commit) ----
+    fri.commit(P, cfg, quotients, q_logs, pf, [&] {
+      check_composition_at_oods(pf, tr0, it0, clog, hrel, powers, coff, oods);
+    });
+    P.tick("fri_commit");
+    pf.proof_of_work = grind_gpu(ch.digest.data(), cfg.pow_bits, st);
+    ch.mix_u64(pf.proof_of_work);
+    P.tick("pow");
+    ht.mark("pow done");
+
   }
-  return out.release();
-}
+
+  // queries, one batched gather for every tree, proof assembly
+  void decommit() {
+    // ---- queries + decommitment ----
+    Queries queries = Queries::draw(ch, cfg.n_queries, q_logs[0]);
+    ht.mark("decommit: queries drawn");
+    std::map<uint32_t, std::vector<uint32_t>> qpos;
+    for (auto l : q_logs) qpos[l] = queries.fold(queries.log_domain_size - l).positions;
+    ht.mark("decommit: qpos");
+    {
+      // One batched gather for every tree of the proof: FRI first layer, inner layers, the 4 commitment trees.
+      GatherBatch gb;
+      {  // ~ n_queries x tree depth x (2 siblings) per tree; growing these vectors dominated the planning time
+        const size_t per_tree = (size_t)cfg.n_queries * 2 * (q_logs[0] + 2);
+        gb.hash_addrs.reserve(per_tree * (fri.inner.size() + 5));
+        gb.word_addrs.reserve((size_t)cfg.n_queries * 8 * (fri.inner.size() + 1));
+        gb.runs.reserve((size_t)cfg.n_queries * 4 * (q_logs[0] + 2));
+      }
+      fri.plan_decommit(queries, qpos, quotients, q_logs, gb);
+      DecommitPlan tree_plan[4];
+      ht.mark("decommit: fri plans");
+      for (int t = 0; t < 4; t++) tree_plan[t] = P.trees[t].merkle.plan_decommit(qpos, gb);
+      ht.mark("decommit: tree plans");
+      gb.run(st);
+      ht.mark("decommit: gather run (upload+kernel+d2h)");
+      fri.finish_decommit(gb, pf);
+      pf.decommitments.resize(4);
+      pf.queried_values.resize(4);
+      for (int t = 0; t < 4; t++) {
+        MerkleTree::finish_decommit(tree_plan[t], gb, pf.queried_values[t], pf.decommitments[t]);
+        pf.commitments.push_back(P.trees[t].root);
+      }
+    }
+    ht.mark("decommit: finish");
+    P.tick("decommit");
+  }
+};
+ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) { return SegmentProver(din, cfg).run(); }
 
 #include "prover_sharded.inc"
 
