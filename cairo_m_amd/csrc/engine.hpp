@@ -88,6 +88,15 @@ void merkle_top(MerkleTopArgs& a, hipStream_t st);   // fills a.ticket
 // device-side transcript step of the FRI commit phase: chan = {digest[8], n_sent} (9 u32);
 // chan <- mix_root(root); felt_out[4] <- draw_felt(); root_log[8] <- root (read back once at the end)
 void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log, hipStream_t st);
+// same, with the channel state {digest[8], n_sent} passed in the kernel arguments and stored to d_chan first
+void chan_init_mix_root_draw(const uint32_t init9[9], uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log,
+                             hipStream_t st);
+// transcript step behind the trace commitment on the device: mix_root(root), interaction PoW, mix_u64(nonce), Relations::draw.
+// d_rel_z[n_rel][4], d_rel_pow[n_rel][max_rel][4] (= DevRelations); d_out16 = {root[8], nonce[2], n_sent, error, z0[4]}
+void step_pow_relations(const uint32_t init9[9], const uint32_t* d_root, uint32_t pow_bits, uint32_t n_rel, uint32_t max_rel, uint32_t* d_rel_z,
+                        uint32_t* d_rel_pow, uint32_t* d_out16, hipStream_t st);
+// d_powers[g] = rho^(n - 1 - g) (QM31 words), rho read from device memory
+void coeff_powers(const uint32_t* d_rho, uint32_t* d_powers, uint32_t n, hipStream_t st);
 uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st);
 // out[q * width + w] = addrs[q][w]  (decommitment gathers: width 1 = values, 8 = hashes)
 void gather_words(const uint32_t* const* d_addrs, uint32_t n, uint32_t width, uint32_t* d_out, hipStream_t st);
@@ -162,7 +171,8 @@ const void* stage_download_async(const void* src, size_t bytes, hipStream_t st);
 // 1024 pinned words per host thread; fixed slots (words): 0 range-check flag, 2-3 grind nonce, 8-15 Merkle root,
 // 16-23 root of tree 0, 32-175 claimed sums, 256-351 FRI challenges, 384-575 FRI roots, 640-1023 last FRI layer
 uint32_t* pinned_words();
-enum PinnedSlot : uint32_t { PIN_FLAG = 0, PIN_NONCE = 2, PIN_ROOT = 8, PIN_ROOT0 = 16, PIN_SUMS = 32, PIN_ALPHAS = 256, PIN_ROOTS = 384,
+constexpr uint32_t INTERACTION_POW_BITS = 2;   // relations::INTERACTION_POW_BITS (prover.rs:90, verifier.rs:55-58)
+enum PinnedSlot : uint32_t { PIN_FLAG = 0, PIN_NONCE = 2, PIN_ROOT = 8, PIN_ROOT0 = 16, PIN_SUMS = 32, PIN_ROOT2 = 176, PIN_COEFF = 184, PIN_STEP1 = 192, PIN_ALPHAS = 256, PIN_ROOTS = 384,
                             PIN_LAST_LAYER = 640, PIN_WORDS = 1024 };
 // Small host->device uploads (pointer arrays, coefficients, positions) go through a pinned staging ring
 // and hipMemcpyAsync on the launch stream: no host sync, no pageable-copy stall.

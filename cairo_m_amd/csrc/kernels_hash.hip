@@ -47,6 +47,94 @@ __global__ void k_chan_mix_root_draw(uint32_t* chan, const uint32_t* root, uint3
   chan_mix_root_draw_quad(threadIdx.x, chan, root, felt_out, root_log, x8, felt);
 }
 
+// powers[g] = rho^(n - 1 - g): the random-coefficient powers of the composition polynomial, one thread per power (square and
+// multiply), from the coefficient the device-side transcript step (k_chan_mix_root_draw) left in device memory
+__global__ void __launch_bounds__(256) k_coeff_powers(const uint32_t* __restrict__ rho4, uint32_t* __restrict__ powers, uint32_t n) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= n) return;
+  QM31 r = QM31::from_u32(rho4), acc{M31(1)};
+  for (uint32_t e = n - 1 - g; e; e >>= 1) {
+    if (e & 1u) acc = acc * r;
+    r = r * r;
+  }
+  acc.to_u32(powers + 4 * g);
+}
+
+// the same step with the channel state handed over in the kernel arguments (no upload in front of it)
+struct ChanWords { uint32_t w[9]; };
+__global__ void k_chan_init_mix_root_draw(ChanWords init, uint32_t* chan, const uint32_t* root, uint32_t* felt_out, uint32_t* root_log) {
+  __shared__ uint32_t x8[8], felt[4];
+  if (threadIdx.x >= 4 || blockIdx.x != 0) return;
+  for (int i = 0; i < 9; i++) chan[i] = init.w[i];   // every lane of the quad stores all nine words, then reads back its own stores
+  chan_mix_root_draw_quad(threadIdx.x, chan, root, felt_out, root_log, x8, felt);
+}
+
+// Device-side transcript step behind the trace commitment (prover.rs:82-94): mix_root(root 1), the interaction proof of work
+// (smallest nonce whose F(digest, nonce) has `pow_bits` trailing zero bits — SimdBackend::grind's predicate), mix_u64(nonce) and
+// Relations::draw (one draw_felts(2) per relation: z, alpha) with the alpha powers the AIR kernels read.  ONE wave: the 64
+// lanes test 64 nonces at a time, and lane k hashes the draw with counter n_sent = k (a draw is retried with the next
+// counter when a word is >= 2P, so the i-th VALID counter belongs to relation i).  The host replays the same steps on its
+// own channel later, from `out` = {root[8], nonce[2], n_sent, error, z of relation 0 [4]}, and checks they agree.
+__global__ void __launch_bounds__(64) k_step_pow_relations(ChanWords init, const uint32_t* __restrict__ root, uint32_t pow_bits, uint32_t n_rel,
+                                                           uint32_t max_rel, uint32_t* __restrict__ rel_z, uint32_t* __restrict__ rel_pow,
+                                                           uint32_t* __restrict__ out) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t iv0 = 0x6A09E667u ^ 0x01010020u;
+  uint32_t h[8], m[16];
+  // mix_root: digest = Blake2s256(digest || root): one final 64-byte block
+  for (int i = 0; i < 8; i++) { m[i] = init.w[i]; m[8 + i] = root[i]; }
+  h[0] = iv0; h[1] = 0xBB67AE85u; h[2] = 0x3C6EF372u; h[3] = 0xA54FF53Au; h[4] = 0x510E527Fu; h[5] = 0x9B05688Cu; h[6] = 0x1F83D9ABu; h[7] = 0x5BE0CD19u;
+  b2s_compress(h, m, 64, 0xFFFFFFFFu);
+  // proof of work over the raw compression F(digest, [lo, hi, 0...], t = 0, f = 0)
+  uint64_t nonce = 0;
+  for (uint64_t base = 0;; base += 64) {
+    uint32_t g[8];
+    for (int i = 0; i < 8; i++) g[i] = h[i];
+    for (int i = 0; i < 16; i++) m[i] = 0;
+    const uint64_t cand = base + lane;
+    m[0] = (uint32_t)cand; m[1] = (uint32_t)(cand >> 32);
+    b2s_compress(g, m);
+    uint32_t tz;
+    if (g[0]) tz = __ffs(g[0]) - 1;
+    else if (g[1]) tz = 32 + __ffs(g[1]) - 1;
+    else if (g[2]) tz = 64 + __ffs(g[2]) - 1;
+    else if (g[3]) tz = 96 + __ffs(g[3]) - 1;
+    else tz = 128;
+    const unsigned long long hit = __ballot(tz >= pow_bits);
+    if (hit) { nonce = base + (uint64_t)(__ffsll((long long)hit) - 1); break; }
+  }
+  // mix_u64(nonce): digest = F(digest, [lo, hi, 0...])
+  for (int i = 0; i < 16; i++) m[i] = 0;
+  m[0] = (uint32_t)nonce; m[1] = (uint32_t)(nonce >> 32);
+  b2s_compress(h, m);
+  // draw_random_bytes with n_sent = lane: Blake2s256(digest || le32(n_sent) || 0^28 || 0x00) — 65 bytes, two blocks
+  uint32_t d[8];
+  d[0] = iv0; d[1] = 0xBB67AE85u; d[2] = 0x3C6EF372u; d[3] = 0xA54FF53Au; d[4] = 0x510E527Fu; d[5] = 0x9B05688Cu; d[6] = 0x1F83D9ABu; d[7] = 0x5BE0CD19u;
+  for (int i = 0; i < 8; i++) { m[i] = h[i]; m[8 + i] = 0; }
+  m[8] = lane;
+  b2s_compress(d, m, 64, 0);
+  for (int i = 0; i < 16; i++) m[i] = 0;
+  b2s_compress(d, m, 65, 0xFFFFFFFFu);
+  bool valid = true;
+  for (int i = 0; i < 8; i++) valid = valid && d[i] < 2u * P;
+  const unsigned long long vmask = __ballot(valid);
+  const uint32_t rank = (uint32_t)__popcll(vmask & ((1ull << lane) - 1ull));
+  if (valid && rank < n_rel) {
+    const QM31 z(M31::from_u32(d[0]), M31::from_u32(d[1]), M31::from_u32(d[2]), M31::from_u32(d[3]));
+    const QM31 alpha(M31::from_u32(d[4]), M31::from_u32(d[5]), M31::from_u32(d[6]), M31::from_u32(d[7]));
+    z.to_u32(rel_z + 4 * rank);
+    QM31 cur{M31(1)};
+    for (uint32_t i = 0; i < max_rel; i++) { cur.to_u32(rel_pow + 4 * (rank * max_rel + i)); cur = cur * alpha; }
+    if (rank == 0) z.to_u32(out + 12);
+    if (rank == n_rel - 1) out[10] = lane + 1;   // the channel's n_sent after the draws
+  }
+  if (lane == 0) {
+    for (int i = 0; i < 8; i++) out[i] = root[i];
+    out[8] = (uint32_t)nonce; out[9] = (uint32_t)(nonce >> 32);
+    out[11] = (uint32_t)__popcll(vmask) < n_rel ? 1u : 0u;   // fewer than n_rel valid draws among 64 counters: cannot happen in practice
+  }
+}
+
 // Decommitment gather: out[q * width + w] = addrs[q][w]  (width 1 = column values, 8 = 32-byte hashes).
 __global__ void k_gather_words(const uint32_t* const* addrs, uint32_t n, uint32_t width, uint32_t* out) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,6 +173,26 @@ void merkle_multi(const MerkleMultiArgs& a, double alg_bytes, hipStream_t st) {
 }
 void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log, hipStream_t st) {
   hipLaunchKernelGGL(k_chan_mix_root_draw, dim3(1), dim3(64), 0, st, d_chan, d_root, d_felt_out, d_root_log);
+  CM_HIP(hipGetLastError());
+}
+void chan_init_mix_root_draw(const uint32_t init9[9], uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log,
+                             hipStream_t st) {
+  ChanWords cw;
+  memcpy(cw.w, init9, sizeof(cw.w));
+  hipLaunchKernelGGL(k_chan_init_mix_root_draw, dim3(1), dim3(64), 0, st, cw, d_chan, d_root, d_felt_out, d_root_log);
+  CM_HIP(hipGetLastError());
+}
+void step_pow_relations(const uint32_t init9[9], const uint32_t* d_root, uint32_t pow_bits, uint32_t n_rel, uint32_t max_rel, uint32_t* d_rel_z,
+                        uint32_t* d_rel_pow, uint32_t* d_out16, hipStream_t st) {
+  ChanWords cw;
+  memcpy(cw.w, init9, sizeof(cw.w));
+  CM_CHECK(n_rel >= 1 && n_rel <= 32, "step_pow_relations: relation count");
+  hipLaunchKernelGGL(k_step_pow_relations, dim3(1), dim3(64), 0, st, cw, d_root, pow_bits, n_rel, max_rel, d_rel_z, d_rel_pow, d_out16);
+  CM_HIP(hipGetLastError());
+}
+void coeff_powers(const uint32_t* d_rho, uint32_t* d_powers, uint32_t n, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_coeff_powers, dim3((n + 255) / 256), dim3(256), 0, st, d_rho, d_powers, n);
   CM_HIP(hipGetLastError());
 }
 void gather_runs(const RowRun* d_runs, uint32_t n_runs, uint32_t* d_out, hipStream_t st) {

@@ -674,6 +674,17 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
   }
 }
 
+// log2 rows of every component, known from the input lengths (Claim::log_sizes)
+static void component_logs(const cm_prover_input& in, uint32_t* clog) {
+  uint64_t nrows[air::N_COMPONENTS] = {0};
+  for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++) nrows[c] = in.n_bundles[c];
+  nrows[air::C_MEMORY] = in.n_initial_memory + in.n_final_memory;
+  nrows[air::C_MERKLE] = in.n_initial_tree + in.n_final_tree;
+  nrows[air::C_CLOCK_UPDATE] = in.n_clock_updates;
+  nrows[air::C_POSEIDON2] = in.n_initial_tree + in.n_final_tree;
+  for (int c = 0; c <= air::C_POSEIDON2; c++) clog[c] = log_size_for(nrows[c]);
+  clog[air::C_RC8] = 8; clog[air::C_RC16] = 16; clog[air::C_RC20] = 20; clog[air::C_BITWISE] = 18;
+}
 // ---- transcript steps shared by the single-GPU and the sharded prover ------------------------------------------------------
 // PcsConfig::mix_into + PublicData::mix_into (prover.rs:33-36, 62-66)
 static void mix_config_and_public_data(Channel& ch, const cm_pcs_config& cfg, const PublicData& d) {
@@ -781,6 +792,8 @@ struct SegmentProver {
   std::vector<size_t> coff;                  // first constraint of every component
   std::vector<QM31> powers;                  // random-coefficient powers, one per constraint
   DevBuf d_powers;
+  DevBuf d_step1;                            // device-side transcript step after tree 1: {root[8], nonce[2], n_sent, error, z0[4]}
+  DevBuf d_step2;                            // device-side transcript step after tree 2: {channel[16], coefficient[4], root[8]}
   CPoint<QM31> oods;
   DevBuf d_oods_table, d_oods_out, d_qblob;  // sampling pointer table, sampled values, DEEP-quotient plan
   size_t o_qjobs = 0, n_qjobs = 0;
@@ -834,14 +847,7 @@ struct SegmentProver {
   // component sizes, twiddles (side stream), transcript setup (prover.rs:33-66)
   void setup() {
     // ---- component log sizes (known from the input lengths) ----
-    uint64_t nrows[air::N_COMPONENTS];
-    for (int c = 0; c < air::N_OPCODE_COMPONENTS; c++) nrows[c] = in.n_bundles[c];
-    nrows[air::C_MEMORY] = in.n_initial_memory + in.n_final_memory;
-    nrows[air::C_MERKLE] = in.n_initial_tree + in.n_final_tree;
-    nrows[air::C_CLOCK_UPDATE] = in.n_clock_updates;
-    nrows[air::C_POSEIDON2] = in.n_initial_tree + in.n_final_tree;
-    for (int c = 0; c <= air::C_POSEIDON2; c++) clog[c] = log_size_for(nrows[c]);
-    clog[air::C_RC8] = 8; clog[air::C_RC16] = 16; clog[air::C_RC20] = 20; clog[air::C_BITWISE] = 18;
+    component_logs(in, clog);
     max_log = 0;
     for (int c = 0; c < air::N_COMPONENTS; c++) max_log = std::max(max_log, clog[c]);
     for (int c = 0; c < air::N_COMPONENTS; c++) CM_CHECK(clog[c] <= 26, "component too large");
@@ -963,29 +969,41 @@ struct SegmentProver {
     }
     P.tick("trace_gen");
     P.commit_enqueue(P.trees[1], &tr_evals, false, st);
-    if (pp_fork) pp_fork->join();   // tree 0 (a chain of ~30 small launches) has been running next to all of the above
-    // ONE round trip: root of tree 0 (when it was built in this proof), root of tree 1, the range-check flag
-    if (pp_fork) CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT0, P.trees[0].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, st));
-    P.trees[1].merkle.root(P.trees[1].root.data(), st);
-    if (pp_fork) memcpy(P.trees[0].root.data(), pinned_words() + PIN_ROOT0, 32);
-    if (pp_fork) ch.mix_root(P.trees[0].root);   // transcript order (prover.rs:70-82): root 0, claim, root 1
+    // Root 0 first (transcript order, prover.rs:70-82: root 0, claim, root 1): tree 0 has been running on its side stream next
+    // to all of the above; its root is copied on THAT stream and waited for here, while the GPU is still busy with tree 1.
+    if (pp_fork) {
+      static thread_local hipEvent_t ev_root0 = nullptr;
+      if (!ev_root0) CM_HIP(hipEventCreateWithFlags(&ev_root0, hipEventDisableTiming));
+      hipStream_t ps = pp_fork->stream(Fork::N - 1);
+      CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT0, P.trees[0].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, ps));
+      CM_HIP(hipEventRecord(ev_root0, ps));
+      pp_fork->join();
+      CM_HIP(hipEventSynchronize(ev_root0));
+      memcpy(P.trees[0].root.data(), pinned_words() + PIN_ROOT0, 32);
+      ch.mix_root(P.trees[0].root);
+    }
     for (int c = 0; c < air::N_COMPONENTS; c++) { pf.claim_log_sizes.push_back(clog[c]); ch.mix_u64(clog[c]); }
-    ch.mix_root(P.trees[1].root);
-    CM_CHECK(flag_host[0] == 0, "trace generation: a range-check / bitwise lookup value is out of range");
+    // Everything from root 1 to the relation challenges happens on the device, right behind the tree (k_step_pow_relations:
+    // mix_root, interaction proof of work, mix_u64(nonce), Relations::draw + alpha powers): the LogUp kernels start without a
+    // host round trip.  The host replays the steps from the copied-back root / nonce when it waits for the claimed sums.
+    {
+      static_assert(sizeof(DevRelations) == 4 * 4 * (air::N_RELATIONS + air::N_RELATIONS * air::MAX_REL_SIZE), "DevRelations layout");
+      uint32_t cw[9];
+      memcpy(cw, ch.digest.data(), 32);
+      cw[8] = ch.n_sent;
+      drel.alloc(sizeof(DevRelations));
+      d_step1.alloc(16 * 4);
+      uint32_t* rel = drel.u32();
+      step_pow_relations(cw, P.trees[1].merkle.layers[0].u32(), INTERACTION_POW_BITS, air::N_RELATIONS, air::MAX_REL_SIZE, rel,
+                         rel + 4 * air::N_RELATIONS, d_step1.u32(), st);
+      CM_HIP(hipMemcpyAsync(pinned_words() + PIN_STEP1, d_step1.p, 16 * 4, hipMemcpyDeviceToHost, st));
+    }
     P.tick("trace_commit");
 
   }
 
   // interaction PoW, relation draws, tree 2: LogUp columns + commitment enqueue, claimed sums (prover.rs:90-102)
   void interaction() {
-    // ---- interaction PoW + relations (prover.rs:90-94) ----
-    pf.interaction_pow = grind_gpu(ch.digest.data(), 2, st);
-    ch.mix_u64(pf.interaction_pow);
-    DevRelations drel_h;
-    draw_relations(ch, hrel, drel_h);
-    drel.alloc(sizeof(DevRelations));
-    stage_upload(drel.p, &drel_h, sizeof(DevRelations), st);
-
     // ---- tree 2: interaction trace (prover.rs:96-102) ----
     hipEvent_t sums_ready = nullptr;
     ColumnSet it_evals;
@@ -1056,6 +1074,23 @@ struct SegmentProver {
     }
     {
       CM_HIP(hipEventSynchronize(sums_ready));
+      // host replay of the device-side step behind tree 1 (its results were copied back in front of the sums)
+      {
+        const uint32_t* s1 = pinned_words() + PIN_STEP1;
+        CM_CHECK(pinned_words()[PIN_FLAG] == 0, "trace generation: a range-check / bitwise lookup value is out of range");
+        memcpy(P.trees[1].root.data(), s1, 32);
+        ch.mix_root(P.trees[1].root);
+        pf.interaction_pow = (uint64_t)s1[8] | ((uint64_t)s1[9] << 32);
+        {
+          Channel probe = ch;   // the nonce must satisfy the proof-of-work predicate on the HOST channel
+          probe.mix_u64(pf.interaction_pow);
+          CM_CHECK(s1[11] == 0 && probe.trailing_zeros() >= INTERACTION_POW_BITS, "interaction proof of work: device step diverged from the host channel");
+        }
+        ch.mix_u64(pf.interaction_pow);
+        DevRelations drel_h;
+        draw_relations(ch, hrel, drel_h);
+        CM_CHECK(ch.n_sent == s1[10] && memcmp(drel_h.z[0], s1 + 12, 16) == 0, "relations: device transcript diverged from the host channel");
+      }
       const uint32_t* sums = pinned_words() + PIN_SUMS;
       for (int c = 0; c < air::N_COMPONENTS; c++) pf.claimed_sums.push_back(QM31::from_u32(sums + 4 * c));
       for (auto& cs : pf.claimed_sums) ch.mix_felts(&cs, 1);
@@ -1180,10 +1215,23 @@ struct SegmentProver {
         }
       }
       DevBuf d_small_args = upload(small_args, st), d_small_cids = upload(small_cids, st);
-      P.commit_finish(P.trees[2]);
+      // Transcript step on the device (prover.rs:131, stwo prove: mix the interaction root, draw the random coefficient): the
+      // channel state goes over in the kernel arguments, k_chan_init_mix_root_draw mixes root 2 and draws the coefficient,
+      // k_coeff_powers expands its powers — the constraint kernels start right behind the tree, with no host round trip.  The
+      // host replays both steps on its own channel when root 3 comes back (oods_sampling) and checks the coefficients agree.
+      {
+        uint32_t cw[9];
+        memcpy(cw, ch.digest.data(), 32);
+        cw[8] = ch.n_sent;
+        d_step2.alloc(4 * (16 + 4 + 8));
+        uint32_t* d_chan = d_step2.u32();
+        chan_init_mix_root_draw(cw, d_chan, P.trees[2].merkle.layers[0].u32(), d_chan + 16, d_chan + 20, st);
+        coeff_powers(d_chan + 16, d_powers.u32(), (uint32_t)total_constraints, st);
+        CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT2, d_chan + 20, 32, hipMemcpyDeviceToHost, st));
+        CM_HIP(hipMemcpyAsync(pinned_words() + PIN_COEFF, d_chan + 16, 16, hipMemcpyDeviceToHost, st));
+      }
       P.tick("interaction_commit");
       for (int t = 0; t < 3; t++) for (auto l : P.trees[t].coeffs.logs) pf.cells += 1ull << l;
-      draw_constraint_powers(ch, powers, d_powers, st);
       KProfRegion kreg("k_constraints(region)", st);
       Fork fk(st);
       launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
@@ -1193,6 +1241,7 @@ struct SegmentProver {
       for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it, ++gi) {
         for (int c : it->second) {
           if (std::find(small_cids.begin(), small_cids.end(), c) != small_cids.end()) continue;
+          // the components of a size group share its accumulator: one stream for all of them; slotted ones are independent
           hipStream_t sc = slot_of[c] >= 0 ? fk.stream(4 + (small_rr++ % 3)) : fk.stream(gi % 4);
           launch_constraints(c, cargs[c], sc);
         }
@@ -1271,7 +1320,18 @@ struct SegmentProver {
         (j.refs[i].prev ? sidx_prev : sidx_cur)[j.refs[i].t][j.refs[i].c] = (uint32_t)(j.out_off + i);
     pf.sampled_values.resize(4);
     for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
-    P.commit_finish(P.trees[3]);
+    // ONE round trip for two roots: root 3 is waited for; root 2 and the random coefficient of the device-side step are
+    // already in pinned memory.  Host replay in transcript order.
+    P.trees[3].merkle.root(P.trees[3].root.data(), st);
+    {
+      memcpy(P.trees[2].root.data(), pinned_words() + PIN_ROOT2, 32);
+      ch.mix_root(P.trees[2].root);
+      const QM31 rho = ch.draw_felt();
+      CM_CHECK(rho == QM31::from_u32(pinned_words() + PIN_COEFF), "composition: device transcript diverged from the host channel");
+      QM31 cur(M31(1));
+      for (size_t g = powers.size(); g-- > 0;) { powers[g] = cur; cur = cur * rho; }   // host copy: the OODS check needs it
+    }
+    ch.mix_root(P.trees[3].root);
     P.tick("composition_commit");
 
     // host side of compute_fri_quotients for every size group, packed into ONE upload:

@@ -308,7 +308,7 @@ std::string verify_proof(const ProofData& pf, const cm_pcs_config& expected) {
   for (auto l : pf.claim_log_sizes) ch.mix_u64(l);
   ch.mix_root(pf.commitments[1]);
   ch.mix_u64(pf.interaction_pow);
-  if (ch.trailing_zeros() < 2) return "ProofOfWork(interaction)";  // relations::INTERACTION_POW_BITS (verifier.rs:55-58)
+  if (ch.trailing_zeros() < INTERACTION_POW_BITS) return "ProofOfWork(interaction)";  // relations::INTERACTION_POW_BITS (verifier.rs:55-58)
   HostRelations rel;
   for (int r = 0; r < air::N_RELATIONS; r++) {
     QM31 z, alpha;

@@ -13,14 +13,15 @@ for r in csv.DictReader(open(m)):
     ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r['Direction'][12:], '-', ''))
 ev.sort()
 gi = [i for i, e in enumerate(ev) if 'k_grind' in e[2]]
-# a proof has two grinds (interaction PoW, final PoW).  bench.py's LAST proof is the verification proof made on the main host
-# thread (cold device pool: hipMallocs), so the proof analysed is the one before it: the last TIMED proof.
+# a proof has ONE k_grind launch (the final PoW; the interaction PoW is part of k_step_pow_relations).  bench.py's LAST proof is
+# the verification proof made on the main host thread (cold device pool: hipMallocs), so the proof analysed is the one before
+# it: the last TIMED proof.
 def proof_start(after_grind):
     i = after_grind + 1
     while i < len(ev) and ('gather' in ev[i][2] or 'COPY' in ev[i][2] or 'copyBuffer' in ev[i][2]) and 'k_preproc' not in ev[i][2]:
         i += 1
     return i
-i0, i1 = proof_start(gi[-5]), proof_start(gi[-3])
+i0, i1 = proof_start(gi[-3]), proof_start(gi[-2])
 sub = ev[i0:i1]
 t0 = sub[0][0]
 cur, busy, gaps, prev = t0, 0, [], None
