@@ -30,6 +30,8 @@ struct QuotientArgs {
   uint32_t log_size;
   const uint32_t* const* cols;     // LDE columns of the size group (device array)
   const uint32_t* col_index;       // per entry: column index in `cols`
+  const uint32_t* const* entry_cols = nullptr;   // optional, per entry: cols[col_index[e]] resolved by the host (one scalar load
+                                                 // per column instead of two dependent ones)
   const uint32_t* coef_c;          // per entry: alpha^i * c_i (4 u32)
   const QuotientBatch* batches;    // device array
   uint32_t n_batches;

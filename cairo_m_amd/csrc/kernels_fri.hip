@@ -50,6 +50,23 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
           return (x & P) + (x >> 31);
         };
         uint32_t k = qb.begin;
+        if (a.entry_cols) {   // resolved column pointers: 16 loads in flight
+          for (; k + 16 <= qb.end; k += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = CM_GCOL(a.entry_cols[k + j])[row];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                const uint32_t* c = a.coef_c + 4 * (k + 4 * g + j);
+                const unsigned long long x = v[4 * g + j];
+                q0 += x * c[0]; q1 += x * c[1]; q2 += x * c[2]; q3 += x * c[3];
+              }
+              q0 = fold(q0); q1 = fold(q1); q2 = fold(q2); q3 = fold(q3);
+            }
+          }
+        }
         for (; k + 8 <= qb.end; k += 8) {
           uint32_t v[8];
 #pragma unroll

@@ -806,7 +806,7 @@ struct SegmentProver {
   struct QEntry { uint32_t col; uint32_t sidx; };   // column of the group, index of its sampled value in d_oods_out
   struct QBatch { CPoint<QM31> pt; std::vector<QEntry> entries; };
   struct QGroup { uint32_t log = 0; std::vector<const uint32_t*> cols; std::vector<QBatch> batches; ColumnSet out;
-                  size_t o_cols = 0, o_out = 0, o_ci = 0, o_cc = 0, o_qb = 0, o_sidx = 0; };
+                  size_t o_cols = 0, o_out = 0, o_ci = 0, o_cc = 0, o_qb = 0, o_sidx = 0, o_ep = 0; };
   std::vector<QGroup> qg;                    // DEEP-quotient size groups
   SegmentProver(const DeviceInput& din_, const cm_pcs_config& cfg_)
       : din(din_), in(din_.meta), cfg(cfg_), out(new ProofData()), pf(*out), st(nullptr), ch(P.ch) {
@@ -1402,16 +1402,18 @@ struct SegmentProver {
         g.o_out = qput(g.out.ptrs.data(), 4 * sizeof(void*));
         {
           std::vector<uint32_t> ci, si;
+          std::vector<const uint32_t*> ep;   // per entry: the column pointer itself
           std::vector<QuotientBatch> qb(g.batches.size());
           for (size_t bi = 0; bi < g.batches.size(); bi++) {
             memset(&qb[bi], 0, sizeof(QuotientBatch));
             qb[bi].begin = (uint32_t)ci.size();
-            for (auto& en : g.batches[bi].entries) { ci.push_back(en.col); si.push_back(en.sidx); }
+            for (auto& en : g.batches[bi].entries) { ci.push_back(en.col); si.push_back(en.sidx); ep.push_back(g.cols[en.col]); }
             qb[bi].end = (uint32_t)ci.size();
             g.batches[bi].pt.x.to_u32(qb[bi].point);   // words = (Pr.x, Pi.x): QM31 = (a.a, a.b, b.a, b.b)
             g.batches[bi].pt.y.to_u32(qb[bi].point + 4);
           }
           g.o_ci = qput(ci.data(), ci.size() * 4);
+          g.o_ep = qput(ep.data(), ep.size() * sizeof(void*));
           g.o_sidx = qput(si.data(), si.size() * 4);
           g.o_cc = qput(nullptr, n_entries * 16);            // filled by k_quotient_coeffs
           g.o_qb = qput(qb.data(), qb.size() * sizeof(QuotientBatch));   // sums / batch coefficient filled on the device
@@ -1469,6 +1471,7 @@ struct SegmentProver {
         a.cols = (const uint32_t* const*)(base + g.o_cols);
         a.out = (uint32_t* const*)(base + g.o_out);
         a.col_index = (const uint32_t*)(base + g.o_ci);
+        a.entry_cols = (const uint32_t* const*)(base + g.o_ep);
         a.coef_c = (const uint32_t*)(base + g.o_cc);
         a.batches = (const QuotientBatch*)(base + g.o_qb);
         a.n_batches = (uint32_t)g.batches.size();
