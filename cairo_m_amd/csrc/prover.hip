@@ -277,6 +277,15 @@ struct Prover {
     }
     if (with_merkle) t.merkle.commit_prepared(s);
   }
+  // Host pacing.  With the transcript steps behind a tree on the device the host COULD enqueue the whole next phase while the
+  // tree is still being built — but the next phase forks over side streams, and fork waits that sit blocked at the head of
+  // the other hardware queues for milliseconds slow the dispatch of the running stream's ~100 small launches: +0.2 ms per
+  // tree (CM_PACE=0 shows it; even 0.8 ms of blocked waits cost 50-80 us).  So the host lets the stream drain behind the
+  // device-side step and only then enqueues the next phase: one launch latency instead of two or three host round trips.
+  void pace() {
+    static const bool run_ahead = getenv("CM_PACE") && atoi(getenv("CM_PACE")) == 0;
+    if (!run_ahead) CM_HIP(hipStreamSynchronize(st));
+  }
 };
 
 // Optional cache of tree 0.  The preprocessed columns are constants (preprocessed/mod.rs:75-82), so their
@@ -759,7 +768,7 @@ static CPoint<QM31> draw_oods_point(Channel& ch) {
 // =========================================================================================================
 // CM_HOST_TRACE=1: host-side time between marks on stderr (where the GPU sits idle waiting for the host)
 struct HostTrace {
-  bool on = getenv("CM_HOST_TRACE") != nullptr;
+  bool on = getenv("CM_HOST_TRACE") != nullptr || getenv("CM_HOST_MARKS") != nullptr;   // MARKS: no synchronising ticks
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
   void mark(const char* what) {
     if (!on) return;
@@ -997,6 +1006,7 @@ struct SegmentProver {
       step_pow_relations(cw, P.trees[1].merkle.layers[0].u32(), INTERACTION_POW_BITS, air::N_RELATIONS, air::MAX_REL_SIZE, rel,
                          rel + 4 * air::N_RELATIONS, d_step1.u32(), st);
       CM_HIP(hipMemcpyAsync(pinned_words() + PIN_STEP1, d_step1.p, 16 * 4, hipMemcpyDeviceToHost, st));
+      P.pace();
     }
     P.tick("trace_commit");
 
@@ -1232,6 +1242,7 @@ struct SegmentProver {
       }
       P.tick("interaction_commit");
       for (int t = 0; t < 3; t++) for (auto l : P.trees[t].coeffs.logs) pf.cells += 1ull << l;
+      P.pace();
       KProfRegion kreg("k_constraints(region)", st);
       Fork fk(st);
       launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
