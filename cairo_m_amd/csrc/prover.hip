@@ -184,6 +184,7 @@ struct CommittedTree {
   DevBuf tables;  // one upload: pointer tables of coeffs / lde / the FFT groups / the Merkle column order
 };
 
+static std::atomic<int> g_proofs_in_flight{0};   // proofs being made by cm_prove_many runners right now (0 outside of it)
 struct Prover {
   hipStream_t st = 0;
   cm_pcs_config cfg;
@@ -282,9 +283,12 @@ struct Prover {
   // the other hardware queues for milliseconds slow the dispatch of the running stream's ~100 small launches: +0.2 ms per
   // tree (CM_PACE=0 shows it; even 0.8 ms of blocked waits cost 50-80 us).  So the host lets the stream drain behind the
   // device-side step and only then enqueues the next phase: one launch latency instead of two or three host round trips.
+  // With several proofs in flight (cm_prove_many) other proofs' kernels fill the dispatch slack and running ahead is the
+  // better choice (10.3 vs 10.5 ms per proof with 4 in flight), so pacing applies to a lone proof only.
   void pace() {
-    static const bool run_ahead = getenv("CM_PACE") && atoi(getenv("CM_PACE")) == 0;
-    if (!run_ahead) CM_HIP(hipStreamSynchronize(st));
+    static const int mode = getenv("CM_PACE") ? atoi(getenv("CM_PACE")) : -1;   // 0 = always run ahead, 1 = always drain (A/B)
+    const bool drain = mode == 1 || (mode != 0 && g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);
+    if (drain) CM_HIP(hipStreamSynchronize(st));
   }
 };
 
@@ -1677,6 +1681,7 @@ int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm
   // `runners` jobs, each pulling segment indices until none is left: exactly that many proofs are in flight
   for (uint32_t r = 0; r < runners; r++) {
     w.submit([&] {
+      struct InFlight { InFlight() { cm::g_proofs_in_flight.fetch_add(1); } ~InFlight() { cm::g_proofs_in_flight.fetch_sub(1); } } in_flight;
       for (;;) {
         uint32_t i;
         { std::lock_guard<std::mutex> lk(sh.mu); i = sh.next++; }
