@@ -227,15 +227,19 @@ CM_HD uint32_t bit_reverse(uint32_t i, uint32_t log) {
 
 // Lazy accumulator for  sum_k c_k * x_k  with c_k in QM31 (4 canonical words) and x_k in M31: the 64-bit
 // products of one coordinate are added unreduced — four of them plus a folded remainder fit a u64
-// (4 * (2^31-1)^2 + 2^32 < 2^64) — and folded back below 2^32 after every fourth term.  On gfx950 this is
+// (4 * (2^31-1)^2 + 3 * 2^32 < 2^64) — and folded back below 3 * 2^32 after every fourth term (m31_fold_lazy).  On gfx950 this is
 // one v_mad_u64_u32 per coordinate-term instead of a multiply + Mersenne fold + modular add.
+// Partial fold of an unreduced 64-bit accumulator: 2^32 = 2 (mod P), so x = lo + 2^32 hi = lo + 2 hi (mod P) < 3 * 2^32.
+// Four more products of canonical values fit on top of that (4 (2^31-1)^2 + 3 * 2^32 = 2^64 - 2^32 + 4 < 2^64), so this
+// single shift-and-add (one v_lshl_add_u64 on gfx950) is all that is needed between groups of four terms — the two-step
+// Mersenne fold ((x & P) + (x >> 31), twice) it replaces was half of the VALU work of the multiply-accumulate loops.
+CM_HD unsigned long long m31_fold_lazy(unsigned long long x) {
+  return (unsigned long long)(uint32_t)x + ((x >> 32) << 1);
+}
 struct QAcc {
   unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
   int pending = 0;
-  static CM_HD unsigned long long fold(unsigned long long x) {
-    x = (x & P) + (x >> 31);
-    return (x & P) + (x >> 31);
-  }
+  static CM_HD unsigned long long fold(unsigned long long x) { return m31_fold_lazy(x); }
   CM_HD void add(const uint32_t* c4, M31 x) {
     const unsigned long long v = x.v;
     q0 += v * c4[0]; q1 += v * c4[1]; q2 += v * c4[2]; q3 += v * c4[3];

@@ -44,11 +44,8 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
       // and 8 column loads are issued before any arithmetic so the lane keeps 8 HBM requests in flight
       // (one load + one QM31 multiply-add at a time ran at ~1 TB/s: latency-bound, not bandwidth-bound).
       if (live) {
-        unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;  // < 2^32 between groups
-        auto fold = [](unsigned long long x) -> unsigned long long {
-          x = (x & P) + (x >> 31);
-          return (x & P) + (x >> 31);
-        };
+        unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;  // < 3 * 2^32 between groups
+        auto fold = [](unsigned long long x) -> unsigned long long { return m31_fold_lazy(x); };
         uint32_t k = qb.begin;
         if (a.entry_cols) {   // resolved column pointers: 16 loads in flight
           for (; k + 16 <= qb.end; k += 16) {

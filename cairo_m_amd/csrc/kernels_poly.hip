@@ -256,10 +256,7 @@ __global__ void __launch_bounds__(256) k_point_tables_multi(const EapJobDev* __r
     if ((i >> k) & 1u) r = r * QM31::from_u32(jb.maps + 4 * (first_bit + k));
   r.to_u32(scratch + (hi_tab ? jb.high_off : jb.low_off) + 4 * i);
 }
-__device__ __forceinline__ unsigned long long fold31x2(unsigned long long x) {
-  x = (x & P) + (x >> 31);
-  return (x & P) + (x >> 31);
-}
+__device__ __forceinline__ unsigned long long fold31x2(unsigned long long x) { return m31_fold_lazy(x); }
 // first block / first column of every job, passed BY VALUE (kernel arguments sit in scalar registers): finding a
 // block's job by walking the 560-byte descriptors in memory cost ~20 dependent scalar loads per block
 struct EapStarts { uint32_t v[64]; };
@@ -316,7 +313,7 @@ __global__ void __launch_bounds__(256) k_eval_partial_multi(const EapJobDev* __r
         }
       }
     }
-    // 4 raw products per coordinate fit a u64 on top of a folded remainder (4 * (2^31-1)^2 + 2^32 < 2^64)
+    // 4 raw products per coordinate fit a u64 on top of a folded remainder (4 * (2^31-1)^2 + 3 * 2^32 < 2^64)
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) { q[k][0] = fold31x2(q[k][0]); q[k][1] = fold31x2(q[k][1]); q[k][2] = fold31x2(q[k][2]); q[k][3] = fold31x2(q[k][3]); }
   }
