@@ -126,24 +126,29 @@ __device__ __forceinline__ M31 m31_fold64(unsigned long long s) {
   return M31(m31_csub(t));
 }
 #endif
-// (a + b u)(c + d u), u^2 = 2 + i.  Device form: the 16 coordinate products are accumulated unreduced in 64 bits
-// (one v_mad_u64_u32 each) in six groups of <= 4 products and folded once per group — 16 mads + 6 folds + 6 modular
-// adds instead of 16 full multiplications + 16 modular adds:
+// (a + b u)(c + d u), u^2 = 2 + i.  Device form: every output coordinate is ONE unreduced 64-bit sum of raw products
+// (v_mad_u64_u32 each) with the signs folded into the operands (P - x for -x, 2y for a doubled term) and a single-instruction
+// partial fold (m31_fold_lazy) wherever more than four product-units would overflow; one Mersenne fold per coordinate at the end
+// and NO modular additions:
 //   r0 = x0y0 - x1y1 + 2(x2y2 - x3y3) - (x2y3 + x3y2)      r2 = x0y2 - x1y3 + x2y0 - x3y1
 //   r1 = x0y1 + x1y0 + (x2y2 - x3y3) + 2(x2y3 + x3y2)      r3 = x0y3 + x1y2 + x2y1 + x3y0
+// 20 mads + 2 partial + 4 full folds (~230 issue cycles) against 16 mads + 6 full folds + 7 modular adds (~300) of the
+// grouped form it replaces; field arithmetic is exact, the canonical result is the same.
+CM_HD unsigned long long m31_fold_lazy(unsigned long long x);
 CM_HD QM31 operator*(QM31 x, QM31 y) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CM_QM31_MUL_PLAIN)
   typedef unsigned long long u64;
   const u64 x0 = x.a.a.v, x1 = x.a.b.v, x2 = x.b.a.v, x3 = x.b.b.v;
-  const u64 y0 = y.a.a.v, y1 = y.a.b.v, y2 = y.b.a.v, y3 = y.b.b.v;
-  const u64 n1 = P - x.a.b.v, n3 = P - x.b.b.v;   // -x1, -x3 as values in [1, P]
-  const M31 e = m31_fold64(x0 * y0 + n1 * y1);
-  const M31 b = m31_fold64(x2 * y2 + n3 * y3);
-  const M31 c = m31_fold64(x0 * y1 + x1 * y0);
-  const M31 d = m31_fold64(x2 * y3 + x3 * y2);
-  const M31 r2 = m31_fold64(x0 * y2 + n1 * y3 + x2 * y0 + n3 * y1);
-  const M31 r3 = m31_fold64(x0 * y3 + x1 * y2 + x2 * y1 + x3 * y0);
-  return QM31(e + b + b - d, c + b + d + d, r2, r3);
+  const u64 n1 = P - x.a.b.v, n2 = P - x.b.a.v, n3 = P - x.b.b.v;   // -x1, -x2, -x3 as values in [1, P]
+  const uint32_t y0 = y.a.a.v, y1 = y.a.b.v, y2 = y.b.a.v, y3 = y.b.b.v;
+  const uint32_t y2d = y2 << 1, y3d = y3 << 1;                        // < 2^32: a product with them counts as two units
+  u64 s0 = x0 * y0 + n1 * y1 + x2 * y2d;                               // 4 units
+  s0 = m31_fold_lazy(s0) + n3 * y3d + n2 * y3 + n3 * y2;               // + 4 units
+  u64 s1 = x0 * y1 + x1 * y0 + x2 * y2 + n3 * y3;                      // 4 units
+  s1 = m31_fold_lazy(s1) + x2 * y3d + x3 * y2d;                        // + 4 units
+  const u64 s2 = x0 * y2 + n1 * y3 + x2 * y0 + n3 * y1;
+  const u64 s3 = x0 * y3 + x1 * y2 + x2 * y1 + x3 * y0;
+  return QM31(m31_fold64(s0), m31_fold64(s1), m31_fold64(s2), m31_fold64(s3));
 #else
   return QM31(x.a * y.a + mul_R(x.b * y.b), x.a * y.b + x.b * y.a);
 #endif
