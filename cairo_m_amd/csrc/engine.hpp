@@ -30,6 +30,17 @@ void interpolate_oop(const uint32_t* const* d_src, uint32_t* const* d_dst, uint3
 void evaluate(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n_in, uint32_t n_out,
               const Twiddles& tw, hipStream_t st);
 void bit_reverse_columns(uint32_t* const* d_cols, uint32_t ncols, uint32_t n, hipStream_t st);
+// interpolate + extend of small columns of ANY mix of sizes in one launch (one block per column): src (2^log_n evaluations;
+// null = the coefficients are already in `coeffs`; may alias `coeffs`) -> coeffs (2^log_n) -> lde (2^(log_n + blowup));
+// inv_n = 2^-log_n as a canonical M31 word
+constexpr uint32_t SMALL_COMMIT_MAX_LOG = 10;
+struct SmallCommitJob { const uint32_t* src; uint32_t* coeffs; uint32_t* lde; uint32_t log_n, inv_n; };
+struct TwiddleTables { uint32_t R; const uint32_t *xtw, *ixtw, *ytw, *iytw; };
+void small_commit(const SmallCommitJob* d_jobs, uint32_t n_jobs, uint32_t max_log, uint32_t blowup, const Twiddles& tw, hipStream_t st);
+inline bool small_commit_serves(uint32_t log, uint32_t blowup) {   // A/B switch: CM_NO_SMALL_COMMIT=1
+  static const bool on = getenv("CM_NO_SMALL_COMMIT") == nullptr;
+  return on && log >= 1 && log <= SMALL_COMMIT_MAX_LOG && SMALL_COMMIT_MAX_LOG + blowup <= 14;
+}
 
 // eval_at_point for a batch of equal-size coefficient columns at ONE point.
 // d_scratch: >= 4*(2^10 + 2^max(0,n-10)) + 4*ncols*2^max(0,n-10) + 32*4 u32.  d_out: 4*ncols u32 (device).

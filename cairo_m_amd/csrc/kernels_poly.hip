@@ -164,6 +164,56 @@ __global__ void __launch_bounds__(256) k_fft_pass(FftPassArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- small columns: interpolate + extend in ONE launch
+// A commitment carries dozens of small columns in several sizes (idle components: 2^4 rows; the tiny builtins; rc8 ...).
+// As size groups they were two latency-bound launches each — ~25 launches of ~6 us per proof, in a row on the tree's
+// stream.  Here one block owns one column whatever its size (<= SMALL_COMMIT_MAX_LOG): evaluations -> LDS -> n inverse
+// layers -> coefficients (scaled by 2^-n) -> zero-extended -> n + blowup forward layers -> LDE, all sizes in one grid.
+__global__ void __launch_bounds__(256) k_small_commit(const SmallCommitJob* __restrict__ jobs, TwiddleTables tw, uint32_t blowup) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
+  const SmallCommitJob jb = jobs[blockIdx.x];
+  const uint32_t n = jb.log_n, N = 1u << n, no = n + blowup, NO = 1u << no;
+  const bool from_coeffs = jb.src == nullptr;   // src may alias coeffs (interpolation in place): it is read into LDS first
+  for (uint32_t e = threadIdx.x; e < N; e += blockDim.x) tile[e] = (from_coeffs ? jb.coeffs : jb.src)[e];
+  __syncthreads();
+  if (!from_coeffs) {
+    for (uint32_t layer = 0; layer < n; layer++) {
+      for (uint32_t b = threadIdx.x; b < (N >> 1); b += blockDim.x) {
+        const uint32_t e0 = ((b >> layer) << (layer + 1)) | (b & ((1u << layer) - 1)), e1 = e0 | (1u << layer);
+        const uint32_t h = e0 >> (layer + 1);
+        const uint32_t t = layer == 0 ? tw.iytw[(1u << (n - 1)) + h]
+                                      : tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - (tw.R - n + layer - 1))) + h];
+        const M31 x(tile[e0]), y(tile[e1]);
+        tile[e0] = (x + y).v;
+        tile[e1] = ((x - y) * M31(t)).v;
+      }
+      __syncthreads();
+    }
+    const M31 sc(jb.inv_n);
+    for (uint32_t e = threadIdx.x; e < N; e += blockDim.x) {
+      const uint32_t v = (M31(tile[e]) * sc).v;
+      tile[e] = v;
+      jb.coeffs[e] = v;
+    }
+  }
+  for (uint32_t e = N + threadIdx.x; e < NO; e += blockDim.x) tile[e] = 0u;
+  __syncthreads();
+  for (uint32_t k = 0; k < no; k++) {
+    const uint32_t layer = no - 1 - k;
+    for (uint32_t b = threadIdx.x; b < (NO >> 1); b += blockDim.x) {
+      const uint32_t e0 = ((b >> layer) << (layer + 1)) | (b & ((1u << layer) - 1)), e1 = e0 | (1u << layer);
+      const uint32_t h = e0 >> (layer + 1);
+      const uint32_t t = layer == 0 ? tw.ytw[(1u << (no - 1)) + h]
+                                    : tw.xtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - (tw.R - no + layer - 1))) + h];
+      const M31 x(tile[e0]), yt = M31(tile[e1]) * M31(t);
+      tile[e0] = (x + yt).v;
+      tile[e1] = (x - yt).v;
+    }
+    __syncthreads();
+  }
+  for (uint32_t e = threadIdx.x; e < NO; e += blockDim.x) jb.lde[e] = tile[e];
+}
+
 // ---------------------------------------------------------------- bit reversal (in place)
 __global__ void k_bit_reverse(uint32_t* const* cols, uint32_t log_n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -461,6 +511,19 @@ void evaluate(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t nco
     launch_pass<false>(first ? d_src : (const uint32_t* const*)d_dst, d_dst, ncols, n_out, passes[k].first,
                        passes[k].second, first ? (1u << n_in) : (1u << n_out), 1u, tw, st);
   }
+  CM_HIP(hipGetLastError());
+}
+void small_commit(const SmallCommitJob* d_jobs, uint32_t n_jobs, uint32_t max_log, uint32_t blowup, const Twiddles& tw, hipStream_t st) {
+  if (!n_jobs) return;
+  CM_CHECK(max_log >= 1 && max_log <= SMALL_COMMIT_MAX_LOG && max_log + blowup <= tw.R && max_log + blowup <= 14, "small_commit: bad sizes");
+  TwiddleTables t{tw.R, tw.xtw, tw.ixtw, tw.ytw, tw.iytw};
+  const size_t lds = (size_t)4 << (max_log + blowup);
+  if (lds > 48 * 1024) {
+    static const hipError_t once = hipFuncSetAttribute((const void*)k_small_commit, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)once;
+  }
+  KProfScope kp("k_small_commit", 0.0, st);
+  hipLaunchKernelGGL(k_small_commit, dim3(n_jobs), dim3(256), lds, st, d_jobs, t, blowup);
   CM_HIP(hipGetLastError());
 }
 void bit_reverse_columns(uint32_t* const* d_cols, uint32_t ncols, uint32_t n, hipStream_t st) {

@@ -242,7 +242,10 @@ struct Prover {
   }
   // everything of a commitment except the root read-back, on stream `s` (tree 0 is built on a side stream while the
   // execution trace is generated: both are chains of small launches)
-  void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true) {
+  // small_evals_in_place: with from_coeffs, the SMALL columns of t.coeffs (small_commit_serves) still hold evaluations —
+  // the caller interpolated only the large ones — and the fused small-column kernel interpolates them in place
+  void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true,
+                      bool small_evals_in_place = false) {
     const std::vector<uint32_t> logs = from_coeffs ? t.coeffs.logs : evals->logs;
     UploadBatch ub;
     if (!from_coeffs) { t.coeffs.alloc(logs, s, false); ub.add(t.coeffs.ptrs, &t.coeffs.d_view); }
@@ -268,8 +271,21 @@ struct Prover {
       t.merkle.prepare(cols, t.lde.logs);
       ub.add(t.merkle.cols, &t.merkle.d_cols_view);
     }
+    // small columns of every size: ONE fused interpolate + extend launch for all of them (k_small_commit)
+    std::vector<SmallCommitJob> sjobs;
+    uint32_t small_max = 0;
+    for (size_t i = 0; i < logs.size(); i++)
+      if (small_commit_serves(logs[i], cfg.log_blowup_factor)) {
+        const uint32_t* src = !from_coeffs ? evals->ptrs[i] : small_evals_in_place ? t.coeffs.ptrs[i] : nullptr;
+        sjobs.push_back(SmallCommitJob{src, t.coeffs.ptrs[i], t.lde.ptrs[i], logs[i], inv(M31::from_u32(1u << logs[i])).v});
+        small_max = std::max(small_max, logs[i]);
+      }
+    SmallCommitJob* d_sjobs = nullptr;
+    if (!sjobs.empty()) ub.add(sjobs, &d_sjobs);
     t.tables = ub.flush(s);   // ONE host->device copy for the whole tree
+    small_commit(d_sjobs, (uint32_t)sjobs.size(), small_max, cfg.log_blowup_factor, *tw, s);
     for (auto& g : grps) {
+      if (small_commit_serves(g.log, cfg.log_blowup_factor)) continue;
       const uint32_t* const* dsrc = d_table + g.off;
       uint32_t* const* dco = (uint32_t* const*)(d_table + g.off + g.n);
       uint32_t* const* dld = (uint32_t* const*)(d_table + g.off + 2 * g.n);
@@ -1082,9 +1098,10 @@ struct SegmentProver {
           for (auto i : kv.second) table.push_back(t.coeffs.ptrs[i]);
         }
         DevBuf d_table = upload(table, st);
-        for (auto& g : grps) interpolate(d_table.as<uint32_t*>() + g.off, g.n, g.log, *P.tw, st);
+        for (auto& g : grps)
+          if (!small_commit_serves(g.log, cfg.log_blowup_factor)) interpolate(d_table.as<uint32_t*>() + g.off, g.n, g.log, *P.tw, st);
       }
-      P.commit_enqueue(t, nullptr, true, st);
+      P.commit_enqueue(t, nullptr, true, st, true, /*small_evals_in_place=*/true);   // the small columns: interpolated + extended in one launch
     }
     {
       CM_HIP(hipEventSynchronize(sums_ready));
