@@ -14,7 +14,7 @@ namespace cm {
 
 struct Twiddles {
   uint32_t R = 0;  // tables cover CanonicCoset(R).circle_domain() and every smaller canonic domain
-  uint32_t *xtw = nullptr, *ixtw = nullptr, *ytw = nullptr, *iytw = nullptr;
+  uint32_t *xtw = nullptr, *ixtw = nullptr, *ytw = nullptr, *iytw = nullptr;   // every entry is 2 * twiddle (< 2^32): see mul_tw2
   uint32_t* scratch = nullptr;   // point tables the build kernels read (twiddles_scratch_words(R) words)
 };
 Twiddles* twiddles_create(uint32_t R, hipStream_t st);

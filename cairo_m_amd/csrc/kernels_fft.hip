@@ -156,13 +156,13 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
         // in every lane: fetch it with a scalar load (no per-lane address arithmetic, no vector memory op).
         if (E - k + 6 <= b) h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
 #ifdef CM_FFT_ABL_NO_TW  /* tools/fft_lab: cost of the twiddle fetch (results are wrong) */
-        M31 w(h | 3u);
+        const uint32_t w = h | 3u;
 #else
-        M31 w(twp[h]);
+        const uint32_t w = twp[h];   // 2 * twiddle (mul_tw2)
 #endif
         M31 x = v[e], y = v[e1];
-        if (INVERSE) { v[e] = x + y; v[e1] = (x - y) * w; }
-        else { M31 yt = y * w; v[e] = x + yt; v[e1] = x - yt; }
+        if (INVERSE) { v[e] = x + y; v[e1] = mul_tw2(x - y, w); }
+        else { M31 yt = mul_tw2(y, w); v[e] = x + yt; v[e1] = x - yt; }
       }
     }
     const bool staged_out = (rr + 1 == G::NR) && !INVERSE && M == 0;
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
 #pragma clang loop unroll(full)
       for (uint32_t e = 0; e < NE; e++) {
         M31 o = v[e];
-        if (INVERSE && a.scale != 1u) o = o * sc;
+        if (INVERSE && a.scale != 1u) o = sc * o;   // the doubled operand of M31 operator* is the loop-invariant one
         dst[gel(e)] = o.v;
       }
     } else {

@@ -15,10 +15,10 @@ namespace cm {
 // (x, y) of CanonicCoset(l).circle_domain() at bit-reversed storage row r
 __device__ __forceinline__ void domain_point_at_row(const TwiddleView& tw, uint32_t l, uint32_t r, M31& x, M31& y) {
   uint32_t h = r >> 1;
-  M31 yy(tw.ytw[(1u << (l - 1)) + h]);
+  M31 yy(tw.ytw[(1u << (l - 1)) + h] >> 1);   // the tables hold 2w
   y = (r & 1u) ? -yy : yy;
   uint32_t L = tw.R - l;
-  M31 xx(tw.xtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + (h >> 1)]);
+  M31 xx(tw.xtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + (h >> 1)] >> 1);
   x = (h & 1u) ? -xx : xx;
 }
 
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_fold_circle(Ptr4 dst, CPtr4 src, uint32
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << (log_n - 1))) return;
   QM31 alpha = alpha_dev ? QM31::from_u32(alpha_dev) : QM31(M31(alpha4_0), M31(alpha4_1), M31(alpha4_2), M31(alpha4_3));
-  M31 yinv(tw.iytw[(1u << (log_n - 1)) + i]);
+  M31 yinv(tw.iytw[(1u << (log_n - 1)) + i] >> 1);
   QM31 f0 = ld4(src.p, 2 * i), f1 = ld4(src.p, 2 * i + 1);
   QM31 v = (f0 + f1) + alpha * ((f0 - f1) * yinv);
   if (accumulate) v = ld4(dst.p, i) * (alpha * alpha) + v;
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) k_fold_line(Ptr4 out, CPtr4 src, uint32_t
   if (i >= (1u << (log_n - 1))) return;
   QM31 alpha = alpha_dev ? QM31::from_u32(alpha_dev) : QM31(M31(alpha4_0), M31(alpha4_1), M31(alpha4_2), M31(alpha4_3));
   uint32_t L = tw.R - (log_n + 1);
-  M31 xinv(tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + i]);
+  M31 xinv(tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + i] >> 1);
   QM31 f0 = ld4(src.p, 2 * i), f1 = ld4(src.p, 2 * i + 1);
   st4(out.p, i, (f0 + f1) + alpha * ((f0 - f1) * xinv));
 }
@@ -187,11 +187,11 @@ __global__ void __launch_bounds__(256) k_fold_line_circle(Ptr4 out, CPtr4 src, C
   if (i >= (1u << (log_n - 1))) return;
   const QM31 alpha = QM31::from_u32(alpha_dev), ac = QM31::from_u32(alpha_c_dev);
   uint32_t L = tw.R - (log_n + 1);
-  M31 xinv(tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + i]);
+  M31 xinv(tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + i] >> 1);
   QM31 f0 = ld4(src.p, 2 * i), f1 = ld4(src.p, 2 * i + 1);
   const QM31 line = (f0 + f1) + alpha * ((f0 - f1) * xinv);
   // circle evaluation of log_n folds onto the line of log_n - 1 (k_fold_circle with its log = log_n)
-  M31 yinv(tw.iytw[(1u << (log_n - 1)) + i]);
+  M31 yinv(tw.iytw[(1u << (log_n - 1)) + i] >> 1);
   QM31 g0 = ld4(circle.p, 2 * i), g1 = ld4(circle.p, 2 * i + 1);
   const QM31 v = (g0 + g1) + ac * ((g0 - g1) * yinv);
   st4(out.p, i, line * (ac * ac) + v);
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
       const QM31 alpha = QM31::from_u32(a.alphas);
       const QM31 alpha2 = alpha * alpha;
       for (uint32_t i = tid; i < n; i += 1024) {
-        M31 yinv(a.tw.iytw[n + i]);
+        M31 yinv(a.tw.iytw[n + i] >> 1);
         QM31 f0 = ld4(L.circle, 2 * i), f1 = ld4(L.circle, 2 * i + 1);
         st4(L.cols, i, ld4(L.cols, i) * alpha2 + ((f0 + f1) + alpha * ((f0 - f1) * yinv)));
       }
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
       const uint32_t Lx = a.tw.R - (l + 1);
       const uint32_t* xt = a.tw.ixtw + (1u << (a.tw.R - 1)) - (1u << (a.tw.R - 1 - Lx));
       for (uint32_t i = tid; i < n / 2; i += 1024) {
-        M31 xinv(xt[i]);
+        M31 xinv(xt[i] >> 1);
         QM31 f0 = ld4(L.cols, 2 * i), f1 = ld4(L.cols, 2 * i + 1);
         st4(dst, i, (f0 + f1) + alpha * ((f0 - f1) * xinv));
       }

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) k_twiddles_x(uint32_t* __restrict__ xtw, 
     v[n++] = twiddle_point(tab, R, init + step * j).x;
   }
   batch_inverse8(v, iv, n);
-  for (uint32_t k = 0; k < n; k++) { const uint32_t t = t0 + k * nthreads; xtw[t] = v[k].v; ixtw[t] = iv[k].v; }
+  for (uint32_t k = 0; k < n; k++) { const uint32_t t = t0 + k * nthreads; xtw[t] = v[k].v << 1; ixtw[t] = iv[k].v << 1; }   // tables hold 2w (mul_tw2)
 }
 __global__ void __launch_bounds__(256) k_twiddles_y(uint32_t* __restrict__ ytw, uint32_t* __restrict__ iytw, uint32_t R, const uint32_t* __restrict__ tab) {
   const uint32_t nthreads = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) k_twiddles_y(uint32_t* __restrict__ ytw, 
     v[n++] = twiddle_point(tab, R, init + step * j).y;
   }
   batch_inverse8(v, iv, n);
-  for (uint32_t k = 0; k < n; k++) { const uint32_t t = 1 + t0 + k * nthreads; ytw[t] = v[k].v; iytw[t] = iv[k].v; }
+  for (uint32_t k = 0; k < n; k++) { const uint32_t t = 1 + t0 + k * nthreads; ytw[t] = v[k].v << 1; iytw[t] = iv[k].v << 1; }
 }
 
 // ---------------------------------------------------------------- butterfly passes
@@ -142,12 +142,12 @@ __global__ void __launch_bounds__(256) k_fft_pass(FftPassArgs a) {
         uint32_t L = a.R - a.n + layer - 1;
         tw = a.xtw[(1u << (a.R - 1)) - (1u << (a.R - 1 - L)) + h];
       }
-      M31 x(tile[e0]), y(tile[e1]), t(tw);
+      M31 x(tile[e0]), y(tile[e1]);
       if (INVERSE) {
         tile[e0] = (x + y).v;
-        tile[e1] = ((x - y) * t).v;
+        tile[e1] = mul_tw2(x - y, tw).v;
       } else {
-        M31 yt = y * t;
+        M31 yt = mul_tw2(y, tw);
         tile[e0] = (x + yt).v;
         tile[e1] = (x - yt).v;
       }
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_fft_pass(FftPassArgs a) {
     uint32_t l = e & ((1u << M) - 1), mid = e >> M;
     uint32_t g = base | (mid << a.lo) | l;
     uint32_t v = tile[e];
-    if (a.scale != 1u) v = (M31(v) * sc).v;
+    if (a.scale != 1u) v = (sc * M31(v)).v;
     dst[g] = v;
   }
 }
@@ -185,13 +185,13 @@ __global__ void __launch_bounds__(256) k_small_commit(const SmallCommitJob* __re
                                       : tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - (tw.R - n + layer - 1))) + h];
         const M31 x(tile[e0]), y(tile[e1]);
         tile[e0] = (x + y).v;
-        tile[e1] = ((x - y) * M31(t)).v;
+        tile[e1] = mul_tw2(x - y, t).v;
       }
       __syncthreads();
     }
     const M31 sc(jb.inv_n);
     for (uint32_t e = threadIdx.x; e < N; e += blockDim.x) {
-      const uint32_t v = (M31(tile[e]) * sc).v;
+      const uint32_t v = (sc * M31(tile[e])).v;
       tile[e] = v;
       jb.coeffs[e] = v;
     }
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) k_small_commit(const SmallCommitJob* __re
       const uint32_t h = e0 >> (layer + 1);
       const uint32_t t = layer == 0 ? tw.ytw[(1u << (no - 1)) + h]
                                     : tw.xtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - (tw.R - no + layer - 1))) + h];
-      const M31 x(tile[e0]), yt = M31(tile[e1]) * M31(t);
+      const M31 x(tile[e0]), yt = mul_tw2(M31(tile[e1]), t);
       tile[e0] = (x + yt).v;
       tile[e1] = (x - yt).v;
     }
