@@ -127,10 +127,18 @@ CM_HD QM31 operator-(QM31 x) { return QM31(-x.a, -x.b); }
 #if defined(__HIP_DEVICE_COMPILE__)
 // Sum of at most four products of values <= P (< 2^64) -> canonical M31: s = lo31 + 2^31 mid31 + 2^62 top2, 2^31 = 1 (mod P)
 __device__ __forceinline__ M31 m31_fold64(unsigned long long s) {
+#ifdef CM_FOLD64_OLD
   const uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
   uint32_t t = (lo & P) + (__funnelshift_r(lo, hi, 31) & P) + (hi >> 30);   // <= 2P + 3 < 2^32
   t = (t & P) + (t >> 31);                                                    // <= P + 1
   return M31(m31_csub(t));
+#else
+  // 2^32 = 2 (mod P): u = lo + 2 hi < 3 * 2^32 (one v_lshl_add_u64), then u = u31 + 2^31 * (u >> 31), u >> 31 <= 5
+  const unsigned long long u = (unsigned long long)(uint32_t)s + ((s >> 32) << 1);
+  const uint32_t ulo = (uint32_t)u, uhi = (uint32_t)(u >> 32);
+  const uint32_t t = (ulo & P) + __funnelshift_r(ulo, uhi, 31);             // <= P + 5
+  return M31(m31_csub(t));
+#endif
 }
 #endif
 // (a + b u)(c + d u), u^2 = 2 + i.  Device form: every output coordinate is ONE unreduced 64-bit sum of raw products
