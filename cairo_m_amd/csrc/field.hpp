@@ -101,10 +101,26 @@ struct CM31 {
 CM_HD CM31 operator+(CM31 x, CM31 y) { return CM31(x.a + y.a, x.b + y.b); }
 CM_HD CM31 operator-(CM31 x, CM31 y) { return CM31(x.a - y.a, x.b - y.b); }
 CM_HD CM31 operator-(CM31 x) { return CM31(-x.a, -x.b); }
-CM_HD CM31 operator*(CM31 x, CM31 y) { return CM31(x.a * y.a - x.b * y.b, x.a * y.b + x.b * y.a); }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ M31 m31_fold64(unsigned long long s);
+#endif
+// device form: each coordinate is one unreduced 64-bit sum of two raw products (-x.b as P - x.b) and one fold
+CM_HD CM31 operator*(CM31 x, CM31 y) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CM_QM31_MUL_PLAIN)
+  typedef unsigned long long u64;
+  const u64 xa = x.a.v, xb = x.b.v, nb = P - x.b.v;
+  return CM31(m31_fold64(xa * y.a.v + nb * y.b.v), m31_fold64(xa * y.b.v + xb * y.a.v));
+#else
+  return CM31(x.a * y.a - x.b * y.b, x.a * y.b + x.b * y.a);
+#endif
+}
 CM_HD CM31 operator*(CM31 x, M31 y) { const uint32_t y2 = y.v << 1; return CM31(mul_tw2(x.a, y2), mul_tw2(x.b, y2)); }   // one shift for both
 CM_HD CM31 inv(CM31 x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CM_QM31_MUL_PLAIN)
+  M31 n = inv(m31_fold64((unsigned long long)x.a.v * x.a.v + (unsigned long long)x.b.v * x.b.v));
+#else
   M31 n = inv(x.a * x.a + x.b * x.b);
+#endif
   return CM31(x.a * n, -(x.b * n));
 }
 // multiply by R = 2 + i
