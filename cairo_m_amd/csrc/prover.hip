@@ -1354,7 +1354,9 @@ struct SegmentProver {
     for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
     // ONE round trip for two roots: root 3 is waited for; root 2 and the random coefficient of the device-side step are
     // already in pinned memory.  Host replay in transcript order.
+    ht.mark("composition: enqueued, waiting for root 3");
     P.trees[3].merkle.root(P.trees[3].root.data(), st);
+    ht.mark("composition: root 3 arrived");
     {
       memcpy(P.trees[2].root.data(), pinned_words() + PIN_ROOT2, 32);
       ch.mix_root(P.trees[2].root);
@@ -1364,6 +1366,7 @@ struct SegmentProver {
       for (size_t g = powers.size(); g-- > 0;) { powers[g] = cur; cur = cur * rho; }   // host copy: the OODS check needs it
     }
     ch.mix_root(P.trees[3].root);
+    ht.mark("composition: host replay of the coefficient step");
     P.tick("composition_commit");
 
     // host side of compute_fri_quotients for every size group, packed into ONE upload:
