@@ -1144,6 +1144,7 @@ struct SegmentProver {
     // per size.
     struct AccRef { ColumnSet* set; size_t first; uint32_t* const* dev() const { return set->dev(first); } };
     std::map<uint32_t, AccRef> accs;  // evaluation log -> its 4 accumulator columns
+    std::set<uint32_t> acc_interpolated;   // evaluation logs whose accumulator is interpolated inside the constraints region
     std::map<uint32_t, std::vector<int>> cgroups;
     for (int c = 0; c < air::N_COMPONENTS; c++) cgroups[clog[c] + 1].push_back(c);
     ColumnSet acc_top, acc_rest;
@@ -1269,13 +1270,22 @@ struct SegmentProver {
       launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
                                fk.stream(7));   // first: latency-bound, hidden under the large kernels
       int gi = 0, small_rr = 0;
+      static const bool early_interp = getenv("CM_NO_EARLY_ACC_INTERP") == nullptr;   // A/B switch
       // large groups first (descending size) so the long kernels start early
       for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it, ++gi) {
+        bool one_stream = true;   // every component of the group ran on the group's stream (no slots, no batched small ones)
         for (int c : it->second) {
-          if (std::find(small_cids.begin(), small_cids.end(), c) != small_cids.end()) continue;
+          if (std::find(small_cids.begin(), small_cids.end(), c) != small_cids.end()) { one_stream = false; continue; }
           // the components of a size group share its accumulator: one stream for all of them; slotted ones are independent
           hipStream_t sc = slot_of[c] >= 0 ? fk.stream(4 + (small_rr++ % 3)) : fk.stream(gi % 4);
+          if (slot_of[c] >= 0) one_stream = false;
           launch_constraints(c, cargs[c], sc);
+        }
+        // DomainEvaluationAccumulator::finalize starts here for such a group: its accumulator is interpolated on the same
+        // stream right behind its constraint kernels — no second fork/join region for the large accumulators
+        if (one_stream && early_interp) {
+          interpolate(accs.at(it->first).dev(), 4, it->first, *P.tw, fk.stream(gi % 4));
+          acc_interpolated.insert(it->first);
         }
       }
       fk.join();
@@ -1290,11 +1300,14 @@ struct SegmentProver {
     // bit-identical, and the extend/add chain over the large domains disappears.
     {
       CommittedTree& t = P.trees[3];
-      {
+      if (acc_interpolated.empty()) {
         Fork fk(st);
         int k = 0;
         for (auto it = accs.rbegin(); it != accs.rend(); ++it, ++k) interpolate(it->second.dev(), 4, it->first, *P.tw, fk.stream(k));
         fk.join();
+      } else {   // what is left are the slotted / batched small sizes: a handful of single-launch transforms, in a row
+        for (auto it = accs.rbegin(); it != accs.rend(); ++it)
+          if (!acc_interpolated.count(it->first)) interpolate(it->second.dev(), 4, it->first, *P.tw, st);
       }
       {
         AddColumnsSrc as;
