@@ -856,6 +856,7 @@ struct SegmentProver {
     fri_and_pow();
     decommit();
 
+    kprof_close_run();   // a run of timed launches still open on this thread
     P.finish();
     pf.phase_ms = P.phase_ms;
     pf.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - P.t0).count();
