@@ -20,6 +20,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+ALL_CPUS = os.sched_getaffinity(0)   # before the library binds proving threads to the GPU's NUMA node
 
 FIB_N = 419_000          # 10*n + 12 = 4,190,012 VM steps (~2^22), one segment
 HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -60,6 +61,8 @@ def cpu_baseline(sample_n, hip_words=None):
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     orc = Oracle(so)
+    # the library keeps threads that prove on the CPUs next to the GPU; the CPU baseline gets the host's cores back
+    os.sched_setaffinity(0, ALL_CPUS)
     inp = synth_fibonacci(sample_n)
     t = time.perf_counter()
     words, cells = orc.prove(inp.view)
