@@ -17,6 +17,10 @@ def oracle_threads():
     return int(os.environ.get("ORACLE_THREADS", min(16, os.cpu_count() or 1)))
 
 
+_ALL_CPUS = os.sched_getaffinity(0)   # the HIP library binds threads that prove to the GPU's NUMA node; the oracle's OpenMP
+                                      # team gets the whole host back (its provers are 2x slower on one socket)
+
+
 class Oracle:
     def __init__(self, so):
         os.environ.setdefault("OMP_NUM_THREADS", str(oracle_threads()))  # read by libgomp when it loads
@@ -102,6 +106,7 @@ def _attach_prover(cls):
 
     def prove(self, view, cfg=(16, 1, 0, 80)):
         """CPU restatement of prove_cairo_m; returns (words, cells)."""
+        os.sched_setaffinity(0, _ALL_CPUS)
         setup(self)
         h = C.c_void_p()
         rc = self.L.orc_prove(view, (C.c_uint32 * 4)(*cfg), C.byref(h))
