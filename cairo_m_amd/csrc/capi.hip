@@ -105,8 +105,19 @@ int32_t cm_stream_create(cm_stream_t* out) {
   });
 }
 int32_t cm_stream_destroy(cm_stream_t s) {
-  return guard([&] { if (s) CM_HIP(hipStreamDestroy(S(s))); });
+  return guard([&] {
+    if (!s) return;
+    stage_forget_stream(S(s));        // its copies out of this thread's upload ring finish first (pool.hip)
+    CM_HIP(hipStreamDestroy(S(s)));
+  });
 }
+int32_t cm_set_cpu_affinity(int32_t mode) {
+  return guard([&] {
+    CM_CHECK(mode == 0 || mode == 1, "cm_set_cpu_affinity: mode must be 0 (never) or 1 (scoped to the proving calls)");
+    set_cpu_affinity_mode(mode);
+  });
+}
+int32_t cm_get_cpu_affinity(void) { return cpu_affinity_mode(); }
 int32_t cm_stream_sync(cm_stream_t s) {
   return guard([&] { CM_HIP(hipStreamSynchronize(S(s))); });
 }

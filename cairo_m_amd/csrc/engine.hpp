@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <sched.h>
 #include <vector>
 #include <string.h>
 #include <utility>
@@ -125,6 +126,21 @@ void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st);
 // thread, so every host thread that enters the library is bound to that device on its first call.
 void set_library_device(int device);
 void bind_thread_to_library_device();
+// CPU placement of proving threads (pool.hip): scoped to one cm_prove_* call on caller threads, permanent on the library's own
+// cm_prove_many workers; cm_set_cpu_affinity(0) / CM_CPU_AFFINITY=0 / CM_NO_CPU_AFFINITY=1 turn it off.
+struct AffinityScope {
+  cpu_set_t saved;
+  bool active = false;
+  AffinityScope();
+  ~AffinityScope();
+  AffinityScope(const AffinityScope&) = delete;
+  AffinityScope& operator=(const AffinityScope&) = delete;
+};
+void set_cpu_affinity_mode(int mode);
+int cpu_affinity_mode();
+void bind_worker_thread_cpus();
+// forget a caller stream that is about to be destroyed (waits for its copies out of the calling thread's upload ring)
+void stage_forget_stream(hipStream_t st);
 
 // The prover's main stream of the calling host thread (created on first use, non-blocking): concurrent proofs
 // from different host threads run on different streams and overlap on the GPU.

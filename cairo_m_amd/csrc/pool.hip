@@ -3,6 +3,7 @@
 // zero hipMalloc/hipFree calls; cm_shutdown()/pool_trim() hands everything back.
 #include <algorithm>
 #include "engine.hpp"
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -75,7 +76,12 @@ struct Stage {
   std::mutex mu;
   uint8_t* base = nullptr;
   size_t size = (size_t)32 << 20, off = 0;
-  std::vector<hipStream_t> users;   // streams with copies out of the ring since the last wrap (main stream + Fork side streams)
+  // One event per stream with copies out of the ring since the last wrap (main stream + Fork side streams + caller streams
+  // of the per-op C ABI), re-recorded behind every copy.  The wrap waits on the EVENTS, never on the stream handles: a caller
+  // may have destroyed its cm_stream_t in the meantime (hipStreamDestroy lets queued work finish; a recorded event stays valid).
+  struct User { hipStream_t st; hipEvent_t ev; };
+  std::vector<User> users;
+  std::vector<hipEvent_t> spare;
   void ensure() {
     if (!base) CM_HIP(hipHostMalloc((void**)&base, size, hipHostMallocDefault));
   }
@@ -103,14 +109,35 @@ void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
   }
   if (s.off + need > s.size) {
     // wrap: every copy still reading the ring must have executed, on whichever stream it was enqueued
-    for (hipStream_t u : s.users) CM_HIP(hipStreamSynchronize(u));
+    for (const Stage::User& u : s.users) { CM_HIP(hipEventSynchronize(u.ev)); s.spare.push_back(u.ev); }
     s.users.clear();
     s.off = 0;
   }
-  if (std::find(s.users.begin(), s.users.end(), st) == s.users.end()) s.users.push_back(st);
+  auto it = std::find_if(s.users.begin(), s.users.end(), [&](const Stage::User& u) { return u.st == st; });
+  if (it == s.users.end()) {
+    hipEvent_t ev;
+    if (!s.spare.empty()) { ev = s.spare.back(); s.spare.pop_back(); }
+    else CM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    s.users.push_back({st, ev});
+    it = s.users.end() - 1;
+  }
   memcpy(s.base + s.off, src, bytes);
   CM_HIP(hipMemcpyAsync(dst, s.base + s.off, bytes, hipMemcpyHostToDevice, st));
+  CM_HIP(hipEventRecord(it->ev, st));
   s.off += need;
+}
+void stage_forget_stream(hipStream_t st) {
+  // cm_stream_destroy on the owning thread: the handle value may be recycled for a new stream, whose copies must get their own
+  // event history — wait for this stream's copies out of the ring and drop the entry
+  Stage& s = stage();
+  std::lock_guard<std::mutex> lk(s.mu);
+  for (size_t i = 0; i < s.users.size(); i++)
+    if (s.users[i].st == st) {
+      (void)hipEventSynchronize(s.users[i].ev);
+      s.spare.push_back(s.users[i].ev);
+      s.users.erase(s.users.begin() + i);
+      break;
+    }
 }
 
 // Pinned landing buffer for device->host results (one per host thread, grown on demand): a hipMemcpyAsync into
@@ -170,45 +197,87 @@ hipStream_t Fork::stream(int i) {
 }
 namespace { int g_library_device = -1; }
 void set_library_device(int device) { g_library_device = device; }
-// The CPUs next to the GPU (sysfs local_cpulist of its PCI function).  A proof is ~450 launches and ~10 host round trips; on a
-// two-socket host every doorbell write, pinned-memory read and completion signal of a thread running on the OTHER socket crosses
-// the inter-socket fabric, which showed as 0.5 ms per proof between otherwise identical boxes.  Threads that prove are therefore
-// kept on the GPU's NUMA node (CM_NO_CPU_AFFINITY=1 leaves the caller's affinity alone).
-static bool local_cpus_of_device(int device, cpu_set_t* set) {
-  char bus[64] = {0};
-  if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) return false;
-  for (char* c = bus; *c; c++) *c = (char)tolower(*c);
-  const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
-  FILE* f = fopen(path.c_str(), "r");
-  if (!f) return false;
-  char line[4096] = {0};
-  const bool ok = fgets(line, sizeof(line), f) != nullptr;
-  fclose(f);
-  if (!ok) return false;
-  CPU_ZERO(set);
-  int n = 0;
-  for (char* tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
-    int a = 0, b = 0;
-    const int got = sscanf(tok, "%d-%d", &a, &b);
-    if (got < 1) continue;
-    if (got == 1) b = a;
-    for (int c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET(c, set); n++; }
-  }
-  return n > 0;
-}
 void bind_thread_to_library_device() {
   static thread_local int bound = -1;
   if (g_library_device >= 0 && bound != g_library_device) {
-    CM_HIP(hipSetDevice(g_library_device));
+    CM_HIP(hipSetDevice(g_library_device));   // hipSetDevice is per host thread
     bound = g_library_device;
-    static const bool pin = getenv("CM_NO_CPU_AFFINITY") == nullptr;
-    cpu_set_t local, cur;
-    if (pin && local_cpus_of_device(g_library_device, &local) && sched_getaffinity(0, sizeof(cur), &cur) == 0) {
-      cpu_set_t both;
-      CPU_AND(&both, &local, &cur);                      // never widen what the caller (cgroup, taskset) allowed
-      if (CPU_COUNT(&both) > 0) (void)sched_setaffinity(0, sizeof(both), &both);   // tid 0 = the calling thread
-    }
   }
+}
+// ---- CPU placement of proving threads --------------------------------------------------------------------------------------
+// A proof is ~450 launches and ~10 host round trips; on a two-socket host every doorbell write, pinned-memory read and
+// completion signal of a thread running on the socket AWAY from the GPU crosses the inter-socket fabric (0.1-0.5 ms per proof
+// between otherwise identical boxes).  Policy (cm_set_cpu_affinity / CM_CPU_AFFINITY):
+//   0  never touch any thread's affinity;
+//   1  (default) SCOPED: a caller thread is moved onto the GPU's local_cpulist for the duration of one cm_prove_* call and gets
+//      its own mask back before the call returns — nothing leaks to the host application, to threads it creates later or to
+//      child processes; the library's own cm_prove_many workers stay on the GPU's node for good.
+// The mask is only ever narrowed inside what the caller (cgroup, taskset) allowed.
+namespace {
+std::atomic<int> g_affinity_mode{-1};
+int affinity_mode() {
+  int m = g_affinity_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("CM_CPU_AFFINITY");
+    m = (getenv("CM_NO_CPU_AFFINITY") != nullptr) ? 0 : (e ? (atoi(e) != 0) : 1);
+    g_affinity_mode.store(m);
+  }
+  return m;
+}
+// sysfs local_cpulist of the device's PCI function ("0-63,128-191"), parsed once per device under a lock (no strtok: the
+// cm_prove_many workers arrive here together)
+bool local_cpus_of_device(int device, cpu_set_t* set) {
+  static std::mutex mu;
+  static std::map<int, std::pair<bool, cpu_set_t>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(device);
+  if (it == cache.end()) {
+    std::pair<bool, cpu_set_t> ent;
+    ent.first = false;
+    CPU_ZERO(&ent.second);
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) == hipSuccess) {
+      for (char* c = bus; *c; c++) *c = (char)tolower(*c);
+      const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+      if (FILE* f = fopen(path.c_str(), "r")) {
+        char line[4096] = {0};
+        if (fgets(line, sizeof(line), f)) {
+          int n = 0;
+          const char* p = line;
+          while (*p) {
+            if (!isdigit((unsigned char)*p)) { p++; continue; }
+            char* end = nullptr;
+            long a = strtol(p, &end, 10), b = a;
+            if (*end == '-') b = strtol(end + 1, &end, 10);
+            for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, &ent.second); n++; }
+            p = end;
+          }
+          ent.first = n > 0;
+        }
+        fclose(f);
+      }
+    }
+    it = cache.emplace(device, ent).first;
+  }
+  *set = it->second.second;
+  return it->second.first;
+}
+bool narrow_to_device(cpu_set_t* saved) {
+  cpu_set_t local, both;
+  if (g_library_device < 0 || !local_cpus_of_device(g_library_device, &local)) return false;
+  if (sched_getaffinity(0, sizeof(*saved), saved) != 0) return false;
+  CPU_AND(&both, &local, saved);                       // never widen what the caller (cgroup, taskset) allowed
+  if (CPU_COUNT(&both) == 0 || CPU_EQUAL(&both, saved)) return false;
+  return sched_setaffinity(0, sizeof(both), &both) == 0;   // tid 0 = the calling thread
+}
+}  // namespace
+void set_cpu_affinity_mode(int mode) { g_affinity_mode.store(mode ? 1 : 0); }
+int cpu_affinity_mode() { return affinity_mode(); }
+AffinityScope::AffinityScope() { active = affinity_mode() == 1 && narrow_to_device(&saved); }
+AffinityScope::~AffinityScope() { if (active) (void)sched_setaffinity(0, sizeof(saved), &saved); }
+void bind_worker_thread_cpus() {
+  cpu_set_t saved;
+  if (affinity_mode() == 1) (void)narrow_to_device(&saved);
 }
 hipStream_t thread_main_stream() {
   static thread_local hipStream_t s = nullptr;

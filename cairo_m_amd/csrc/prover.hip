@@ -837,6 +837,7 @@ struct SegmentProver {
   struct QGroup { uint32_t log = 0; std::vector<const uint32_t*> cols; std::vector<QBatch> batches; ColumnSet out;
                   size_t o_cols = 0, o_out = 0, o_ci = 0, o_cc = 0, o_qb = 0, o_sidx = 0, o_ep = 0; };
   std::vector<QGroup> qg;                    // DEEP-quotient size groups
+  AffinityScope cpu_scope;   // the calling thread sits next to the GPU for this proof only (pool.hip)
   SegmentProver(const DeviceInput& din_, const cm_pcs_config& cfg_)
       : din(din_), in(din_.meta), cfg(cfg_), out(new ProofData()), pf(*out), st(nullptr), ch(P.ch) {
     pf.config = cfg;
@@ -870,7 +871,6 @@ struct SegmentProver {
     } else if (tl_pp_cache.valid) {
       tl_pp_cache = PreprocessedCache();  // switched off: give the buffers back to the pool
     }
-    return out.release();
     return out.release();
   }
 
@@ -1607,6 +1607,7 @@ struct ProveWorkers {
     std::lock_guard<std::mutex> lk(mu);
     while (threads.size() < n) {
       threads.emplace_back([this] {
+        bool placed = false;
         for (;;) {
           std::function<void()> job;
           {
@@ -1615,6 +1616,8 @@ struct ProveWorkers {
             job = std::move(jobs.front());
             jobs.pop_front();
           }
+          // library-owned thread: it stays next to the GPU (cm_init has run by the time a job arrives)
+          if (!placed) { bind_worker_thread_cpus(); placed = true; }
           job();
         }
       });
@@ -1636,8 +1639,11 @@ bool proof_from_words(const uint32_t* w, uint64_t n, ProofData& p, std::string& 
 }  // namespace cm
 
 // ================================================================= C ABI
-struct cm_proof { cm::ProofData* d; std::string json; std::vector<uint32_t> words; };
-struct cm_device_input { cm::DeviceInput* d; };
+struct cm_proof {   // owns its ProofData: every failure path (parse error, exception mid-proof) releases it with the wrapper
+  cm::ProofData* d = nullptr; std::string json; std::vector<uint32_t> words;
+  ~cm_proof() { delete d; }
+};
+struct cm_device_input { cm::DeviceInput* d = nullptr; ~cm_device_input() { delete d; } };
 extern "C" int32_t cm_set_last_error(const char* msg);
 
 template <class F>
@@ -1650,11 +1656,11 @@ static cm_pcs_config default_cfg() { return cm_pcs_config{16, 1, 0, 80}; }
 
 extern "C" {
 int32_t cm_input_upload(const cm_prover_input* input, cm_device_input** out) {
-  return pguard([&] { cm_device_input* h = new cm_device_input(); h->d = cm::upload_input(*input); *out = h; });
+  return pguard([&] { std::unique_ptr<cm_device_input> h(new cm_device_input()); h->d = cm::upload_input(*input); *out = h.release(); });
 }
 struct cm_host_input { cm::host::ProverInputOwned owned; cm_prover_input view; };  // = host_api.hip
 int32_t cm_adapt_segment_device(const cm_runner_segment* seg, cm_device_input** out) {
-  return pguard([&] { cm_device_input* h = new cm_device_input(); h->d = cm::adapt_segment_device(*seg); *out = h; });
+  return pguard([&] { std::unique_ptr<cm_device_input> h(new cm_device_input()); h->d = cm::adapt_segment_device(*seg); *out = h.release(); });
 }
 int32_t cm_device_input_download(const cm_device_input* in, cm_host_input** out) {
   return pguard([&] {
@@ -1664,13 +1670,13 @@ int32_t cm_device_input_download(const cm_device_input* in, cm_host_input** out)
     *out = h;
   });
 }
-int32_t cm_input_free(cm_device_input* h) { if (h) { delete h->d; delete h; } return 0; }
+int32_t cm_input_free(cm_device_input* h) { delete h; return 0; }
 int32_t cm_prove_device(const cm_device_input* input, const cm_pcs_config* config, cm_proof** out) {
   return pguard([&] {
     cm_pcs_config cfg = config ? *config : default_cfg();
-    cm_proof* p = new cm_proof();
+    std::unique_ptr<cm_proof> p(new cm_proof());
     p->d = cm::prove(*input->d, cfg);
-    *out = p;
+    *out = p.release();
   });
 }
 int32_t cm_prove_segment(const cm_prover_input* input, const cm_pcs_config* config, cm_proof** out) {
@@ -1696,9 +1702,9 @@ int32_t cm_prove_sharded(const cm_device_input* input, const cm_pcs_config* conf
   return pguard([&] {
     CM_CHECK(comm && comm->all_gather && comm->all_to_all_v && comm->send_buf && comm->recv_buf, "cm_prove_sharded: incomplete cm_comm");
     cm_pcs_config cfg = config ? *config : default_cfg();
-    cm_proof* p = new cm_proof();
+    std::unique_ptr<cm_proof> p(new cm_proof());
     p->d = cm::prove_sharded(*input->d, cfg, *comm);
-    *out = p;
+    *out = p.release();
   });
 }
 int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
@@ -1920,7 +1926,7 @@ int32_t cm_proof_from_words(const uint32_t* words, uint64_t n_words, cm_proof** 
     *out = p.release();
   });
 }
-int32_t cm_proof_free(cm_proof* p) { if (p) { delete p->d; delete p; } return 0; }
+int32_t cm_proof_free(cm_proof* p) { delete p; return 0; }
 int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out) {
   return pguard([&] {
     cm_proof* q = const_cast<cm_proof*>(p);

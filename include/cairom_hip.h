@@ -44,6 +44,17 @@ int32_t cm_last_error(char* buf, size_t buf_len);
 int32_t cm_stream_create(cm_stream_t* out);
 int32_t cm_stream_destroy(cm_stream_t s);
 int32_t cm_stream_sync(cm_stream_t s);
+/* CPU placement of proving threads.  A proof is ~450 kernel launches and ~10 host round trips; on a two-socket host a
+ * thread on the socket away from the GPU pays the inter-socket fabric on each of them (0.1-0.5 ms per proof).
+ *   mode 1 (default; env CM_CPU_AFFINITY=1): SCOPED — during cm_prove_device / cm_prove_segment / cm_prove_sharded the
+ *          calling thread's affinity is narrowed to the GPU's sysfs local_cpulist (intersected with the mask it
+ *          already had) and the caller's own mask is restored before the call returns, so nothing leaks into the
+ *          host application, into threads it creates later or into child processes.  The library's own
+ *          cm_prove_many worker threads stay on the GPU's node.
+ *   mode 0 (env CM_CPU_AFFINITY=0 or CM_NO_CPU_AFFINITY=1): the library never calls sched_setaffinity.
+ * cm_get_cpu_affinity returns the mode in force. */
+int32_t cm_set_cpu_affinity(int32_t mode);
+int32_t cm_get_cpu_affinity(void);
 
 /* ---- Column<T> / ColumnOps (Stwo core::backend::{Column, ColumnOps}; used through
  *      `ComponentTrace::to_evals`, crates/prover/src/components/mod.rs:168-177) ----------------- */

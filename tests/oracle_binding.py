@@ -1,7 +1,6 @@
 """ctypes binding of oracle/liboracle.so — the CPU restatement used as the parity checker."""
 import ctypes as C
 import os
-import os
 import numpy as np
 
 _u32p = C.POINTER(C.c_uint32)
@@ -15,10 +14,6 @@ def oracle_threads():
     """OpenMP threads the oracle runs with: its loops are short, so beyond a few tens of threads the
     fork/join cost dominates (a 256-core host is slower than an 8-core one)."""
     return int(os.environ.get("ORACLE_THREADS", min(16, os.cpu_count() or 1)))
-
-
-_ALL_CPUS = os.sched_getaffinity(0)   # the HIP library binds threads that prove to the GPU's NUMA node; the oracle's OpenMP
-                                      # team gets the whole host back (its provers are 2x slower on one socket)
 
 
 class Oracle:
@@ -106,7 +101,6 @@ def _attach_prover(cls):
 
     def prove(self, view, cfg=(16, 1, 0, 80)):
         """CPU restatement of prove_cairo_m; returns (words, cells)."""
-        os.sched_setaffinity(0, _ALL_CPUS)
         setup(self)
         h = C.c_void_p()
         rc = self.L.orc_prove(view, (C.c_uint32 * 4)(*cfg), C.byref(h))
