@@ -91,6 +91,43 @@ __device__ __forceinline__ void b2s_compress_quad(uint32_t& h0, uint32_t& h1, co
   h1 ^= b ^ d;
 }
 
+// ---- Merkle node framing (framing.hpp switch `hash_node`) ------------------------------------------------------------
+// RFC = false: Stwo's raw compression chain from the zero state, t = f = 0 (the default; every kernel below compiles to
+// exactly the code it had before the switch existed).  RFC = true: RFC 7693 Blake2s-256 of the same byte string
+// left || right || le32(column values): parameter block in h[0], running byte counter, final flag on the last block.
+template <bool RFC>
+struct NodeFrame {
+  uint32_t total, done;
+  __device__ __forceinline__ NodeFrame(bool has_children, uint32_t n_cols)
+      : total(RFC ? (has_children ? 64u : 0u) + 4u * n_cols : 0u), done(0) {}
+  __device__ __forceinline__ void init(uint32_t (&h)[8]) const {
+    if (RFC) {
+      h[0] = 0x6A09E667u ^ 0x01010020u; h[1] = 0xBB67AE85u; h[2] = 0x3C6EF372u; h[3] = 0xA54FF53Au;
+      h[4] = 0x510E527Fu; h[5] = 0x9B05688Cu; h[6] = 0x1F83D9ABu; h[7] = 0x5BE0CD19u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) h[k] = 0;
+    }
+  }
+  __device__ __forceinline__ void init_quad(uint32_t q, uint32_t& h0, uint32_t& h1) const {
+    if (RFC) {
+      h0 = b2s_sel4(q, 0x6A09E667u ^ 0x01010020u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au);
+      h1 = b2s_sel4(q, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u);
+    } else {
+      h0 = 0; h1 = 0;
+    }
+  }
+  // one 64-byte block carrying `bytes` message bytes (zero padded)
+  __device__ __forceinline__ void absorb(uint32_t (&h)[8], const uint32_t (&m)[16], uint32_t bytes) {
+    if (RFC) { done += bytes; b2s_compress(h, m, done, done == total ? 0xFFFFFFFFu : 0u); }
+    else b2s_compress(h, m);
+  }
+  __device__ __forceinline__ void absorb_quad(uint32_t& h0, uint32_t& h1, const uint32_t (&m)[16], uint32_t q, uint32_t bytes) {
+    if (RFC) { done += bytes; b2s_compress_quad(h0, h1, m, q, done, done == total ? 0xFFFFFFFFu : 0u); }
+    else b2s_compress_quad(h0, h1, m, q);
+  }
+};
+
 // ---- device-side Fiat-Shamir steps for the FRI commit phase -----------------------------------------------
 // Between two FRI layers the transcript only does mix_root(layer root) and draw_felt() (the folding
 // challenge).  Doing those two hashes on the device keeps the whole commit phase on the stream:

@@ -4,11 +4,47 @@
 #include "../../include/cairom_hip.h"
 #include "engine.hpp"
 #include "merkle_tree.hpp"
+#include "framing.hpp"
 #include <string.h>
+#include <stdio.h>
 #include <string>
+#include <atomic>
 #include <mutex>
 
 using namespace cm;
+
+// ---- process-wide framing switches (framing.hpp) -----------------------------------------------------------------------
+namespace cm {
+namespace {
+std::mutex g_framing_mu;
+Framing g_framing;
+std::atomic<bool> g_framing_init{false};
+}  // namespace
+const Framing& framing() {
+  if (!g_framing_init) {
+    std::lock_guard<std::mutex> lk(g_framing_mu);
+    if (!g_framing_init) {
+      Framing f;
+      if (const char* e = getenv("CM_FRAMING")) {
+        const std::string err = Framing::parse(e, f);
+        if (!err.empty()) { fprintf(stderr, "libcairom_hip: CM_FRAMING ignored: %s\n", err.c_str()); f = Framing(); }
+      }
+      g_framing = f;
+      g_framing_init = true;
+    }
+  }
+  return g_framing;
+}
+std::string set_framing(const char* spec) {
+  Framing f;
+  const std::string err = Framing::parse(spec, f);
+  if (!err.empty()) return err;
+  (void)framing();   // settle the env initialisation first
+  std::lock_guard<std::mutex> lk(g_framing_mu);
+  g_framing = f;
+  return "";
+}
+}  // namespace cm
 
 namespace {
 thread_local std::string g_last_error;
@@ -118,6 +154,20 @@ int32_t cm_set_cpu_affinity(int32_t mode) {
   });
 }
 int32_t cm_get_cpu_affinity(void) { return cpu_affinity_mode(); }
+int32_t cm_set_framing(const char* spec) {
+  return guard([&] {
+    const std::string err = set_framing(spec);
+    if (!err.empty()) throw CmError(1, err);
+  });
+}
+int32_t cm_get_framing(char* buf, size_t buf_len) {
+  const std::string d = framing().describe();
+  if (!buf || !buf_len) return (int32_t)d.size();
+  const size_t n = d.size() < buf_len - 1 ? d.size() : buf_len - 1;
+  memcpy(buf, d.data(), n);
+  buf[n] = 0;
+  return (int32_t)n;
+}
 int32_t cm_stream_sync(cm_stream_t s) {
   return guard([&] { CM_HIP(hipStreamSynchronize(S(s))); });
 }
@@ -141,6 +191,28 @@ int32_t cm_col_h2d(cm_handle h, const uint32_t* src, uint64_t n, cm_stream_t s) 
 int32_t cm_col_d2h(cm_handle h, uint32_t* dst, uint64_t n, cm_stream_t s) {
   return guard([&] {
     CM_HIP(hipMemcpyAsync(dst, P32(h), n * 4, hipMemcpyDeviceToHost, S(s)));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+// Column<T>::{at, set, clone} of a Rust-side backend: element ranges and device-to-device copies
+int32_t cm_col_read(cm_handle h, uint64_t offset_u32, uint32_t* dst, uint64_t n, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(h && (dst || !n), "cm_col_read: null column / destination");
+    CM_HIP(hipMemcpyAsync(dst, P32(h) + offset_u32, n * 4, hipMemcpyDeviceToHost, S(s)));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_col_write(cm_handle h, uint64_t offset_u32, const uint32_t* src, uint64_t n, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(h && (src || !n), "cm_col_write: null column / source");
+    CM_HIP(hipMemcpyAsync(P32(h) + offset_u32, src, n * 4, hipMemcpyHostToDevice, S(s)));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
+int32_t cm_col_copy(cm_handle dst, cm_handle src, uint64_t n, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(dst && src, "cm_col_copy: null column");
+    CM_HIP(hipMemcpyAsync(P32(dst), P32(src), n * 4, hipMemcpyDeviceToDevice, S(s)));
     CM_HIP(hipStreamSynchronize(S(s)));
   });
 }

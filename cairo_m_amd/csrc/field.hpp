@@ -226,6 +226,15 @@ CM_HD CPoint<F> cadd(CPoint<F> p, CPoint<F> q) {
 }
 template <class F>
 CM_HD CPoint<F> cconj(CPoint<F> p) { return CPoint<F>{p.x, -p.y}; }
+// derived `Ord` of CirclePoint<SecureField> (x then y; QM31 as its four words in order): the key of a BTreeMap over sample
+// points — framing switch `sample_batch=sorted`
+inline bool secure_point_less(const CPoint<QM31>& a, const CPoint<QM31>& b) {
+  uint32_t wa[8], wb[8];
+  a.x.to_u32(wa); a.y.to_u32(wa + 4);
+  b.x.to_u32(wb); b.y.to_u32(wb + 4);
+  for (int i = 0; i < 8; i++) if (wa[i] != wb[i]) return wa[i] < wb[i];
+  return false;
+}
 CM_HD M31 double_x(M31 x) { M31 s = x * x; return s + s - M31(1); }
 CM_HD QM31 double_x(QM31 x) { QM31 s = x * x; return s + s - M31(1); }
 

@@ -9,11 +9,31 @@
 #include <array>
 #include <vector>
 #include "field.hpp"
+#include "framing.hpp"
 
 namespace cm {
 namespace hostch {
 
 using Hash32 = std::array<uint8_t, 32>;
+
+// Transcript log (cm_set_transcript_log / cm_proof_transcript): one entry per Channel-trait call the reference prover makes
+// (Stwo `Channel::{mix_u32s, mix_felts, mix_u64, draw_felt, draw_felts, draw_random_bytes}` + `MerkleChannel::mix_root`), with
+// the digest AFTER the call.  integration/prover-hip/tests/golden_dump.rs records the same entries from the reference through
+// a logging channel wrapper, and the oracle records them too: tests compare the three step by step.
+struct TranscriptEntry {
+  const char* op;
+  Hash32 digest;                 // channel digest after the call
+  uint32_t n_words;              // words mixed in / drawn
+  std::vector<uint32_t> words;   // the first <= 16 of them (mixed input or drawn output)
+};
+using TranscriptLog = std::vector<TranscriptEntry>;
+// a copied Channel (PoW probes) must not write into the log of the channel it was copied from
+struct LogRef {
+  TranscriptLog* p = nullptr;
+  LogRef() {}
+  LogRef(const LogRef&) : p(nullptr) {}
+  LogRef& operator=(const LogRef&) { return *this; }
+};
 
 inline void compress(uint32_t h[8], const uint32_t m[16], uint64_t t, uint32_t f0) {
   static const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
@@ -65,6 +85,13 @@ inline Hash32 blake2s256(const uint8_t* data, size_t len) {
 struct Channel {
   Hash32 digest{};
   uint32_t n_challenges = 0, n_sent = 0;
+  LogRef log;
+  void note(const char* op, const uint32_t* w, size_t n) {
+    if (!log.p) return;
+    TranscriptEntry e{op, digest, (uint32_t)n, {}};
+    e.words.assign(w, w + (n < 16 ? n : 16));
+    log.p->push_back(std::move(e));
+  }
   void update(const Hash32& d) { digest = d; n_challenges++; n_sent = 0; }
   uint32_t trailing_zeros() const {
     uint32_t w[4];
@@ -72,43 +99,65 @@ struct Channel {
     for (int i = 0; i < 4; i++) if (w[i]) return 32 * i + __builtin_ctz(w[i]);
     return 128;
   }
-  void mix_u32s(const uint32_t* w, size_t n) {
+  void absorb_u32s(const uint32_t* w, size_t n) {
     std::vector<uint8_t> buf(32 + 4 * n);
     memcpy(buf.data(), digest.data(), 32);
     if (n) memcpy(buf.data() + 32, w, 4 * n);
     update(blake2s256(buf.data(), buf.size()));
   }
+  void mix_u32s(const uint32_t* w, size_t n) {
+    absorb_u32s(w, n);
+    note("mix_u32s", w, n);
+  }
   void mix_felts(const QM31* f, size_t n) {
     std::vector<uint32_t> w(4 * n);
     for (size_t i = 0; i < n; i++) f[i].to_u32(&w[4 * i]);
-    mix_u32s(w.data(), w.size());
+    absorb_u32s(w.data(), w.size());
+    note("mix_felts", w.data(), w.size());
   }
-  // raw compression F(digest, [lo, hi, 0...], t=0, f=0) — the form Stwo's SIMD grind searches over
+  // framing switch `mix_u64` (framing.hpp): raw compression F(digest, [lo, hi, 0...], t=0, f=0) — the form Stwo's SIMD grind
+  // searches over — or mix_u32s(&[lo, hi])
   void mix_u64(uint64_t v) {
-    uint32_t h[8], m[16] = {0};
-    memcpy(h, digest.data(), 32);
-    m[0] = (uint32_t)v; m[1] = (uint32_t)(v >> 32);
-    compress(h, m, 0, 0);
-    Hash32 d;
-    memcpy(d.data(), h, 32);
-    update(d);
+    const uint32_t lohi[2] = {(uint32_t)v, (uint32_t)(v >> 32)};
+    if (framing().mix_u64_u32s) {
+      absorb_u32s(lohi, 2);
+    } else {
+      uint32_t h[8], m[16] = {0};
+      memcpy(h, digest.data(), 32);
+      m[0] = lohi[0]; m[1] = lohi[1];
+      compress(h, m, 0, 0);
+      Hash32 d;
+      memcpy(d.data(), h, 32);
+      update(d);
+    }
+    note("mix_u64", lohi, 2);
   }
   void mix_root(const Hash32& root) {
     uint8_t buf[64];
     memcpy(buf, digest.data(), 32);
     memcpy(buf + 32, root.data(), 32);
     update(blake2s256(buf, 64));
+    uint32_t w[8];
+    memcpy(w, root.data(), 32);
+    note("mix_root", w, 8);
   }
-  Hash32 draw_random_bytes() {
+  Hash32 random_bytes() {   // unlogged core of draw_random_bytes
     uint8_t buf[65] = {0};
     memcpy(buf, digest.data(), 32);
     memcpy(buf + 32, &n_sent, 4);
     n_sent++;
     return blake2s256(buf, 65);
   }
+  Hash32 draw_random_bytes() {
+    Hash32 b = random_bytes();
+    uint32_t w[8];
+    memcpy(w, b.data(), 32);
+    note("draw_random_bytes", w, 8);
+    return b;
+  }
   void draw_base_felts(M31 out[8]) {
     for (;;) {
-      Hash32 b = draw_random_bytes();
+      Hash32 b = random_bytes();
       uint32_t u[8];
       memcpy(u, b.data(), 32);
       bool ok = true;
@@ -121,6 +170,8 @@ struct Channel {
   QM31 draw_felt() {
     M31 f[8];
     draw_base_felts(f);
+    const uint32_t w[4] = {f[0].v, f[1].v, f[2].v, f[3].v};
+    note("draw_felt", w, 4);
     return QM31(f[0], f[1], f[2], f[3]);
   }
   void draw_two_felts(QM31& a, QM31& b) {  // draw_felts(2): one hash, 8 base felts
@@ -128,6 +179,9 @@ struct Channel {
     draw_base_felts(f);
     a = QM31(f[0], f[1], f[2], f[3]);
     b = QM31(f[4], f[5], f[6], f[7]);
+    uint32_t w[8];
+    for (int i = 0; i < 8; i++) w[i] = f[i].v;
+    note("draw_felts", w, 8);
   }
 };
 

@@ -9,6 +9,7 @@
 #include "fri_kernels.hpp"
 #include "kprof.hpp"
 #include "blake2s_dev.hpp"
+#include "framing.hpp"
 
 namespace cm {
 
@@ -197,6 +198,7 @@ __global__ void __launch_bounds__(256) k_fold_line_circle(Ptr4 out, CPtr4 src, C
   st4(out.p, i, line * (ac * ac) + v);
 }
 
+template <bool RFC>   // framing.hpp switch `hash_node`
 __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
   // Tree levels of <= 256 nodes: one node per QUAD of lanes (b2s_compress_quad, ~1.4 us instead of ~2.7 us per
   // dependent compression) with the level being consumed kept in LDS; larger levels: one node per lane through HBM.
@@ -243,8 +245,10 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
 #pragma unroll
             for (int c = 0; c < 16; c++) m[c] = p[c];
           }
-          uint32_t h0 = 0, h1 = 0;
-          b2s_compress_quad(h0, h1, m, q);
+          NodeFrame<RFC> fr(!leaf, leaf ? 4u : 0u);
+          uint32_t h0, h1;
+          fr.init_quad(q, h0, h1);
+          fr.absorb_quad(h0, h1, m, q, leaf ? 16u : 64u);
           uint32_t* o = L.merkle[k] + (size_t)node * 8;
           o[q] = h0; o[4 + q] = h1;
           buf[cur][node * 8 + q] = h0; buf[cur][node * 8 + 4 + q] = h1;
@@ -264,8 +268,10 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
             m[0] = c0.x; m[1] = c0.y; m[2] = c0.z; m[3] = c0.w; m[4] = c1.x; m[5] = c1.y; m[6] = c1.z; m[7] = c1.w;
             m[8] = c2.x; m[9] = c2.y; m[10] = c2.z; m[11] = c2.w; m[12] = c3.x; m[13] = c3.y; m[14] = c3.z; m[15] = c3.w;
           }
-          uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-          b2s_compress(h, m);
+          NodeFrame<RFC> fr(!leaf, leaf ? 4u : 0u);
+          uint32_t h[8];
+          fr.init(h);
+          fr.absorb(h, m, leaf ? 16u : 64u);
           uint4* o = reinterpret_cast<uint4*>(L.merkle[k] + (size_t)i * 8);
           o[0] = make_uint4(h[0], h[1], h[2], h[3]);
           o[1] = make_uint4(h[4], h[5], h[6], h[7]);
@@ -338,7 +344,8 @@ void quotient_coeffs(const QuotientCoefJob* d_jobs, uint32_t n_jobs, const uint3
 void fri_tail(const FriTailArgs& a, hipStream_t st) {
   CM_CHECK(a.top_log <= FRI_TAIL_MAX_LOG && a.last_log < a.top_log, "fri_tail: bad layer range");
   KProfScope kp("k_fri_tail", 0.0, st);
-  hipLaunchKernelGGL(k_fri_tail, dim3(1), dim3(1024), 0, st, a);
+  if (framing().hash_node_rfc) hipLaunchKernelGGL(k_fri_tail<true>, dim3(1), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL(k_fri_tail<false>, dim3(1), dim3(1024), 0, st, a);
   CM_HIP(hipGetLastError());
 }
 

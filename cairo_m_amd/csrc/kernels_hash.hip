@@ -15,21 +15,37 @@
 #include "kprof.hpp"
 #include "blake2s_dev.hpp"
 #include "merkle_kernels.hpp"
+#include "framing.hpp"
 
 namespace cm {
 
 // Proof of work: smallest nonce in [base, base + n) with trailing_zeros(F(digest, [lo,hi,0..])[0..16B]) >= bits.
 // result initialised to ~0ull; atomicMin keeps the smallest hit.
 struct GrindDigest { uint32_t w[8]; };   // the channel digest travels as a kernel argument: no host->device copy
+// mix_u64 of the channel whose digest is `dg` (framing.hpp switch `mix_u64`): U32S = false -> the raw compression
+// F(digest, [lo, hi, 0...], t = 0, f = 0); U32S = true -> Blake2s256(digest || le32(lo) || le32(hi)), one final 40-byte block
+template <bool U32S>
+__device__ __forceinline__ void mix_u64_dev(const uint32_t (&dg)[8], uint64_t v, uint32_t (&h)[8]) {
+  uint32_t m[16] = {0};
+  if (U32S) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) m[k] = dg[k];
+    m[8] = (uint32_t)v; m[9] = (uint32_t)(v >> 32);
+    h[0] = 0x6A09E667u ^ 0x01010020u; h[1] = 0xBB67AE85u; h[2] = 0x3C6EF372u; h[3] = 0xA54FF53Au;
+    h[4] = 0x510E527Fu; h[5] = 0x9B05688Cu; h[6] = 0x1F83D9ABu; h[7] = 0x5BE0CD19u;
+    b2s_compress(h, m, 40, 0xFFFFFFFFu);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = dg[k];
+    m[0] = (uint32_t)v; m[1] = (uint32_t)(v >> 32);
+    b2s_compress(h, m);
+  }
+}
+template <bool U32S>
 __global__ void __launch_bounds__(256) k_grind(GrindDigest digest, uint32_t bits, uint64_t base, unsigned long long* result) {
   const uint64_t nonce = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t h[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) h[k] = digest.w[k];
-  uint32_t m[16] = {0};
-  m[0] = (uint32_t)nonce;
-  m[1] = (uint32_t)(nonce >> 32);
-  b2s_compress(h, m);
+  mix_u64_dev<U32S>(digest.w, nonce, h);
   // trailing zeros of the first 16 bytes as LE u128
   uint32_t tz;
   if (h[0]) tz = __ffs(h[0]) - 1;
@@ -75,6 +91,7 @@ __global__ void k_chan_init_mix_root_draw(ChanWords init, uint32_t* chan, const 
 // lanes test 64 nonces at a time, and lane k hashes the draw with counter n_sent = k (a draw is retried with the next
 // counter when a word is >= 2P, so the i-th VALID counter belongs to relation i).  The host replays the same steps on its
 // own channel later, from `out` = {root[8], nonce[2], n_sent, error, z of relation 0 [4]}, and checks they agree.
+template <bool U32S>
 __global__ void __launch_bounds__(64) k_step_pow_relations(ChanWords init, const uint32_t* __restrict__ root, uint32_t pow_bits, uint32_t n_rel,
                                                            uint32_t max_rel, uint32_t* __restrict__ rel_z, uint32_t* __restrict__ rel_pow,
                                                            uint32_t* __restrict__ out) {
@@ -85,15 +102,12 @@ __global__ void __launch_bounds__(64) k_step_pow_relations(ChanWords init, const
   for (int i = 0; i < 8; i++) { m[i] = init.w[i]; m[8 + i] = root[i]; }
   h[0] = iv0; h[1] = 0xBB67AE85u; h[2] = 0x3C6EF372u; h[3] = 0xA54FF53Au; h[4] = 0x510E527Fu; h[5] = 0x9B05688Cu; h[6] = 0x1F83D9ABu; h[7] = 0x5BE0CD19u;
   b2s_compress(h, m, 64, 0xFFFFFFFFu);
-  // proof of work over the raw compression F(digest, [lo, hi, 0...], t = 0, f = 0)
+  // proof of work over mix_u64 (default framing: the raw compression F(digest, [lo, hi, 0...], t = 0, f = 0))
   uint64_t nonce = 0;
   for (uint64_t base = 0;; base += 64) {
     uint32_t g[8];
-    for (int i = 0; i < 8; i++) g[i] = h[i];
-    for (int i = 0; i < 16; i++) m[i] = 0;
     const uint64_t cand = base + lane;
-    m[0] = (uint32_t)cand; m[1] = (uint32_t)(cand >> 32);
-    b2s_compress(g, m);
+    mix_u64_dev<U32S>(h, cand, g);
     uint32_t tz;
     if (g[0]) tz = __ffs(g[0]) - 1;
     else if (g[1]) tz = 32 + __ffs(g[1]) - 1;
@@ -103,10 +117,12 @@ __global__ void __launch_bounds__(64) k_step_pow_relations(ChanWords init, const
     const unsigned long long hit = __ballot(tz >= pow_bits);
     if (hit) { nonce = base + (uint64_t)(__ffsll((long long)hit) - 1); break; }
   }
-  // mix_u64(nonce): digest = F(digest, [lo, hi, 0...])
-  for (int i = 0; i < 16; i++) m[i] = 0;
-  m[0] = (uint32_t)nonce; m[1] = (uint32_t)(nonce >> 32);
-  b2s_compress(h, m);
+  // mix_u64(nonce)
+  {
+    uint32_t g[8];
+    mix_u64_dev<U32S>(h, nonce, g);
+    for (int i = 0; i < 8; i++) h[i] = g[i];
+  }
   // draw_random_bytes with n_sent = lane: Blake2s256(digest || le32(n_sent) || 0^28 || 0x00) — 65 bytes, two blocks
   uint32_t d[8];
   d[0] = iv0; d[1] = 0xBB67AE85u; d[2] = 0x3C6EF372u; d[3] = 0xA54FF53Au; d[4] = 0x510E527Fu; d[5] = 0x9B05688Cu; d[6] = 0x1F83D9ABu; d[7] = 0x5BE0CD19u;
@@ -156,19 +172,22 @@ void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* con
   // algorithmic bytes: column values once + 64 B of child hashes in, 32 B out per node
   KProfScope kp("k_merkle_layer", (4.0 * ncols + (d_prev ? 64.0 : 0.0) + 32.0) * (double)n, st,
                 /* Blake2s compressions */ (double)n * ((d_prev ? 1.0 : 0.0) + (double)((ncols + 15) / 16)));
-  hipLaunchKernelGGL(k_merkle_layer, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
+  if (framing().hash_node_rfc) hipLaunchKernelGGL(k_merkle_layer<true>, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
+  else hipLaunchKernelGGL(k_merkle_layer<false>, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
   CM_HIP(hipGetLastError());
 }
 void merkle_layer_quad(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
                        uint32_t* d_out, hipStream_t st) {
   uint32_t n = 1u << log_size;
   KProfScope kp("k_merkle_layer_quad", (4.0 * ncols + (d_prev ? 64.0 : 0.0) + 32.0) * (double)n, st);
-  hipLaunchKernelGGL(k_merkle_layer_quad, dim3((4 * n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
+  if (framing().hash_node_rfc) hipLaunchKernelGGL(k_merkle_layer_quad<true>, dim3((4 * n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
+  else hipLaunchKernelGGL(k_merkle_layer_quad<false>, dim3((4 * n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
   CM_HIP(hipGetLastError());
 }
 void merkle_multi(const MerkleMultiArgs& a, double alg_bytes, hipStream_t st) {
   KProfScope kp("k_merkle_multi", alg_bytes, st);
-  hipLaunchKernelGGL(k_merkle_multi, dim3((1u << a.top_log) / 256), dim3(256), 0, st, a);
+  if (framing().hash_node_rfc) hipLaunchKernelGGL(k_merkle_multi<true>, dim3((1u << a.top_log) / 256), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_merkle_multi<false>, dim3((1u << a.top_log) / 256), dim3(256), 0, st, a);
   CM_HIP(hipGetLastError());
 }
 void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log, hipStream_t st) {
@@ -187,7 +206,8 @@ void step_pow_relations(const uint32_t init9[9], const uint32_t* d_root, uint32_
   ChanWords cw;
   memcpy(cw.w, init9, sizeof(cw.w));
   CM_CHECK(n_rel >= 1 && n_rel <= 32, "step_pow_relations: relation count");
-  hipLaunchKernelGGL(k_step_pow_relations, dim3(1), dim3(64), 0, st, cw, d_root, pow_bits, n_rel, max_rel, d_rel_z, d_rel_pow, d_out16);
+  if (framing().mix_u64_u32s) hipLaunchKernelGGL(k_step_pow_relations<true>, dim3(1), dim3(64), 0, st, cw, d_root, pow_bits, n_rel, max_rel, d_rel_z, d_rel_pow, d_out16);
+  else hipLaunchKernelGGL(k_step_pow_relations<false>, dim3(1), dim3(64), 0, st, cw, d_root, pow_bits, n_rel, max_rel, d_rel_z, d_rel_pow, d_out16);
   CM_HIP(hipGetLastError());
 }
 void coeff_powers(const uint32_t* d_rho, uint32_t* d_powers, uint32_t n, hipStream_t st) {
@@ -220,12 +240,14 @@ void merkle_top(MerkleTopArgs& a, hipStream_t st) {
   CM_CHECK(a.top_log >= 9 && a.top_log <= MERKLE_TOP_MAX_LOG, "merkle_top: bad layer range");
   a.ticket = next_ticket(st);
   KProfScope kp("k_merkle_top", 0.0, st);
-  hipLaunchKernelGGL(k_merkle_top, dim3(1u << (a.top_log - 8)), dim3(256), 0, st, a);
+  if (framing().hash_node_rfc) hipLaunchKernelGGL(k_merkle_top<true>, dim3(1u << (a.top_log - 8)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_merkle_top<false>, dim3(1u << (a.top_log - 8)), dim3(256), 0, st, a);
   CM_HIP(hipGetLastError());
 }
 void merkle_tail(const MerkleTailArgs& a, hipStream_t st) {
   KProfScope kp("k_merkle_tail", 0.0, st);
-  hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(1024), 0, st, a);
+  if (framing().hash_node_rfc) hipLaunchKernelGGL(k_merkle_tail<true>, dim3(1), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL(k_merkle_tail<false>, dim3(1), dim3(1024), 0, st, a);
   CM_HIP(hipGetLastError());
 }
 uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st) {
@@ -237,7 +259,8 @@ uint64_t grind_gpu(const uint8_t digest[32], uint32_t bits, hipStream_t st) {
   uint64_t batch = 1ull << (bits + 3 < 12 ? 12 : (bits + 3 > 22 ? 22 : bits + 3));
   for (uint64_t base = 0;; base += batch, batch = batch < (1ull << 22) ? batch * 2 : batch) {
     CM_HIP(hipMemsetAsync(d_res.p, 0xFF, 8, st));   // ~0ull: atomicMin keeps the smallest nonce
-    hipLaunchKernelGGL(k_grind, dim3(batch / 256), dim3(256), 0, st, dg, bits, base, (unsigned long long*)d_res.p);
+    if (framing().mix_u64_u32s) hipLaunchKernelGGL(k_grind<true>, dim3(batch / 256), dim3(256), 0, st, dg, bits, base, (unsigned long long*)d_res.p);
+    else hipLaunchKernelGGL(k_grind<false>, dim3(batch / 256), dim3(256), 0, st, dg, bits, base, (unsigned long long*)d_res.p);
     CM_HIP(hipGetLastError());
     CM_HIP(hipMemcpyAsync(res, d_res.p, 8, hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));

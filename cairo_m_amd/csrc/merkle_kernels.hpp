@@ -8,6 +8,7 @@
 namespace cm {
 
 // hashes[i] = hash_node(children (prev[2i], prev[2i+1]) if prev != null, cols[*][i])
+template <bool RFC>
 __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const uint32_t* __restrict__ prev,
                                                       const uint32_t* const* __restrict__ cols, uint32_t n_cols,
                                                       uint32_t* __restrict__ out) {
@@ -21,7 +22,9 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
   const uint32_t i = blk0 + tid;
   __builtin_assume(i < (1u << 29));  // byte offsets fit 32 bits: scalar column base + 32-bit lane offset addressing
   const bool full_block = blk0 + 256 <= n;
-  uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  NodeFrame<RFC> fr(prev != nullptr, n_cols);
+  uint32_t h[8];
+  fr.init(h);
   uint32_t m[16];
   if (prev) {
     if (full_block) {
@@ -38,7 +41,7 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
       m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
       m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
       m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
-      b2s_compress(h, m);
+      fr.absorb(h, m, 64);
     } else if (i < n) {
       const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
       uint4 a = p[0], b = p[1], c = p[2], d = p[3];
@@ -46,7 +49,7 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
       m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
       m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
       m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
-      b2s_compress(h, m);
+      fr.absorb(h, m, 64);
     }
   }
   if (i < n) {
@@ -55,7 +58,7 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
     for (; c0 + 16 <= n_cols; c0 += 16) {  // full chunks: 16 loads issue back to back, no per-column bounds branches
 #pragma unroll
       for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
-      b2s_compress(h, m);
+      fr.absorb(h, m, 64);
     }
     if (n_cols - c0 == 4) {
       // SecureColumn leaves (every FRI layer, the composition tree): 4 live message words, 12 literal zeros — the compiler
@@ -63,11 +66,11 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
       uint32_t z[16] = {0};
 #pragma unroll
       for (uint32_t k = 0; k < 4; k++) z[k] = CM_GCOL(cols[c0 + k])[i];
-      b2s_compress(h, z);
+      fr.absorb(h, z, 16);
     } else if (c0 < n_cols) {
 #pragma unroll
       for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? CM_GCOL(cols[c0 + k])[i] : 0u;
-      b2s_compress(h, m);
+      fr.absorb(h, m, 4u * (n_cols - c0));
     }
   }
   if (full_block) {
@@ -85,10 +88,59 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
   }
 }
 
+// hash_node of one tree node, one thread per node (h is initialised here) / one quad of lanes per node
+template <bool RFC>
+__device__ __forceinline__ void merkle_node_thread(const uint32_t* children, const uint32_t* const* __restrict__ cols, uint32_t c_begin,
+                                                   uint32_t c_end, uint32_t i, uint32_t (&h)[8]) {
+  NodeFrame<RFC> fr(children != nullptr, c_end - c_begin);
+  fr.init(h);
+  uint32_t m[16];
+  if (children) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = children[k];
+    fr.absorb(h, m, 64);
+  }
+  uint32_t c0 = c_begin;
+  for (; c0 + 16 <= c_end; c0 += 16) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
+    fr.absorb(h, m, 64);
+  }
+  if (c0 < c_end) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? CM_GCOL(cols[c0 + k])[i] : 0u;
+    fr.absorb(h, m, 4u * (c_end - c0));
+  }
+}
+template <bool RFC>
+__device__ __forceinline__ void merkle_node_quad(const uint32_t* children, const uint32_t* const* __restrict__ cols, uint32_t c_begin,
+                                                 uint32_t c_end, uint32_t i, uint32_t q, uint32_t& h0, uint32_t& h1) {
+  NodeFrame<RFC> fr(children != nullptr, c_end - c_begin);
+  fr.init_quad(q, h0, h1);
+  uint32_t m[16];
+  if (children) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = children[k];
+    fr.absorb_quad(h0, h1, m, q, 64);
+  }
+  uint32_t c0 = c_begin;
+  for (; c0 + 16 <= c_end; c0 += 16) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
+    fr.absorb_quad(h0, h1, m, q, 64);
+  }
+  if (c0 < c_end) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? CM_GCOL(cols[c0 + k])[i] : 0u;
+    fr.absorb_quad(h0, h1, m, q, 4u * (c_end - c0));
+  }
+}
+
 // K consecutive layers (top_log, top_log-1, ..., top_log-K+1) in one launch.  A block hashes 256 nodes of the
 // top layer, keeps them in LDS, then 128 parents, 64 grand-parents, ...  Every layer is written to HBM (the
 // decommitment gathers need it) but intermediate layers are never re-read from HBM, and a 2^22 tree needs
 // 5 launches instead of 16.  Mid-size layers are launch-latency-bound as separate kernels.
+template <bool RFC>
 __global__ void __launch_bounds__(256) k_merkle_multi(MerkleMultiArgs a) {
   __shared__ uint32_t bufA[256 * 8];
   __shared__ uint32_t bufB[128 * 8];
@@ -104,25 +156,27 @@ __global__ void __launch_bounds__(256) k_merkle_multi(MerkleMultiArgs a) {
     const uint32_t node0 = blockIdx.x * active;  // first node of this block at this level
     if (tid < active) {
       const uint32_t i = node0 + tid;
-      uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const uint32_t c_begin = a.col_begin[lv], c_end = a.col_end[lv];
+      NodeFrame<RFC> fr(lv > 0 || a.prev, c_end - c_begin);
+      uint32_t h[8];
+      fr.init(h);
       uint32_t m[16];
       if (lv > 0 || a.prev) {
         const uint32_t* p = (lv == 0) ? a.prev + (size_t)i * 16 : buf[cur ^ 1] + tid * 16;
 #pragma unroll
         for (int k = 0; k < 16; k++) m[k] = p[k];
-        b2s_compress(h, m);
+        fr.absorb(h, m, 64);
       }
-      const uint32_t c_begin = a.col_begin[lv], c_end = a.col_end[lv];
       uint32_t c0 = c_begin;
       for (; c0 + 16 <= c_end; c0 += 16) {
 #pragma unroll
         for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(a.cols[c0 + k])[i];
-        b2s_compress(h, m);
+        fr.absorb(h, m, 64);
       }
       if (c0 < c_end) {
 #pragma unroll
         for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? CM_GCOL(a.cols[c0 + k])[i] : 0u;
-        b2s_compress(h, m);
+        fr.absorb(h, m, 4u * (c_end - c0));
       }
       uint4* o = reinterpret_cast<uint4*>(a.layers[lv] + (size_t)i * 8);
       o[0] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -139,6 +193,7 @@ __global__ void __launch_bounds__(256) k_merkle_multi(MerkleMultiArgs a) {
 // All layers 2^top_log .. 2^0 of a tree in ONE launch (one 1024-thread block): the small layers are pure
 // launch/dependency latency as separate kernels (26 trees x 10 layers per proof).  Hashes of the layer being
 // consumed stay in LDS; every layer is still written to HBM for the decommitment gathers.
+template <bool RFC>
 __global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
   // One node per QUAD of lanes (b2s_compress_quad): these layers have <= 256 nodes, so lanes are plentiful and
   // the sequential compression chain per node (up to ~70 compressions for the 2^5-row idle components) is all
@@ -153,27 +208,10 @@ __global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
   for (int l = (int)a.top_log; l >= 0; l--) {
     const uint32_t n = 1u << l;
     if (node < n) {
-      uint32_t h0 = 0, h1 = 0;
-      uint32_t m[16];
       const bool from_global = (l == (int)a.top_log);
-      if (!from_global || a.prev) {
-        const uint32_t* p = from_global ? a.prev + (size_t)node * 16 : buf[cur ^ 1] + node * 16;
-#pragma unroll
-        for (int k = 0; k < 16; k++) m[k] = p[k];
-        b2s_compress_quad(h0, h1, m, q);
-      }
-      const uint32_t c_begin = a.col_begin[l], c_end = a.col_end[l];
-      uint32_t c0 = c_begin;
-      for (; c0 + 16 <= c_end; c0 += 16) {
-#pragma unroll
-        for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(a.cols[c0 + k])[node];
-        b2s_compress_quad(h0, h1, m, q);
-      }
-      if (c0 < c_end) {
-#pragma unroll
-        for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? CM_GCOL(a.cols[c0 + k])[node] : 0u;
-        b2s_compress_quad(h0, h1, m, q);
-      }
+      const uint32_t* ch = (!from_global || a.prev) ? (from_global ? a.prev + (size_t)node * 16 : buf[cur ^ 1] + node * 16) : nullptr;
+      uint32_t h0, h1;
+      merkle_node_quad<RFC>(ch, a.cols, a.col_begin[l], a.col_end[l], node, q, h0, h1);
       uint32_t* o = a.layers[l] + (size_t)node * 8;
       o[q] = h0; o[4 + q] = h1;
       buf[cur][node * 8 + q] = h0; buf[cur][node * 8 + 4 + q] = h1;
@@ -186,46 +224,7 @@ __global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
 // Layers 2^top_log .. 2^0 in one launch (see MerkleTopArgs).  Phase 1: 9 levels per block (256 nodes -> 1), one node
 // per lane while >= 128 nodes are active, one node per quad of lanes below (half the dependent latency).  Phase 2: the
 // block that draws the last ticket reads the 2^(top_log-8) nodes the blocks produced and finishes like k_merkle_tail.
-__device__ __forceinline__ void merkle_node_thread(const uint32_t* children, const uint32_t* const* __restrict__ cols, uint32_t c_begin,
-                                                   uint32_t c_end, uint32_t i, uint32_t (&h)[8]) {
-  uint32_t m[16];
-  if (children) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) m[k] = children[k];
-    b2s_compress(h, m);
-  }
-  uint32_t c0 = c_begin;
-  for (; c0 + 16 <= c_end; c0 += 16) {
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
-    b2s_compress(h, m);
-  }
-  if (c0 < c_end) {
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? CM_GCOL(cols[c0 + k])[i] : 0u;
-    b2s_compress(h, m);
-  }
-}
-__device__ __forceinline__ void merkle_node_quad(const uint32_t* children, const uint32_t* const* __restrict__ cols, uint32_t c_begin,
-                                                 uint32_t c_end, uint32_t i, uint32_t q, uint32_t& h0, uint32_t& h1) {
-  uint32_t m[16];
-  if (children) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) m[k] = children[k];
-    b2s_compress_quad(h0, h1, m, q);
-  }
-  uint32_t c0 = c_begin;
-  for (; c0 + 16 <= c_end; c0 += 16) {
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
-    b2s_compress_quad(h0, h1, m, q);
-  }
-  if (c0 < c_end) {
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < c_end) ? CM_GCOL(cols[c0 + k])[i] : 0u;
-    b2s_compress_quad(h0, h1, m, q);
-  }
-}
+template <bool RFC>
 __global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
   __shared__ uint32_t bufA[256 * 8];
   __shared__ uint32_t bufB[128 * 8];
@@ -245,9 +244,9 @@ __global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
     if (active >= 128) {
       if (tid < active) {
         const uint32_t i = node0 + tid;
-        uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t h[8];
         const uint32_t* ch = lv > 0 ? buf[cur ^ 1] + tid * 16 : (a.prev ? a.prev + (size_t)i * 16 : nullptr);
-        merkle_node_thread(ch, a.cols, c_begin, c_end, i, h);
+        merkle_node_thread<RFC>(ch, a.cols, c_begin, c_end, i, h);
         uint4* o = reinterpret_cast<uint4*>(a.layers[l] + (size_t)i * 8);
         o[0] = make_uint4(h[0], h[1], h[2], h[3]);
         o[1] = make_uint4(h[4], h[5], h[6], h[7]);
@@ -258,8 +257,8 @@ __global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
       const uint32_t node = tid >> 2, q = tid & 3u;
       if (node < active) {
         const uint32_t i = node0 + node;
-        uint32_t h0 = 0, h1 = 0;
-        merkle_node_quad(buf[cur ^ 1] + node * 16, a.cols, c_begin, c_end, i, q, h0, h1);
+        uint32_t h0, h1;
+        merkle_node_quad<RFC>(buf[cur ^ 1] + node * 16, a.cols, c_begin, c_end, i, q, h0, h1);
         uint32_t* o = a.layers[l] + (size_t)i * 8;
         o[q] = h0; o[4 + q] = h1;
         buf[cur][node * 8 + q] = h0; buf[cur][node * 8 + 4 + q] = h1;
@@ -289,8 +288,8 @@ __global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
     for (uint32_t nd = node; nd < n; nd += 64) {
       const bool from_global = (l == base_log - 1);
       const uint32_t* ch = from_global ? a.layers[base_log] + (size_t)nd * 16 : buf[cur ^ 1] + nd * 16;
-      uint32_t h0 = 0, h1 = 0;
-      merkle_node_quad(ch, a.cols, a.col_begin[l], a.col_end[l], nd, q, h0, h1);
+      uint32_t h0, h1;
+      merkle_node_quad<RFC>(ch, a.cols, a.col_begin[l], a.col_end[l], nd, q, h0, h1);
       uint32_t* o = a.layers[l] + (size_t)nd * 8;
       o[q] = h0; o[4 + q] = h1;
       buf[cur][nd * 8 + q] = h0; buf[cur][nd * 8 + 4 + q] = h1;
@@ -302,31 +301,34 @@ __global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
 
 // One layer, one node per quad of lanes: for mid-size layers that carry hundreds of columns (poseidon2: 443
 // columns at 2^10 rows) the chain length per node dominates, not the node count.
+template <bool RFC>
 __global__ void __launch_bounds__(256) k_merkle_layer_quad(uint32_t log_size, const uint32_t* __restrict__ prev,
                                                            const uint32_t* const* __restrict__ cols, uint32_t n_cols,
                                                            uint32_t* __restrict__ out) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   const uint32_t i = t >> 2, q = t & 3u;
   if (i >= (1u << log_size)) return;  // whole quads drop out together
-  uint32_t h0 = 0, h1 = 0;
+  NodeFrame<RFC> fr(prev != nullptr, n_cols);
+  uint32_t h0, h1;
+  fr.init_quad(q, h0, h1);
   uint32_t m[16];
   if (prev) {
     const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
     uint4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
     m[0] = x0.x; m[1] = x0.y; m[2] = x0.z; m[3] = x0.w; m[4] = x1.x; m[5] = x1.y; m[6] = x1.z; m[7] = x1.w;
     m[8] = x2.x; m[9] = x2.y; m[10] = x2.z; m[11] = x2.w; m[12] = x3.x; m[13] = x3.y; m[14] = x3.z; m[15] = x3.w;
-    b2s_compress_quad(h0, h1, m, q);
+    fr.absorb_quad(h0, h1, m, q, 64);
   }
   uint32_t c0 = 0;
   for (; c0 + 16 <= n_cols; c0 += 16) {
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
-    b2s_compress_quad(h0, h1, m, q);
+    fr.absorb_quad(h0, h1, m, q, 64);
   }
   if (c0 < n_cols) {
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? CM_GCOL(cols[c0 + k])[i] : 0u;
-    b2s_compress_quad(h0, h1, m, q);
+    fr.absorb_quad(h0, h1, m, q, 4u * (n_cols - c0));
   }
   out[(size_t)i * 8 + q] = h0;
   out[(size_t)i * 8 + 4 + q] = h1;

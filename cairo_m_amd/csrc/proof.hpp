@@ -6,12 +6,14 @@
 //   * proof_to_words : flat u32 stream used by the parity tests (same format as oracle/oproof.hpp).
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
 #include <string>
 #include <vector>
 #include <array>
 #include "../../include/cairom_hip.h"
 #include "field.hpp"
 #include "merkle_tree.hpp"
+#include "host_channel.hpp"
 #include "air/air_common.hpp"
 
 namespace cm {
@@ -42,10 +44,30 @@ struct ProofData {
   std::vector<QM31> last_layer_poly;
   uint32_t last_layer_log_size = 0;
   // statistics (not part of the proof)
+  hostch::TranscriptLog transcript;   // every Fiat-Shamir step of this proof, when cm_set_transcript_log(1) (host_channel.hpp)
   uint64_t cells = 0, steps = 0;
   std::vector<double> phase_ms;
   double total_ms = 0;
 };
+
+// [{"op": "mix_u64", "digest": "<64 hex digits: the channel digest after the call>", "n_words": 2, "words": [..first <= 16..]}, ...]
+inline std::string transcript_to_json(const hostch::TranscriptLog& log) {
+  std::string out = "[";
+  char buf[80];
+  for (size_t i = 0; i < log.size(); i++) {
+    const auto& e = log[i];
+    out += i ? ",\n {\"op\": \"" : "{\"op\": \"";
+    out += e.op;
+    out += "\", \"digest\": \"";
+    for (int k = 0; k < 32; k++) { snprintf(buf, sizeof(buf), "%02x", e.digest[k]); out += buf; }
+    snprintf(buf, sizeof(buf), "\", \"n_words\": %u, \"words\": [", e.n_words);
+    out += buf;
+    for (size_t k = 0; k < e.words.size(); k++) { snprintf(buf, sizeof(buf), k ? ", %u" : "%u", e.words[k]); out += buf; }
+    out += "]}";
+  }
+  out += "]";
+  return out;
+}
 
 inline std::vector<uint32_t> proof_to_words(const ProofData& p) {
   std::vector<uint32_t> w;

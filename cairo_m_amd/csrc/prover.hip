@@ -10,6 +10,7 @@
 #include "fri_kernels.hpp"
 #include "gpu_air.hpp"
 #include "host_channel.hpp"
+#include "framing.hpp"
 #include "proof.hpp"
 #include "kprof.hpp"
 #include "point_eval.hpp"
@@ -184,6 +185,7 @@ struct CommittedTree {
   DevBuf tables;  // one upload: pointer tables of coeffs / lde / the FFT groups / the Merkle column order
 };
 
+static std::atomic<int> g_transcript_log{0};     // cm_set_transcript_log: proofs record every Fiat-Shamir step (ProofData::transcript)
 static std::atomic<int> g_proofs_in_flight{0};   // proofs being made by cm_prove_many runners right now (0 outside of it)
 struct Prover {
   hipStream_t st = 0;
@@ -717,10 +719,11 @@ static void component_logs(const cm_prover_input& in, uint32_t* clog) {
 // ---- transcript steps shared by the single-GPU and the sharded prover ------------------------------------------------------
 // PcsConfig::mix_into + PublicData::mix_into (prover.rs:33-36, 62-66)
 static void mix_config_and_public_data(Channel& ch, const cm_pcs_config& cfg, const PublicData& d) {
+  // PcsConfig::mix_into + FriConfig::mix_into (prover.rs:36); the order inside FriConfig is a framing switch (framing.hpp `pcs_mix`)
   ch.mix_u64(cfg.pow_bits);
   ch.mix_u64(cfg.log_blowup_factor);
-  ch.mix_u64(cfg.n_queries);
-  ch.mix_u64(cfg.log_last_layer_degree_bound);
+  if (framing().pcs_mix_blq) { ch.mix_u64(cfg.log_last_layer_degree_bound); ch.mix_u64(cfg.n_queries); }
+  else { ch.mix_u64(cfg.n_queries); ch.mix_u64(cfg.log_last_layer_degree_bound); }
   uint32_t w[7] = {d.initial_pc, d.initial_fp, d.final_pc, d.final_fp, d.clock, d.initial_root, d.final_root};
   ch.mix_u32s(w, 7);
   uint32_t lens[3] = {(uint32_t)d.program.size(), (uint32_t)d.input.size(), (uint32_t)d.output.size()};
@@ -842,6 +845,7 @@ struct SegmentProver {
       : din(din_), in(din_.meta), cfg(cfg_), out(new ProofData()), pf(*out), st(nullptr), ch(P.ch) {
     pf.config = cfg;
     bind_thread_to_library_device();
+    if (g_transcript_log.load()) P.ch.log.p = &pf.transcript;
     P.cfg = cfg;
     P.st = thread_main_stream();
     st = P.st;
@@ -1444,6 +1448,8 @@ struct SegmentProver {
             g.batches[bi].entries.push_back(QEntry{i, (ns == 2 && k == 0) ? sidx_prev[r.t][r.c] : sidx_cur[r.t][r.c]});
           }
         }
+        if (framing().sample_batch_sorted)   // ColumnSampleBatch::new_vec as a BTreeMap keyed by point (framing.hpp)
+          std::stable_sort(g.batches.begin(), g.batches.end(), [](const QBatch& a, const QBatch& b) { return secure_point_less(a.pt, b.pt); });
         size_t n_entries = 0;
         for (auto& bt : g.batches) n_entries += bt.entries.size();
         g.out.alloc(std::vector<uint32_t>(4, g.log), st, false);
@@ -1640,7 +1646,7 @@ bool proof_from_words(const uint32_t* w, uint64_t n, ProofData& p, std::string& 
 
 // ================================================================= C ABI
 struct cm_proof {   // owns its ProofData: every failure path (parse error, exception mid-proof) releases it with the wrapper
-  cm::ProofData* d = nullptr; std::string json; std::vector<uint32_t> words;
+  cm::ProofData* d = nullptr; std::string json, transcript_json; std::vector<uint32_t> words;
   ~cm_proof() { delete d; }
 };
 struct cm_device_input { cm::DeviceInput* d = nullptr; ~cm_device_input() { delete d; } };
@@ -1933,6 +1939,15 @@ int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out)
     if (q->json.empty()) q->json = cm::proof_to_json(*p->d);
     *json_out = q->json.c_str();
     *len_out = q->json.size();
+  });
+}
+int32_t cm_set_transcript_log(int32_t on) { cm::g_transcript_log.store(on ? 1 : 0); return 0; }
+int32_t cm_proof_transcript(const cm_proof* p, const char** json_out, size_t* len_out) {
+  return pguard([&] {
+    cm_proof* q = const_cast<cm_proof*>(p);
+    if (q->transcript_json.empty()) q->transcript_json = cm::transcript_to_json(p->d->transcript);
+    *json_out = q->transcript_json.c_str();
+    *len_out = q->transcript_json.size();
   });
 }
 int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* n_out) {

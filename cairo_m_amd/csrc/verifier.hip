@@ -99,6 +99,12 @@ namespace {
 
 // ---- Merkle (Stwo MerkleVerifier::verify over Blake2sMerkleHasher) ------------------------------------------
 Hash32 hash_node(const Hash32* left, const Hash32* right, const uint32_t* vals, size_t n) {
+  if (framing().hash_node_rfc) {   // framing.hpp `hash_node=rfc`: Blake2s-256 of left || right || le32(values)
+    std::vector<uint8_t> buf((left ? 64 : 0) + 4 * n);
+    if (left) { memcpy(buf.data(), left->data(), 32); memcpy(buf.data() + 32, right->data(), 32); }
+    if (n) memcpy(buf.data() + (left ? 64 : 0), vals, 4 * n);
+    return hostch::blake2s256(buf.data(), buf.size());
+  }
   uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, m[16];
   if (left) {
     memcpy(m, left->data(), 32);
@@ -225,6 +231,8 @@ QM31 row_quotient(const std::vector<std::vector<Sample>>& cols, QM31 random_coef
       if (b == batches.size()) batches.push_back(Batch{s.pt, {}});
       batches[b].entries.push_back({c, s.value});
     }
+  if (framing().sample_batch_sorted)
+    std::stable_sort(batches.begin(), batches.end(), [](const Batch& a, const Batch& b) { return secure_point_less(a.pt, b.pt); });
   QM31 acc;
   for (auto& b : batches) {
     QM31 alpha(M31(1)), num;
@@ -291,8 +299,8 @@ std::string verify_proof(const ProofData& pf, const cm_pcs_config& expected) {
   Channel ch;
   ch.mix_u64(cfg.pow_bits);
   ch.mix_u64(cfg.log_blowup_factor);
-  ch.mix_u64(cfg.n_queries);
-  ch.mix_u64(cfg.log_last_layer_degree_bound);
+  if (framing().pcs_mix_blq) { ch.mix_u64(cfg.log_last_layer_degree_bound); ch.mix_u64(cfg.n_queries); }
+  else { ch.mix_u64(cfg.n_queries); ch.mix_u64(cfg.log_last_layer_degree_bound); }
   mix_public_data(pf.public_data, ch);
   // column log sizes per tree (preprocessed, trace, interaction, composition)
   std::vector<std::vector<uint32_t>> logs(4);

@@ -63,6 +63,18 @@ class Backend:
         self._ck(self.L.cm_col_d2h(C.c_uint64(h), _p(out), C.c_uint64(n), C.c_uint64(0)))
         return out
 
+    def col_read(self, h, offset, n):
+        out = np.empty(n, dtype=np.uint32)
+        self._ck(self.L.cm_col_read(C.c_uint64(h), C.c_uint64(offset), _p(out), C.c_uint64(n), C.c_uint64(0)))
+        return out
+
+    def col_write(self, h, offset, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint32)
+        self._ck(self.L.cm_col_write(C.c_uint64(h), C.c_uint64(offset), _p(arr), C.c_uint64(arr.size), C.c_uint64(0)))
+
+    def col_copy(self, dst, src, n):
+        self._ck(self.L.cm_col_copy(C.c_uint64(dst), C.c_uint64(src), C.c_uint64(n), C.c_uint64(0)))
+
     @staticmethod
     def _harr(hs):
         return (C.c_uint64 * len(hs))(*hs)
@@ -243,10 +255,101 @@ class Proof:
         self.L.cm_last_error(buf, C.c_size_t(512))
         return rc, buf.value.decode(errors="replace") if rc else ""
 
+    def transcript(self):
+        """cm_proof_transcript: the Fiat-Shamir steps of this proof (list of {"op", "digest", "n_words", "words"}); empty
+        unless set_transcript_log(True) was in force when it was made."""
+        import json
+        p = C.c_char_p()
+        n = C.c_size_t(0)
+        rc = self.L.cm_proof_transcript(self.h, C.byref(p), C.byref(n))
+        if rc:
+            raise _lib_error(self.L, rc)
+        return json.loads(C.string_at(p, n.value).decode())
+
     def free(self):
         if self.h:
             self.L.cm_proof_free(self.h)
             self.h = None
+
+
+def set_framing(spec, lib=None):
+    """cm_set_framing (process-wide; host code, works without a GPU): named switches for the Stwo-side conventions no
+    reference vector settles — include/cairom_hip.h.  "" restores the defaults."""
+    L = lib or load_library()
+    rc = L.cm_set_framing((spec or "").encode())
+    if rc:
+        raise _lib_error(L, rc)
+
+
+def get_framing(lib=None):
+    L = lib or load_library()
+    buf = C.create_string_buffer(256)
+    L.cm_get_framing(buf, C.c_size_t(256))
+    return buf.value.decode()
+
+
+def set_transcript_log(on, lib=None):
+    (lib or load_library()).cm_set_transcript_log(C.c_int32(1 if on else 0))
+
+
+class ArrayInput:
+    """A ProverInput given as explicit arrays (hand-built inputs such as crates/prover/tests/prover.rs:33-112, or the `input`
+    object of a tests/golden/ref_*.json file): the same `.view` / `.steps` / `.free()` surface as HostInput.
+    arrays: dict with regs[4], roots[2], ranges[6], bundles<k> (n x 12), data_accesses (n x 4), initial_memory / final_memory
+    (n x 7: address, v0..v3, clock, multiplicity — IN THE ROW ORDER the memory component must use), clock_updates (n x 6),
+    initial_tree / final_tree (n x 8) — the layout prover_input_arrays() returns."""
+
+    def __init__(self, arrays):
+        self._keep = []
+        v = ProverInputView()
+
+        def arr(name, words):
+            a = np.ascontiguousarray(np.array(arrays.get(name, []), dtype=np.uint32).reshape(-1, words))
+            self._keep.append(a)
+            return a
+
+        for i, x in enumerate(arrays.get("regs", [0, 0, 0, 0])):
+            v.regs[i] = int(x)
+        total = 0
+        for i in range(N_OPCODE_COMPONENTS):
+            a = arr(f"bundles{i}", 12)
+            v.bundles[i] = a.ctypes.data if a.shape[0] else None
+            v.n_bundles[i] = a.shape[0]
+            total += a.shape[0]
+        for name, words, fld in (("data_accesses", 4, "data_accesses"), ("initial_memory", 7, "initial_memory"),
+                                 ("final_memory", 7, "final_memory"), ("clock_updates", 6, "clock_updates"),
+                                 ("initial_tree", 8, "initial_tree"), ("final_tree", 8, "final_tree")):
+            a = arr(name, words)
+            setattr(v, fld, a.ctypes.data if a.shape[0] else None)
+            setattr(v, "n_" + fld, a.shape[0])
+        for i, x in enumerate(arrays.get("roots", [0, 0])):
+            v.roots[i] = int(x)
+        for i, x in enumerate(arrays.get("ranges", [0] * 6)):
+            v.ranges[i] = int(x)
+        self._v = v
+        self.steps = total
+
+    @property
+    def view(self):
+        return C.cast(C.pointer(self._v), C.c_void_p)
+
+    def free(self):
+        pass
+
+
+def partial_merkle_tree(cells, initial=True, ranges=(0, 0, 0, 0, 0, 0), lib=None):
+    """build_partial_merkle_tree (crates/prover/src/adapter/merkle.rs:183-295) over cells = [(address, v0, v1, v2, v3), ...]:
+    (nodes n x 8, root).  Host code."""
+    L = lib or load_library()
+    c = np.ascontiguousarray(np.array(cells, dtype=np.uint32).reshape(-1, 5))
+    cap = max(4096, 64 * c.shape[0] * 31)
+    out = np.zeros((cap, 8), dtype=np.uint32)
+    n, root = C.c_uint64(0), C.c_uint32(0)
+    rc = L.cm_adapter_partial_tree(_p(c), C.c_uint32(c.shape[0]), C.c_int32(1 if initial else 0), (C.c_uint32 * 6)(*ranges), _p(out),
+                                   C.c_uint64(cap), C.byref(n), C.byref(root))
+    if rc:
+        raise _lib_error(L, rc)
+    return out[:n.value].copy(), root.value
 
 
 def _cfg(cfg):
@@ -316,6 +419,24 @@ def prover_input_arrays(view_ptr):
     out["initial_tree"] = arr(v.initial_tree, v.n_initial_tree, 8)
     out["final_tree"] = arr(v.final_tree, v.n_final_tree, 8)
     return out
+
+
+class RunnerSegmentView(C.Structure):
+    """cm_runner_segment (read-only mirror)."""
+    _fields_ = [("trace", C.c_void_p), ("n_trace", C.c_uint64), ("memory_trace", C.c_void_p), ("n_memory_trace", C.c_uint64),
+                ("initial_memory", C.c_void_p), ("n_initial_memory", C.c_uint64), ("ranges", C.c_uint32 * 6)]
+
+
+def runner_segment_arrays(view_ptr):
+    """cm_runner_segment* -> {"trace": (n, 2) (pc, fp), "memory_trace": (n, 5), "initial_memory": (n, 4), "ranges": [6]} (copies)."""
+    v = C.cast(view_ptr, C.POINTER(RunnerSegmentView)).contents
+
+    def arr(ptr, n, words):
+        if not n:
+            return np.zeros((0, words), dtype=np.uint32)
+        return np.ctypeslib.as_array(C.cast(ptr, _u32p), shape=(int(n), words)).copy()
+    return {"trace": arr(v.trace, v.n_trace, 2), "memory_trace": arr(v.memory_trace, v.n_memory_trace, 5),
+            "initial_memory": arr(v.initial_memory, v.n_initial_memory, 4), "ranges": list(v.ranges)}
 
 
 class HostSegment:

@@ -55,6 +55,25 @@ int32_t cm_stream_sync(cm_stream_t s);
  * cm_get_cpu_affinity returns the mode in force. */
 int32_t cm_set_cpu_affinity(int32_t mode);
 int32_t cm_get_cpu_affinity(void);
+/* Framing switches for the Stwo-side conventions that no in-tree reference vector settles (Stwo @ ab57a1c is an empty
+ * submodule of the reference, .gitmodules:1-3; crates/prover/tests/prover.rs only asserts verify(..).is_ok()).  spec =
+ * comma-separated name=value pairs, "" / "default" = all defaults; process-wide; env CM_FRAMING gives the initial value:
+ *   mix_u64       = raw (default: one raw compression F(digest, [lo, hi, 0..]) — what SimdBackend::grind searches over,
+ *                   prover.rs:90 / verifier.rs:55-58)  |  u32s (Blake2s256(digest || lo || hi) = mix_u32s(&[lo, hi]))
+ *   hash_node     = raw (default: compression chain from the zero state, t = f = 0)  |  rfc (RFC 7693 Blake2s-256 of
+ *                   left || right || le32(values))                       — Blake2sMerkleHasher::hash_node / commit_on_layer
+ *   sample_batch  = insertion (default)  |  sorted (by point)           — ColumnSampleBatch::new_vec
+ *   pcs_mix       = bql (default: pow_bits, log_blowup, n_queries, log_last_layer)  |  blq   — PcsConfig::mix_into, prover.rs:36
+ * A reference-produced transcript (integration/prover-hip/tests/golden_dump.rs -> tests/golden/ref_*.json, compared step by
+ * step by tests/test_ref_golden.py) tells which value is right; prover and verifier must run under the same setting.
+ * cm_get_framing writes the setting in force ("mix_u64=raw,hash_node=raw,...") and returns its length. */
+int32_t cm_set_framing(const char* spec);
+int32_t cm_get_framing(char* buf, size_t buf_len);
+/* Transcript log: on = every proof records one entry per Fiat-Shamir call the reference prover makes (Stwo Channel::{mix_u32s,
+ * mix_felts, mix_u64, draw_felt, draw_felts, draw_random_bytes} + MerkleChannel::mix_root, in the order of prover.rs:36-131)
+ * with the channel digest after the call.  cm_proof_transcript returns them as JSON (buffer owned by the proof):
+ * [{"op": "mix_u64", "digest": "<64 hex>", "n_words": 2, "words": [first <= 16 words mixed / drawn]}, ...]. */
+int32_t cm_set_transcript_log(int32_t on);
 
 /* ---- Column<T> / ColumnOps (Stwo core::backend::{Column, ColumnOps}; used through
  *      `ComponentTrace::to_evals`, crates/prover/src/components/mod.rs:168-177) ----------------- */
@@ -62,6 +81,10 @@ int32_t cm_col_alloc(uint64_t n_u32, cm_handle* out);
 int32_t cm_col_free(cm_handle h);
 int32_t cm_col_h2d(cm_handle h, const uint32_t* src, uint64_t n_u32, cm_stream_t s);
 int32_t cm_col_d2h(cm_handle h, uint32_t* dst, uint64_t n_u32, cm_stream_t s);
+/* Column::at / Column::set (element ranges, offsets in u32 words) and Column::clone (device to device) */
+int32_t cm_col_read(cm_handle h, uint64_t offset_u32, uint32_t* dst, uint64_t n_u32, cm_stream_t s);
+int32_t cm_col_write(cm_handle h, uint64_t offset_u32, const uint32_t* src, uint64_t n_u32, cm_stream_t s);
+int32_t cm_col_copy(cm_handle dst, cm_handle src, uint64_t n_u32, cm_stream_t s);
 /* ColumnOps::bit_reverse_column, in place, on n_cols columns of 2^log_n */
 int32_t cm_bit_reverse(const cm_handle* cols, uint32_t n_cols, uint32_t log_n, cm_stream_t s);
 
@@ -277,6 +300,7 @@ int32_t cm_proof_words(const cm_proof* p, const uint32_t** words_out, uint64_t* 
 /* JSON text of the proof; *len_out = length without the terminating NUL; the buffer is owned by
  * the proof object. */
 int32_t cm_proof_json(const cm_proof* p, const char** json_out, size_t* len_out);
+int32_t cm_proof_transcript(const cm_proof* p, const char** json_out, size_t* len_out);
 /* The four commitment roots (trees 0..3), 32 bytes each. */
 int32_t cm_proof_commitments(const cm_proof* p, uint8_t roots[4][32]);
 /* ---- device-side adapter -----------------------------------------------------------------

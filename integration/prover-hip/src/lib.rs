@@ -7,28 +7,28 @@
 //! The two data-layout contracts it relies on are tested on the C side: the proof JSON has exactly the serde shape of
 //! `Proof<H>` (tests/test_proof_json.py, schema extracted from this reference's structs) and `cm_prover_input` is what the
 //! HIP prover is tested against (tests/test_gpu_prove.py).
+pub mod backend;
 pub mod ffi;
+pub mod flat;
 
 use std::ffi::CStr;
 use std::sync::Once;
 
 use cairo_m_prover::Proof;
-use cairo_m_prover::adapter::{ExecutionBundle, ProverInput};
+use cairo_m_prover::adapter::ProverInput;
 use cairo_m_prover::errors::{ProvingError, VerificationError};
 use cairo_m_prover::prover_config::REGULAR_96_BITS;
-use num_traits::Zero;
-use stwo_prover::core::fields::m31::M31;
-use stwo_prover::core::fields::qm31::QM31;
 use stwo_prover::core::pcs::PcsConfig;
 use stwo_prover::core::prover::{ProvingError as StwoProvingError, VerificationError as StwoVerificationError};
 use stwo_prover::core::vcs::blake2_merkle::Blake2sMerkleHasher;
 
 use ffi::*;
+use flat::{Flat, MemoryOrder};
 
 /// Opcode groups of `define_opcodes!` (crates/prover/src/components/opcodes/mod.rs:223-268), in macro order: component k
 /// of the HIP library = group k; inside a group the bundles of the listed opcodes are concatenated in this order, exactly
 /// as `opcodes::Claim::write_trace` does (opcodes/mod.rs:51-58).
-const OPCODE_GROUPS: [&[u32]; CM_N_OPCODE_COMPONENTS] = {
+pub(crate) const OPCODE_GROUPS: [&[u32]; CM_N_OPCODE_COMPONENTS] = {
     use cairo_m_common::instruction::*;
     [
         &[ASSERT_EQ_FP_IMM],
@@ -60,7 +60,7 @@ const OPCODE_GROUPS: [&[u32]; CM_N_OPCODE_COMPONENTS] = {
     ]
 };
 
-fn last_error() -> String {
+pub(crate) fn last_error() -> String {
     let mut buf = vec![0i8; 2048];
     unsafe {
         cm_last_error(buf.as_mut_ptr(), buf.len());
@@ -69,7 +69,7 @@ fn last_error() -> String {
 }
 
 /// Selects the GPU once per process (one process per GPU; `CAIROM_HIP_DEVICE` or LOCAL_RANK picks the device).
-fn ensure_init() {
+pub(crate) fn ensure_init() {
     static INIT: Once = Once::new();
     INIT.call_once(|| {
         let dev = std::env::var("CAIROM_HIP_DEVICE")
@@ -82,131 +82,12 @@ fn ensure_init() {
     });
 }
 
-fn bundle(b: &ExecutionBundle) -> cm_bundle {
-    // what `Pack::pack` reads (crates/prover/src/utils/execution_bundle.rs:29-75)
-    let words = b.instruction.instruction.to_smallvec();
-    let mut inst = [0u32; 6];
-    for (k, w) in words.iter().enumerate() {
-        inst[k] = w.0;
-    }
-    cm_bundle {
-        pc: b.registers.pc.0,
-        fp: b.registers.fp.0,
-        clock: b.clock.0,
-        inst_prev_clock: b.instruction.prev_clock.0,
-        inst,
-        span_start: b.access_span.start,
-        span_len: b.access_span.len as u32,
-    }
-}
-
-fn cell(addr: &M31, (value, clock, mult): &(QM31, M31, M31)) -> cm_memory_cell {
-    let v = value.to_m31_array();
-    cm_memory_cell { address: addr.0, value: [v[0].0, v[1].0, v[2].0, v[3].0], clock: clock.0, multiplicity: mult.0 }
-}
-
 fn pcs(c: &PcsConfig) -> cm_pcs_config {
     cm_pcs_config {
         pow_bits: c.pow_bits,
         log_blowup_factor: c.fri_config.log_blowup_factor,
         log_last_layer_degree_bound: c.fri_config.log_last_layer_degree_bound,
         n_queries: c.fri_config.n_queries as u32,
-    }
-}
-
-/// Owned flattening of a `ProverInput`; `view()` borrows it as the C struct.
-struct Flat {
-    bundles: Vec<Vec<cm_bundle>>,
-    data_accesses: Vec<cm_data_access>,
-    initial_memory: Vec<cm_memory_cell>,
-    final_memory: Vec<cm_memory_cell>,
-    clock_updates: Vec<cm_clock_update>,
-    initial_tree: Vec<cm_merkle_node>,
-    final_tree: Vec<cm_merkle_node>,
-    regs: [u32; 4],
-    roots: [u32; 2],
-    ranges: [[u32; 2]; 3],
-}
-
-impl Flat {
-    /// Consumes the bundles like `prove_cairo_m` does (opcodes/mod.rs:53-58 drains `states_by_opcodes`).
-    fn new(input: &mut ProverInput) -> Self {
-        let ins = &mut input.instructions;
-        let bundles = OPCODE_GROUPS
-            .iter()
-            .map(|group| {
-                let mut v = Vec::new();
-                for opcode in group.iter() {
-                    if let Some(states) = ins.states_by_opcodes.get_mut(opcode) {
-                        v.extend(states.drain(..).map(|b| bundle(&b)));
-                    }
-                }
-                v
-            })
-            .collect();
-        let data_accesses = ins
-            .data_accesses
-            .iter()
-            .map(|a| cm_data_access { address: a.address.0, prev_clock: a.prev_clock.0, prev_value: a.prev_value.0, value: a.value.0 })
-            .collect();
-        // Row order of the memory component: the reference iterates its HashMaps (memory.rs:104-133), i.e. an unspecified
-        // order; the library commits the rows in the order given here.  Ascending addresses make the proof reproducible.
-        let mut init: Vec<_> = input.memory.initial_memory.iter().collect();
-        init.sort_by_key(|(a, _)| a.0);
-        let mut fin: Vec<_> = input.memory.final_memory.iter().collect();
-        fin.sort_by_key(|(a, _)| a.0);
-        let node = |n: &cairo_m_prover::adapter::merkle::NodeData| {
-            let a = n.to_m31_array();
-            cm_merkle_node {
-                index: a[0].0, depth: a[1].0, left_value: a[2].0, right_value: a[3].0, parent_value: a[4].0,
-                left_mult: a[5].0, right_mult: a[6].0, parent_mult: a[7].0,
-            }
-        };
-        let r = &input.public_address_ranges;
-        Flat {
-            bundles,
-            data_accesses,
-            initial_memory: init.into_iter().map(|(a, s)| cell(a, s)).collect(),
-            final_memory: fin.into_iter().map(|(a, s)| cell(a, s)).collect(),
-            clock_updates: input
-                .memory
-                .clock_update_data
-                .iter()
-                .map(|(addr, prev_clk, value)| {
-                    let v = value.to_m31_array();
-                    cm_clock_update { address: addr.0, prev_clock: prev_clk.0, value: [v[0].0, v[1].0, v[2].0, v[3].0] }
-                })
-                .collect(),
-            initial_tree: input.merkle_trees.initial_tree.iter().map(node).collect(),
-            final_tree: input.merkle_trees.final_tree.iter().map(node).collect(),
-            regs: [ins.initial_registers.pc.0, ins.initial_registers.fp.0, ins.final_registers.pc.0, ins.final_registers.fp.0],
-            roots: [
-                input.merkle_trees.initial_root.unwrap_or_else(M31::zero).0,
-                input.merkle_trees.final_root.unwrap_or_else(M31::zero).0,
-            ],
-            ranges: [[r.program.start, r.program.end], [r.input.start, r.input.end], [r.output.start, r.output.end]],
-        }
-    }
-
-    fn view(&self) -> cm_prover_input {
-        let mut bundles = [std::ptr::null(); CM_N_OPCODE_COMPONENTS];
-        let mut n_bundles = [0u64; CM_N_OPCODE_COMPONENTS];
-        for (k, v) in self.bundles.iter().enumerate() {
-            bundles[k] = v.as_ptr();
-            n_bundles[k] = v.len() as u64;
-        }
-        cm_prover_input {
-            initial_pc: self.regs[0], initial_fp: self.regs[1], final_pc: self.regs[2], final_fp: self.regs[3],
-            bundles, n_bundles,
-            data_accesses: self.data_accesses.as_ptr(), n_data_accesses: self.data_accesses.len() as u64,
-            initial_memory: self.initial_memory.as_ptr(), n_initial_memory: self.initial_memory.len() as u64,
-            final_memory: self.final_memory.as_ptr(), n_final_memory: self.final_memory.len() as u64,
-            clock_updates: self.clock_updates.as_ptr(), n_clock_updates: self.clock_updates.len() as u64,
-            initial_tree: self.initial_tree.as_ptr(), n_initial_tree: self.initial_tree.len() as u64,
-            final_tree: self.final_tree.as_ptr(), n_final_tree: self.final_tree.len() as u64,
-            initial_root: self.roots[0], final_root: self.roots[1],
-            program_range: self.ranges[0], input_range: self.ranges[1], output_range: self.ranges[2],
-        }
     }
 }
 
@@ -224,7 +105,8 @@ impl Drop for ProofHandle {
 pub fn prove_cairo_m_hip(input: &mut ProverInput, pcs_config: Option<PcsConfig>) -> Result<Proof<Blake2sMerkleHasher>, ProvingError> {
     ensure_init();
     let cfg = pcs(&pcs_config.unwrap_or(REGULAR_96_BITS));
-    let flat = Flat::new(input);
+    // ascending addresses: the reference iterates a HashMap here (components/memory.rs:105-109), i.e. an unspecified order
+    let flat = Flat::new(input, MemoryOrder::AscendingAddress);
     let view = flat.view();
     let mut out: *mut cm_proof = std::ptr::null_mut();
     let rc = unsafe { cm_prove_segment(&view, &cfg, &mut out) };

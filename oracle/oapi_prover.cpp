@@ -11,7 +11,30 @@ const char* orc_last_error() { return g_err.c_str(); }
 struct orc_proof_handle {
   std::vector<uint32_t> words;
   uint64_t cells;
+  std::string transcript_json;
 };
+// same JSON as the product's cm_proof_transcript: [{"op", "digest" (hex, after the call), "n_words", "words"}, ...]
+static std::string transcript_json(const TranscriptLog& log) {
+  std::string out = "[";
+  char buf[64];
+  for (size_t i = 0; i < log.size(); i++) {
+    const TranscriptEntry& e = log[i];
+    out += i ? ",\n {\"op\": \"" : "{\"op\": \"";
+    out += e.op;
+    out += "\", \"digest\": \"";
+    for (int k = 0; k < 32; k++) { snprintf(buf, sizeof(buf), "%02x", e.digest[k]); out += buf; }
+    snprintf(buf, sizeof(buf), "\", \"n_words\": %u, \"words\": [", e.n_words);
+    out += buf;
+    for (size_t k = 0; k < e.words.size(); k++) { snprintf(buf, sizeof(buf), k ? ", %u" : "%u", e.words[k]); out += buf; }
+    out += "]}";
+  }
+  return out + "]";
+}
+int orc_set_framing(const char* spec) {
+  std::string e = set_framing(spec ? spec : "");
+  if (!e.empty()) { g_err = e; return 1; }
+  return 0;
+}
 // cfg = {pow_bits, log_blowup, log_last_layer, n_queries} or NULL
 int orc_prove(const cm_prover_input* in, const uint32_t* cfg, orc_proof_handle** out) {
   try {
@@ -21,6 +44,7 @@ int orc_prove(const cm_prover_input* in, const uint32_t* cfg, orc_proof_handle**
     orc_proof_handle* h = new orc_proof_handle();
     h->words = serialize(po.proof);
     h->cells = po.cells;
+    h->transcript_json = transcript_json(po.transcript);
     *out = h;
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
@@ -28,6 +52,7 @@ int orc_prove(const cm_prover_input* in, const uint32_t* cfg, orc_proof_handle**
 uint64_t orc_proof_n_words(const orc_proof_handle* h) { return h->words.size(); }
 void orc_proof_words(const orc_proof_handle* h, uint32_t* dst) { memcpy(dst, h->words.data(), h->words.size() * 4); }
 uint64_t orc_proof_cells(const orc_proof_handle* h) { return h->cells; }
+const char* orc_proof_transcript(const orc_proof_handle* h) { return h->transcript_json.c_str(); }
 void orc_proof_free(orc_proof_handle* h) { delete h; }
 
 // cfg: {pow_bits, log_blowup, log_last_layer, n_queries} the VERIFIER expects; NULL = REGULAR_96_BITS

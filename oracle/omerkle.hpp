@@ -9,6 +9,7 @@
 #pragma once
 #include "oblake2s.hpp"
 #include "ofield.hpp"
+#include "oframing.hpp"
 #include <map>
 #include <string>
 #include <algorithm>
@@ -16,6 +17,12 @@
 namespace orc {
 
 inline Hash32 hash_node(const Hash32* left, const Hash32* right, const uint32_t* vals, size_t nvals) {
+  if (framing().hash_node_rfc) {   // "candidate B" (framing switch hash_node=rfc): RFC 7693 Blake2s-256 of left || right || le32(values)
+    std::vector<uint8_t> buf((left ? 64 : 0) + 4 * nvals);
+    if (left) { memcpy(buf.data(), left->data(), 32); memcpy(buf.data() + 32, right->data(), 32); }
+    if (nvals) memcpy(buf.data() + (left ? 64 : 0), vals, 4 * nvals);
+    return blake2s256(buf);
+  }
   uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (left) {
     uint32_t m[16];

@@ -324,6 +324,14 @@ struct SampleBatch {
   std::vector<std::pair<size_t, QM31>> cols;  // (column index within the size group, value)
 };
 inline bool same_point(const PointQ& a, const PointQ& b) { return a.x == b.x && a.y == b.y; }
+// derived Ord of CirclePoint<SecureField>: x then y, each QM31 as its words (a, b, c, d) — framing switch sample_batch=sorted
+inline bool point_less(const PointQ& a, const PointQ& b) {
+  uint32_t wa[8], wb[8];
+  a.x.to_u32(wa); a.y.to_u32(wa + 4);
+  b.x.to_u32(wb); b.y.to_u32(wb + 4);
+  for (int i = 0; i < 8; i++) if (wa[i] != wb[i]) return wa[i] < wb[i];
+  return false;
+}
 
 // columns: LDE columns of one size (log), samples[c] = list of (point, value)
 inline std::vector<Col> accumulate_quotients(uint32_t log, const std::vector<const Col*>& columns,
@@ -336,6 +344,7 @@ inline std::vector<Col> accumulate_quotients(uint32_t log, const std::vector<con
       if (b == batches.size()) batches.push_back(SampleBatch{s.first, {}});
       batches[b].cols.push_back({c, s.second});
     }
+  if (framing().sample_batch_sorted) std::stable_sort(batches.begin(), batches.end(), [](const SampleBatch& a, const SampleBatch& b) { return point_less(a.point, b.point); });
   // line coefficients (column_line_coeffs) and per-batch random coefficient powers
   struct LC { QM31 a, b, c; };
   std::vector<std::vector<LC>> lcs(batches.size());
@@ -457,6 +466,7 @@ struct ProveOutput {
   uint64_t cells = 0;
   std::vector<ComponentTrace> traces;  // kept for tests (trace-domain columns)
   Relations relations;
+  TranscriptLog transcript;            // every Fiat-Shamir step (ochannel.hpp)
 };
 
 // optional phase timing to stderr (ORC_TIMING=1) — used to find the oracle's own slow spots
@@ -476,12 +486,13 @@ inline ProveOutput prove_segment(const cm_prover_input& in, const PcsConfig& cfg
   Proof& pf = out.proof;
   pf.config = cfg;
   Channel ch;
+  ch.log.p = &out.transcript;
   OrcTick tick;
-  // PcsConfig::mix_into
+  // PcsConfig::mix_into (order inside FriConfig::mix_into: framing switch pcs_mix)
   ch.mix_u64(cfg.pow_bits);
   ch.mix_u64(cfg.log_blowup);
-  ch.mix_u64(cfg.n_queries);
-  ch.mix_u64(cfg.log_last_layer);
+  if (framing().pcs_mix_blq) { ch.mix_u64(cfg.log_last_layer); ch.mix_u64(cfg.n_queries); }
+  else { ch.mix_u64(cfg.n_queries); ch.mix_u64(cfg.log_last_layer); }
   PcsProver pcs;
   pcs.cfg = cfg;
   pf.public_data = make_public_data(in);

@@ -21,6 +21,7 @@ struct RowQuotient {
         if (b == batches.size()) batches.push_back(SampleBatch{s.first, {}});
         batches[b].cols.push_back({c, s.second});
       }
+    if (framing().sample_batch_sorted) std::stable_sort(batches.begin(), batches.end(), [](const SampleBatch& a, const SampleBatch& b) { return point_less(a.point, b.point); });
     lcs.resize(batches.size());
     batch_coeff.resize(batches.size());
     for (size_t b = 0; b < batches.size(); b++) {
@@ -85,8 +86,8 @@ inline std::string verify_proof(const Proof& pf, const PcsConfig& expected = Pcs
   Channel ch;
   ch.mix_u64(cfg.pow_bits);
   ch.mix_u64(cfg.log_blowup);
-  ch.mix_u64(cfg.n_queries);
-  ch.mix_u64(cfg.log_last_layer);
+  if (framing().pcs_mix_blq) { ch.mix_u64(cfg.log_last_layer); ch.mix_u64(cfg.n_queries); }
+  else { ch.mix_u64(cfg.n_queries); ch.mix_u64(cfg.log_last_layer); }
   mix_public_data(pf.public_data, ch);
   // column log sizes per tree
   std::vector<std::vector<uint32_t>> logs(4);

@@ -99,8 +99,8 @@ def _attach_prover(cls):
     def err(self):
         return self.L.orc_last_error().decode(errors="replace")
 
-    def prove(self, view, cfg=(16, 1, 0, 80)):
-        """CPU restatement of prove_cairo_m; returns (words, cells)."""
+    def prove(self, view, cfg=(16, 1, 0, 80), transcript=False):
+        """CPU restatement of prove_cairo_m; returns (words, cells) — or (words, cells, transcript entries)."""
         setup(self)
         h = C.c_void_p()
         rc = self.L.orc_prove(view, (C.c_uint32 * 4)(*cfg), C.byref(h))
@@ -110,8 +110,19 @@ def _attach_prover(cls):
         w = np.zeros(n, dtype=np.uint32)
         self.L.orc_proof_words(h, _p(w))
         cells = self.L.orc_proof_cells(h)
+        tr = None
+        if transcript:
+            import json
+            self.L.orc_proof_transcript.restype = C.c_char_p
+            tr = json.loads(self.L.orc_proof_transcript(h).decode())
         self.L.orc_proof_free(h)
-        return w, cells
+        return (w, cells, tr) if transcript else (w, cells)
+
+    def set_framing(self, spec):
+        """orc_set_framing: the oracle's copy of the named framing switches (oracle/oframing.hpp)."""
+        setup(self)
+        if self.L.orc_set_framing((spec or "").encode()):
+            raise RuntimeError(err(self))
 
     def verify(self, words, cfg=None):
         """cfg = the PcsConfig the VERIFIER expects (None = REGULAR_96_BITS), like verify_cairo_m's second argument."""
@@ -192,7 +203,7 @@ def _attach_prover(cls):
         self.L.orc_poseidon2_permute(_p(s))
         return s
 
-    cls.prove, cls.verify, cls.assert_constraints = prove, verify, assert_constraints
+    cls.prove, cls.verify, cls.assert_constraints, cls.set_framing = prove, verify, assert_constraints, set_framing
     cls.component_trace, cls.poseidon2_permute = component_trace, poseidon2_permute
     cls.component_interaction, cls.component_constraints, cls.fri_decompose = component_interaction, component_constraints, fri_decompose
     cls.fold_circle_into_line, cls.fold_line, cls.accumulate_quotients = fold_circle_into_line, fold_line, accumulate_quotients

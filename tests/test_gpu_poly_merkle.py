@@ -148,3 +148,19 @@ def test_grind_parity(backend, oracle):
     for bits in (2, 8, 16):
         digest = bytes(rng.integers(0, 256, size=32, dtype=np.uint8))
         assert backend.grind(digest, bits) == oracle.grind(digest, bits)
+
+
+def test_column_element_access_and_copy(backend):
+    """Column::at / Column::set / Column::clone of a Rust-side backend (integration/prover-hip/src/backend.rs): cm_col_read,
+    cm_col_write, cm_col_copy."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 2**31 - 1, size=1000, dtype=np.uint32)
+    h = backend.upload(a)
+    assert backend.col_read(h, 17, 5).tolist() == a[17:22].tolist()
+    backend.col_write(h, 998, np.array([7, 9], dtype=np.uint32))
+    a[998:] = [7, 9]
+    g = backend.col_alloc(1000)
+    backend.col_copy(g, h, 1000)
+    assert np.array_equal(backend.download(g, 1000), a)
+    backend.col_free(h)
+    backend.col_free(g)

@@ -39,7 +39,8 @@ def c_structs():
 
 def test_repr_c_structs_match_the_header():
     rs, cs = rust_structs(), c_structs()
-    for name in ("cm_bundle", "cm_data_access", "cm_memory_cell", "cm_clock_update", "cm_merkle_node", "cm_prover_input", "cm_pcs_config"):
+    for name in ("cm_bundle", "cm_data_access", "cm_memory_cell", "cm_clock_update", "cm_merkle_node", "cm_prover_input", "cm_pcs_config",
+                 "cm_sample_batches", "cm_runner_segment"):
         assert name in rs and name in cs, name
         assert [f[0] for f in rs[name]] == [f[0] for f in cs[name]], name
         for (rn, rt), (cn, ct, arr) in zip(rs[name], cs[name]):
@@ -53,16 +54,32 @@ def test_repr_c_structs_match_the_header():
                 assert rt.endswith(f";{n}]"), (name, rn, rt, arr)
 
 
-def test_extern_functions_are_exported():
+def header_functions():
+    """name -> argument count of every function include/cairom_hip.h declares"""
+    hdr = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
+    hdr = re.sub(r"typedef struct [^{;]*\{.*?\}\s*\w+;", "", hdr, flags=re.S)
+    out = {}
+    for m in re.finditer(r"^\s*(?:const )?\w+\*?\s+(cm_\w+)\((.*?)\);", hdr, flags=re.S | re.M):
+        args = " ".join(m.group(2).split())
+        out[m.group(1)] = 0 if args in ("", "void") else len(re.split(r",(?![^\[]*\])", args))
+    return out
+
+
+def test_every_header_function_has_an_extern_twin_and_is_exported():
+    """ffi.rs covers the WHOLE C ABI (the HipBackend trait impls of src/backend.rs bind the per-op entry points):
+    every function of the header is declared in the extern block with the same number of arguments and is exported by the
+    library; the extern block declares nothing the header does not."""
     L = C.CDLL(os.path.join(ROOT, "cairo_m_amd", "libcairom_hip.so"))
     block = FFI[FFI.index('unsafe extern "C"'):]
-    fns = re.findall(r"pub fn (\w+)\((.*?)\) -> i32;", block, re.S)
-    assert len(fns) >= 6
-    hdr = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
-    for name, args in fns:
+    fns = {name: args for name, args in re.findall(r"pub fn (\w+)\((.*?)\) -> [^;]+;", block, re.S)}
+    hdr = header_functions()
+    assert len(hdr) > 70
+    assert sorted(set(hdr) - set(fns)) == [], "header functions without an extern twin in ffi.rs"
+    assert sorted(set(fns) - set(hdr)) == [], "extern declarations the header does not have"
+    for name, n_args in hdr.items():
         getattr(L, name)
-        proto = re.search(r"int32_t " + name + r"\((.*?)\);", hdr, re.S).group(1)
-        assert len([a for a in args.split(",") if a.strip()]) == len([a for a in proto.split(",") if a.strip()]), name
+        got = len([a for a in fns[name].split(",") if a.strip()])
+        assert got == n_args, (name, got, n_args)
 
 
 def test_opcode_groups_equal_the_component_table():

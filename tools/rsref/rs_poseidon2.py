@@ -160,13 +160,23 @@ def main():
     nodes = np.concatenate([a["initial_tree"], a["final_tree"]])
     inputs = np.zeros((nodes.shape[0], T), dtype=np.int64)
     inputs[:, 0], inputs[:, 1] = nodes[:, 2], nodes[:, 3]            # (left_value, right_value, 0 x 14): merkle.rs:127-133
-    inputs = inputs[:200]                                             # 200 live rows + 56 padding rows are plenty (443 columns each)
+    all_inputs = inputs
+    inputs = inputs[:200]                                             # 200 live rows + 56 padding rows kept cell by cell (443 columns each)
     cells = witness_cells(src, interp, g, inputs)
+    # FULL LENGTH: every node of both trees (all live rows + all padding rows of the 2^log-row trace) through the same
+    # interpreted closure; the fixture keeps one Blake2s-256 digest per column (443 x 32 bytes) instead of ~1.8 M cells
+    import hashlib
+    full = witness_cells(src, interp, g, all_inputs)
+    digests = np.stack([np.frombuffer(hashlib.blake2s(np.ascontiguousarray(full[c]).tobytes()).digest(), dtype=np.uint8)
+                        for c in range(full.shape[0])])
+    assert np.array_equal(full[:, :192], cells[:, :192])
     inp.free()
     wp = os.path.join(ROOT, "tests", "golden", "air_witness_vectors.npz")
     old = dict(np.load(wp))
     old["poseidon2"] = cells
     old["poseidon2_inputs"] = inputs.astype(np.uint32)
+    old["poseidon2_full_digests"] = digests                          # blake2s(column c as little-endian u32), full-length trace
+    old["poseidon2_full_shape"] = np.array([full.shape[0], full.shape[1], all_inputs.shape[0]])
     np.savez_compressed(wp, **old)
     print("poseidon2 witness", cells.shape, os.path.getsize(wp), "bytes")
 
