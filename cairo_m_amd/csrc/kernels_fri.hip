@@ -116,6 +116,115 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
   }
 }
 
+// Large domains, R rows per thread (rows blk * 256 R + k * 256 + tid: every k is one coalesced wave access) and at most two
+// sample batches (a size group has the OODS point and, for the LogUp cumulative-sum columns, the previous point):
+// the R * n_batches CM31 denominators of a thread are inverted with ONE field inversion (Montgomery's trick: prefix
+// products, one inverse, back-substitution) instead of one 37-multiplication exponentiation each — in the one-row kernel the
+// inversions were ~40 % of the VALU work of a row.  Same field elements, so the output is bit-identical.
+template <int R>
+__global__ void __launch_bounds__(256) k_quotients_rows(QuotientArgs a) {
+  const uint32_t rbase = blockIdx.x * (256u * R) + threadIdx.x;     // n is a multiple of 256 R (the launcher checks)
+  const uint32_t nb = a.n_batches;                                   // 1 or 2
+  M31 py[R];
+  CM31 dinv[2][R];
+  {
+    CM31 den[2][R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      M31 px;
+      domain_point_at_row(a.tw, a.log_size, a.row0 + rbase + 256u * k, px, py[k]);
+#pragma unroll
+      for (uint32_t b = 0; b < 2; b++) {
+        if (b < nb) {
+          const QuotientBatch& qb = a.batches[b];
+          // (Pr.x - p.x) * Pi.y - (Pr.y - p.y) * Pi.x in CM31
+          CM31 prx(M31(qb.point[0]), M31(qb.point[1])), pix(M31(qb.point[2]), M31(qb.point[3]));
+          CM31 pry(M31(qb.point[4]), M31(qb.point[5])), piy(M31(qb.point[6]), M31(qb.point[7]));
+          den[b][k] = (prx - CM31(px)) * piy - (pry - CM31(py[k])) * pix;
+        } else {
+          den[b][k] = CM31(M31(1));
+        }
+      }
+    }
+    // batch inverse over den[0][0..R), then den[1][0..R) when there are two batches
+    constexpr int N = 2 * R;
+    CM31 pre[N];   // pre[i] = d_0 * ... * d_i  (d_i = den[i / R][i % R])
+    pre[0] = den[0][0];
+#pragma unroll
+    for (int i = 1; i < N; i++) pre[i] = (i < R || nb == 2) ? pre[i - 1] * den[i / R][i % R] : pre[i - 1];
+    CM31 run = inv(pre[N - 1]);
+#pragma unroll
+    for (int i = N - 1; i >= 1; i--) {
+      if (i < R || nb == 2) {
+        dinv[i / R][i % R] = run * pre[i - 1];
+        run = run * den[i / R][i % R];
+      } else {
+        dinv[i / R][i % R] = CM31(M31(1));
+      }
+    }
+    dinv[0][0] = run;
+  }
+  QM31 acc[R];
+  for (uint32_t b = 0; b < nb; b++) {
+    const QuotientBatch& qb = a.batches[b];
+    unsigned long long q[R][4];
+#pragma unroll
+    for (int k = 0; k < R; k++) { q[k][0] = 0; q[k][1] = 0; q[k][2] = 0; q[k][3] = 0; }
+    uint32_t e = qb.begin;
+    constexpr int CH = 16 / R;     // columns per step: 16 loads in flight per lane
+    for (; e + CH <= qb.end; e += CH) {
+      uint32_t v[CH][R];
+#pragma unroll
+      for (int j = 0; j < CH; j++) {
+        const cm_gptr col = CM_GCOL(a.entry_cols[e + j]);
+#pragma unroll
+        for (int k = 0; k < R; k++) v[j][k] = col[rbase + 256u * k];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; j++) {
+        const uint32_t* c = a.coef_c + 4 * (e + j);
+        const unsigned long long c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const unsigned long long x = v[j][k];
+          q[k][0] += x * c0; q[k][1] += x * c1; q[k][2] += x * c2; q[k][3] += x * c3;
+        }
+        if ((j & 3) == 3) {   // four raw products per coordinate fit a u64 next to the lazily folded rest
+#pragma unroll
+          for (int k = 0; k < R; k++) { q[k][0] = m31_fold_lazy(q[k][0]); q[k][1] = m31_fold_lazy(q[k][1]); q[k][2] = m31_fold_lazy(q[k][2]); q[k][3] = m31_fold_lazy(q[k][3]); }
+        }
+      }
+      if (CH & 3) {
+#pragma unroll
+        for (int k = 0; k < R; k++) { q[k][0] = m31_fold_lazy(q[k][0]); q[k][1] = m31_fold_lazy(q[k][1]); q[k][2] = m31_fold_lazy(q[k][2]); q[k][3] = m31_fold_lazy(q[k][3]); }
+      }
+    }
+    for (; e < qb.end; e++) {
+      const cm_gptr col = CM_GCOL(a.entry_cols[e]);
+      const uint32_t* c = a.coef_c + 4 * e;
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const unsigned long long x = col[rbase + 256u * k];
+        q[k][0] = m31_fold_lazy(q[k][0] + x * c[0]); q[k][1] = m31_fold_lazy(q[k][1] + x * c[1]);
+        q[k][2] = m31_fold_lazy(q[k][2] + x * c[2]); q[k][3] = m31_fold_lazy(q[k][3] + x * c[3]);
+      }
+    }
+    const QM31 sum_a = QM31::from_u32(qb.sum_a), sum_b = QM31::from_u32(qb.sum_b), bc = QM31::from_u32(qb.batch_coeff);
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      QM31 num(M31::reduce(q[k][0]), M31::reduce(q[k][1]), M31::reduce(q[k][2]), M31::reduce(q[k][3]));
+      num = num - (sum_a * py[k] + sum_b);
+      const CM31 di = b == 0 ? dinv[0][k] : dinv[1][k];
+      acc[k] = acc[k] * bc + mul_cm31(num, di);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; k++) {
+    const uint32_t row = rbase + 256u * k;
+    a.out[0][row] = acc[k].a.a.v; a.out[1][row] = acc[k].a.b.v; a.out[2][row] = acc[k].b.a.v; a.out[3][row] = acc[k].b.b.v;
+  }
+}
+
 // compute_fri_quotients' per-sample coefficients on the device (one block per batch): entry k of a batch gets
 // alpha = coeff^(k+1); with v its sampled value and (Px, Py) the batch's point: a = conj(v) - v, c = conj(Py) - Py,
 // b = v c - a Py; coef_c = alpha c, sum_a = sum alpha a, sum_b = sum alpha b, batch_coeff = coeff^n.
@@ -301,7 +410,13 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
 void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st) {
   uint32_t n = a.n_rows ? a.n_rows : (1u << a.log_size);
   KProfScope kp("k_quotients", (4.0 * n_cols + 16.0) * (double)n, st);
-  if (a.log_size >= 14) hipLaunchKernelGGL(k_quotients<1>, dim3((n + 255) / 256), dim3(256), 0, st, a);
+  // two rows per thread with one shared denominator inversion (A/B: CM_QUOT_ROWS=1 restores the one-row kernel)
+  static const int rows = getenv("CM_QUOT_ROWS") ? atoi(getenv("CM_QUOT_ROWS")) : 2;
+  if (a.log_size >= 14 && rows == 2 && a.entry_cols && a.n_batches >= 1 && a.n_batches <= 2 && n % 512 == 0)
+    hipLaunchKernelGGL(k_quotients_rows<2>, dim3(n / 512), dim3(256), 0, st, a);
+  else if (a.log_size >= 14 && rows == 4 && a.entry_cols && a.n_batches >= 1 && a.n_batches <= 2 && n % 1024 == 0)
+    hipLaunchKernelGGL(k_quotients_rows<4>, dim3(n / 1024), dim3(256), 0, st, a);
+  else if (a.log_size >= 14) hipLaunchKernelGGL(k_quotients<1>, dim3((n + 255) / 256), dim3(256), 0, st, a);
   else if (a.log_size >= 10) hipLaunchKernelGGL(k_quotients<8>, dim3((n + 31) / 32), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_quotients<64>, dim3((n + 3) / 4), dim3(256), 0, st, a);
   CM_HIP(hipGetLastError());

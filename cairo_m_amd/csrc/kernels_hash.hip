@@ -9,6 +9,7 @@
 // pointers are wave-uniform (scalar loads).  Hash framing: state = 0; optional F(state, left||right);
 // then one F per 16 column words (zero padded); t = f = 0 (see DESIGN.md "Merkle node framing").
 #include <string.h>
+#include <algorithm>
 #include "field.hpp"
 #include "device_common.hpp"
 #include "engine.hpp"
@@ -172,6 +173,23 @@ void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* con
   // algorithmic bytes: column values once + 64 B of child hashes in, 32 B out per node
   KProfScope kp("k_merkle_layer", (4.0 * ncols + (d_prev ? 64.0 : 0.0) + 32.0) * (double)n, st,
                 /* Blake2s compressions */ (double)n * ((d_prev ? 1.0 : 0.0) + (double)((ncols + 15) / 16)));
+  // narrow layers (no columns or one SecureColumn): a wave walks several 64-node chunks with the next chunk's loads in flight
+  // (k_merkle_narrow).  Chunks per wave: as many as still leave >= 2 waves per wave slot of the chip (256 CUs x 32 slots).
+  // A/B: CM_MERKLE_NPW=0 restores k_merkle_layer for these layers, 1 / 2 / 4 / 8 force a chunk count.
+  static const int npw_env = getenv("CM_MERKLE_NPW") ? atoi(getenv("CM_MERKLE_NPW")) : -1;
+  if (npw_env != 0 && (ncols == 0 || ncols == 4) && (d_prev || ncols) && log_size >= 14) {
+    uint32_t npw = npw_env > 0 ? (uint32_t)npw_env : std::min(8u, std::max(1u, n >> 20));
+    while (npw > 1 && (n % (256u * npw)) != 0) npw >>= 1;
+    const dim3 grid(n / (256u * npw));
+    const bool rfc = framing().hash_node_rfc;
+#define CM_NARROW(R, P, C) hipLaunchKernelGGL((k_merkle_narrow<R, P, C>), grid, dim3(256), 0, st, d_prev, d_cols, d_out, npw)
+    if (d_prev && ncols) { if (rfc) CM_NARROW(true, true, 4); else CM_NARROW(false, true, 4); }
+    else if (d_prev) { if (rfc) CM_NARROW(true, true, 0); else CM_NARROW(false, true, 0); }
+    else { if (rfc) CM_NARROW(true, false, 4); else CM_NARROW(false, false, 4); }
+#undef CM_NARROW
+    CM_HIP(hipGetLastError());
+    return;
+  }
   if (framing().hash_node_rfc) hipLaunchKernelGGL(k_merkle_layer<true>, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
   else hipLaunchKernelGGL(k_merkle_layer<false>, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
   CM_HIP(hipGetLastError());

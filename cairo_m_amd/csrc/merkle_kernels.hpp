@@ -88,6 +88,88 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint32_t log_size, const u
   }
 }
 
+// ---- narrow layers: one or two compressions per node ---------------------------------------------------------------------
+// SecureColumn trees (the composition tree, every FRI layer) have 4 columns on their leaf layer and none below: a node is ONE
+// compression (children only, or 4 column words) or two (children + 4 words).  With one node per thread and one short-lived
+// wave per 64 nodes, k_merkle_layer runs those layers at ~33 G compressions/s against ~50 G/s on wide layers (rocprofv3
+// timeline, profiles/r03*): a wave lives ~16 us of which ~10 us is its share of the SIMD's VALU — the rest (wave launch, the
+// exposed load latency, four block barriers around the LDS staging) cannot be hidden by other waves because 8 per SIMD is the
+// occupancy limit.  Here a WAVE walks `npw` consecutive 64-node chunks: the coalesced loads of chunk c + 1 are in flight while
+// chunk c is compressed, and the children / result staging goes through a wave-private LDS window (in-order DS ops of one wave:
+// no block barrier at all).  NC = 0 (children only) or 4 (SecureColumn words); PREV = the layer has children.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool RFC, bool PREV, int NC>
+__global__ void __launch_bounds__(256) k_merkle_narrow(const uint32_t* __restrict__ prev, const uint32_t* const* __restrict__ cols,
+                                                       uint32_t* __restrict__ out, uint32_t npw) {
+  static_assert(NC == 0 || NC == 4, "narrow layers carry no columns or one SecureColumn");
+  static_assert(PREV || NC == 4, "a node hashes something");
+  __shared__ uint4 stage[4][256];           // per wave: 64 nodes x 64 B
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  uint4* st = stage[w];
+  const uint32_t node0 = (blockIdx.x * 4u + w) * 64u * npw;   // the wave's first node; chunk c = nodes [node0 + 64 c, + 64)
+  __builtin_assume(node0 < (1u << 29));
+  cm_gptr col[NC ? NC : 1];
+#pragma unroll
+  for (int k = 0; k < NC; k++) col[k] = CM_GCOL(cols[k]);
+  uint4 raw0, raw1, raw2, raw3;
+  uint32_t zc0 = 0, zc1 = 0, zc2 = 0, zc3 = 0;
+  // (plain scalars, no arrays / lambdas: an indexed `raw[j]` captured by reference went to scratch memory)
+#define CM_NARROW_ISSUE(nb_)                                                                   \
+  {                                                                                            \
+    if (PREV) {                                                                                \
+      const uint4* p_ = reinterpret_cast<const uint4*>(prev + (size_t)(nb_) * 16);             \
+      raw0 = p_[lane]; raw1 = p_[64 + lane]; raw2 = p_[128 + lane]; raw3 = p_[192 + lane];     \
+    }                                                                                          \
+    if (NC) { zc0 = col[0][(nb_) + lane]; zc1 = col[1][(nb_) + lane]; zc2 = col[2][(nb_) + lane]; zc3 = col[3][(nb_) + lane]; } \
+  }
+  CM_NARROW_ISSUE(node0)
+  for (uint32_t c = 0; c < npw; c++) {
+    const uint32_t nb = node0 + 64u * c;
+    uint32_t m[16], z[16];
+    if (PREV) {
+      // uint4 number q = 64 j + lane of the window belongs to node q >> 2, part q & 3; the slot rotation by (node >> 2) keeps
+      // both the 128-bit writes and the per-node reads conflict-free (same scheme as k_merkle_layer)
+#define CM_NARROW_PUT(j_, r_)                                                   \
+  {                                                                             \
+    const uint32_t q_ = (j_) * 64 + lane, node_ = q_ >> 2, part_ = q_ & 3;      \
+    st[node_ * 4 + ((part_ + (node_ >> 2)) & 3)] = r_;                          \
+  }
+      CM_NARROW_PUT(0, raw0) CM_NARROW_PUT(1, raw1) CM_NARROW_PUT(2, raw2) CM_NARROW_PUT(3, raw3)
+#undef CM_NARROW_PUT
+      wave_lds_sync();
+      const uint4 a = st[lane * 4 + ((0 + (lane >> 2)) & 3)], b = st[lane * 4 + ((1 + (lane >> 2)) & 3)];
+      const uint4 cc = st[lane * 4 + ((2 + (lane >> 2)) & 3)], d = st[lane * 4 + ((3 + (lane >> 2)) & 3)];
+      m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+      m[8] = cc.x; m[9] = cc.y; m[10] = cc.z; m[11] = cc.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+      wave_lds_sync();
+    }
+    if (NC) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) z[k] = 0;     // 12 literal zeros: most message additions of this compression fold away
+      z[0] = zc0; z[1] = zc1; z[2] = zc2; z[3] = zc3;
+    }
+    if (c + 1 < npw) CM_NARROW_ISSUE(nb + 64u)   // the next chunk's loads fly during this chunk's compressions
+    NodeFrame<RFC> fr(PREV, NC);
+    uint32_t h[8];
+    fr.init(h);
+    if (PREV) fr.absorb(h, m, 64);
+    if (NC) fr.absorb(h, z, 4u * NC);
+    // result: 64 x 32 B through the wave's LDS window, stored with two wave-contiguous 1 KiB instructions
+    st[lane * 2 + 0] = make_uint4(h[0], h[1], h[2], h[3]);
+    st[lane * 2 + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+    wave_lds_sync();
+    uint4* o = reinterpret_cast<uint4*>(out + (size_t)nb * 8);
+    o[lane] = st[lane];
+    o[64 + lane] = st[64 + lane];
+    wave_lds_sync();
+  }
+#undef CM_NARROW_ISSUE
+}
+
 // hash_node of one tree node, one thread per node (h is initialised here) / one quad of lanes per node
 template <bool RFC>
 __device__ __forceinline__ void merkle_node_thread(const uint32_t* children, const uint32_t* const* __restrict__ cols, uint32_t c_begin,

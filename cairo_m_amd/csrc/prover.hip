@@ -147,19 +147,29 @@ void download_input(const DeviceInput& d, host::ProverInputOwned& o) {
 }
 
 // ---- column sets -------------------------------------------------------------------------------------------
+constexpr size_t COL_SKEW_WORDS_DEFAULT = 0;   // A/B: CM_COL_SKEW_BYTES
 struct ColumnSet {
   std::vector<uint32_t> logs;
   std::vector<uint32_t*> ptrs;
   DevBuf buf, d_ptrs;
   uint32_t** d_view = nullptr;  // device pointer table living in somebody else's upload (UploadBatch)
-  void alloc(const std::vector<uint32_t>& logs_, hipStream_t st, bool upload_ptrs = true) {
+  // Column skew: the columns of a set are powers of two long, so without padding row r of EVERY column has the same address
+  // modulo the column size — a kernel that reads one row of many columns (Merkle leaves, DEEP quotients, constraints, LogUp:
+  // every lane-coalesced 256-byte run of a wave) then keeps hitting the same HBM channel / bank group.  Large columns are
+  // therefore laid out `skew_words()` apart in addition to their length (a multiple of 64 words: runs stay 256-byte aligned).
+  static size_t skew_words() {
+    static const size_t w = getenv("CM_COL_SKEW_BYTES") ? (size_t)atol(getenv("CM_COL_SKEW_BYTES")) / 4 : COL_SKEW_WORDS_DEFAULT;
+    return w & ~(size_t)63;
+  }
+  void alloc(const std::vector<uint32_t>& logs_, hipStream_t st, bool upload_ptrs = true, bool contiguous = false) {
     logs = logs_;
+    const size_t skew = contiguous ? 0 : skew_words();
     size_t total = 0;
-    for (auto l : logs) total += (size_t)1 << l;
+    for (auto l : logs) total += ((size_t)1 << l) + (l >= 14 ? skew : 0);
     buf.alloc(total * 4);
     ptrs.resize(logs.size());
     size_t off = 0;
-    for (size_t i = 0; i < logs.size(); i++) { ptrs[i] = buf.u32() + off; off += (size_t)1 << logs[i]; }
+    for (size_t i = 0; i < logs.size(); i++) { ptrs[i] = buf.u32() + off; off += ((size_t)1 << logs[i]) + (logs[i] >= 14 ? skew : 0); }
     d_view = nullptr;
     if (upload_ptrs) d_ptrs = upload(ptrs, st);
   }
@@ -185,6 +195,7 @@ struct CommittedTree {
   DevBuf tables;  // one upload: pointer tables of coeffs / lde / the FFT groups / the Merkle column order
 };
 
+constexpr uint32_t FFT_CHUNK_MB_DEFAULT = 0;   // Infinity-Cache blocking of the transform sweeps (commit_enqueue); A/B: CM_FFT_CHUNK_MB
 static std::atomic<int> g_transcript_log{0};     // cm_set_transcript_log: proofs record every Fiat-Shamir step (ProofData::transcript)
 static std::atomic<int> g_proofs_in_flight{0};   // proofs being made by cm_prove_many runners right now (0 outside of it)
 struct Prover {
@@ -291,8 +302,22 @@ struct Prover {
       const uint32_t* const* dsrc = d_table + g.off;
       uint32_t* const* dco = (uint32_t* const*)(d_table + g.off + g.n);
       uint32_t* const* dld = (uint32_t* const*)(d_table + g.off + 2 * g.n);
-      if (!from_coeffs) interpolate_oop(dsrc, dco, g.n, g.log, *tw, s);
-      evaluate((const uint32_t* const*)dco, dld, g.n, g.log, g.log + cfg.log_blowup_factor, *tw, s);
+      // Infinity-Cache blocking: the four sweeps of a column (IFFT 2 passes, LDE 2 passes) are issued back to back for a CHUNK
+      // of columns whose working set (evaluations + coefficients + LDE) fits the 256 MiB L3, so every sweep after the first
+      // reads what the previous one just wrote from the on-die cache instead of HBM.  CM_FFT_CHUNK_MB: working-set budget
+      // (0 = whole group per sweep, the round-2 order).
+      static const uint32_t chunk_mb = getenv("CM_FFT_CHUNK_MB") ? (uint32_t)atoi(getenv("CM_FFT_CHUNK_MB")) : FFT_CHUNK_MB_DEFAULT;
+      uint32_t per = g.n;
+      if (chunk_mb) {
+        const uint64_t col_bytes = ((uint64_t)4 << g.log) * (from_coeffs ? 1 : 2) + ((uint64_t)4 << (g.log + cfg.log_blowup_factor));
+        per = (uint32_t)std::max<uint64_t>(1, ((uint64_t)chunk_mb << 20) / col_bytes);
+        if (per >= g.n || (g.log < 16)) per = g.n;
+      }
+      for (uint32_t c0 = 0; c0 < g.n; c0 += per) {
+        const uint32_t nc = std::min(per, g.n - c0);
+        if (!from_coeffs) interpolate_oop(dsrc + c0, dco + c0, nc, g.log, *tw, s);
+        evaluate((const uint32_t* const*)dco + c0, dld + c0, nc, g.log, g.log + cfg.log_blowup_factor, *tw, s);
+      }
     }
     if (with_merkle) t.merkle.commit_prepared(s);
   }
