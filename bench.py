@@ -108,8 +108,11 @@ def cpu_baseline(sample_n, single_n, threads, hip_words=None):
     return parity, out
 
 
-def run_sharded_child(args, world):
-    """`python -m torch.distributed.run ... -m cairo_m_amd.sharded --json` with a time limit; returns bench.py's `sharded` object."""
+def run_sharded_child(args, world, comm="torch", timeout=None):
+    """`python -m torch.distributed.run ... -m cairo_m_amd.sharded --json` with a time limit; returns bench.py's `sharded` object.
+    comm: "torch" = collectives through torch.distributed callbacks (host-blocking); "rccl" = the library's own stream-ordered
+    RCCL communicator (cm_rccl_comm_create)."""
+    timeout = timeout or args.sharded_timeout
     import signal
     import socket
     import subprocess
@@ -122,7 +125,7 @@ def run_sharded_child(args, world):
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "cairo_m_amd.sharded", "--fib-n", str(args.fib_n), "--steps", str(args.steps),
-           "--dist-backend", args.dist_backend, "--check-single", "--json"]
+           "--dist-backend", args.dist_backend, "--check-single", "--json", "--comm", comm]
     if args.force_device >= 0:
         cmd += ["--force-device", str(args.force_device)]
     mode = "one proof sharded over all ranks (strong scaling)"
@@ -131,7 +134,7 @@ def run_sharded_child(args, world):
         p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=fo, stderr=fe, start_new_session=True,
                              preexec_fn=lambda: os.sched_setaffinity(0, ALL_CPUS))   # every rank places itself next to ITS GPU
         try:
-            p.wait(timeout=args.sharded_timeout)
+            p.wait(timeout=timeout)
         except subprocess.TimeoutExpired:
             # the launcher and every rank it started (the ranks sit in process groups of their own): exactly those PIDs
             import psutil
@@ -150,7 +153,7 @@ def run_sharded_child(args, world):
             except OSError:
                 pass
             p.wait()
-            return {"mode": mode, "error": f"no result within {args.sharded_timeout} s (child job killed)"}
+            return {"mode": mode, "comm": comm, "error": f"no result within {timeout} s (child job killed)"}
         fo.seek(0)
         fe.seek(0)
         out, err = fo.read(), fe.read()
@@ -361,9 +364,13 @@ def main():
         store = dist.distributed_c10d._get_default_store()
         if rank == 0:
             sharded = run_sharded_child(args, world)
+            if sharded and "error" not in sharded and args.dist_backend == "nccl":
+                # the same proof with the in-library RCCL communicator (no host sync, no Python in the data path); a failure
+                # here costs only this sub-object
+                sharded["in_library_rccl"] = run_sharded_child(args, world, comm="rccl", timeout=min(180, args.sharded_timeout))
             store.set("cm_sharded_child_done", "1")
         else:
-            store.wait(["cm_sharded_child_done"], datetime.timedelta(seconds=args.sharded_timeout + 120))
+            store.wait(["cm_sharded_child_done"], datetime.timedelta(seconds=2 * args.sharded_timeout + 120))
     verified = None
     hip_words = None
     end_to_end = None

@@ -1297,8 +1297,19 @@ struct SegmentProver {
       P.pace();
       KProfRegion kreg("k_constraints(region)", st);
       Fork fk(st);
+      // side-stream plan of the region (A/B: CM_CSTREAMS="g0,g1,g2,g3,small,slot0,slot1,slot2" = stream index of the size
+      // groups in descending size, of the batched small components and of the slotted ones)
+      static const std::vector<int> cplan = [] {
+        std::vector<int> v = {0, 1, 2, 3, 7, 4, 5, 6};
+        if (const char* e = getenv("CM_CSTREAMS")) {
+          std::vector<int> w;
+          for (const char* p = e; *p;) { w.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
+          if (w.size() == 8) v = w;
+        }
+        return v;
+      }();
       launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
-                               fk.stream(7));   // first: latency-bound, hidden under the large kernels
+                               fk.stream(cplan[4]));   // first: latency-bound, hidden under the large kernels
       int gi = 0, small_rr = 0;
       static const bool early_interp = getenv("CM_NO_EARLY_ACC_INTERP") == nullptr;   // A/B switch
       // large groups first (descending size) so the long kernels start early
@@ -1307,14 +1318,14 @@ struct SegmentProver {
         for (int c : it->second) {
           if (std::find(small_cids.begin(), small_cids.end(), c) != small_cids.end()) { one_stream = false; continue; }
           // the components of a size group share its accumulator: one stream for all of them; slotted ones are independent
-          hipStream_t sc = slot_of[c] >= 0 ? fk.stream(4 + (small_rr++ % 3)) : fk.stream(gi % 4);
+          hipStream_t sc = slot_of[c] >= 0 ? fk.stream(cplan[5 + (small_rr++ % 3)]) : fk.stream(cplan[gi % 4]);
           if (slot_of[c] >= 0) one_stream = false;
           launch_constraints(c, cargs[c], sc);
         }
         // DomainEvaluationAccumulator::finalize starts here for such a group: its accumulator is interpolated on the same
         // stream right behind its constraint kernels — no second fork/join region for the large accumulators
         if (one_stream && early_interp) {
-          interpolate(accs.at(it->first).dev(), 4, it->first, *P.tw, fk.stream(gi % 4));
+          interpolate(accs.at(it->first).dev(), 4, it->first, *P.tw, fk.stream(cplan[gi % 4]));
           acc_interpolated.insert(it->first);
         }
       }
@@ -1545,6 +1556,7 @@ struct SegmentProver {
       KProfRegion kregq("k_quotients", st);   // concurrent launches: timed as one interval
       Fork fkq(st);
       int qk = 0;
+      std::vector<std::pair<QuotientArgs, double>> qargs;
       for (auto& g : qg) {
         QuotientArgs a;
         a.tw = view(*P.tw); a.log_size = g.log;
@@ -1555,10 +1567,15 @@ struct SegmentProver {
         a.coef_c = (const uint32_t*)(base + g.o_cc);
         a.batches = (const QuotientBatch*)(base + g.o_qb);
         a.n_batches = (uint32_t)g.batches.size();
-        launch_quotients(a, (double)g.cols.size(), fkq.stream(qk++));
+        qargs.push_back({a, (double)g.cols.size()});
         q_logs.push_back(g.log);
         quotients.push_back(std::move(g.out));
       }
+      // the small groups (latency-bound column-slice kernels, ~170 us in a row) go FIRST, together on one side stream, so that
+      // they hide under the large groups instead of trailing them (they ended the region ~90 us after the last large kernel);
+      // the large groups follow by descending size, one stream each
+      for (auto& qa : qargs) if (qa.first.log_size < 14) launch_quotients(qa.first, qa.second, fkq.stream(Fork::N - 1));
+      for (auto& qa : qargs) if (qa.first.log_size >= 14) launch_quotients(qa.first, qa.second, fkq.stream(qk++ % (Fork::N - 1)));
       fkq.join();
       kregq.close();
     }

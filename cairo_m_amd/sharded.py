@@ -23,9 +23,13 @@ _A2A = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_u
 _AG = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64)
 
 
+_SETSTREAM = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64)
+
+
 class CmComm(C.Structure):
     _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("ctx", C.c_void_p), ("send_buf", C.c_void_p), ("recv_buf", C.c_void_p),
-                ("buf_words", C.c_uint64), ("all_to_all_v", _A2A), ("all_gather", _AG)]
+                ("buf_words", C.c_uint64), ("all_to_all_v", _A2A), ("all_gather", _AG),
+                ("flags", C.c_uint32), ("set_stream", _SETSTREAM)]       # 0 / NULL: the blocking form (this module's TorchComm)
 
 
 def shard_plan(host_input, world, lib=None):
@@ -56,7 +60,8 @@ class TorchComm:
         self.bytes_moved = 0
         self.calls = 0
         self._a2a, self._ag = _A2A(self._all_to_all_v), _AG(self._all_gather)   # keep the thunks alive
-        self.c = CmComm(self.rank, self.world, None, self.send.data_ptr(), self.recv.data_ptr(), staging_words, self._a2a, self._ag)
+        self.c = CmComm(self.rank, self.world, None, self.send.data_ptr(), self.recv.data_ptr(), staging_words, self._a2a, self._ag,
+                        0, _SETSTREAM())
 
     def _sync(self):
         if self.send.is_cuda:
@@ -123,6 +128,38 @@ class TorchComm:
             return 1
 
 
+class RcclComm:
+    """The IN-LIBRARY communicator (include/cairom_hip.h cm_rccl_*): RCCL collectives enqueued on the prover's own stream, no
+    host synchronisation and no Python in the data path.  torch.distributed is used ONCE, to hand rank 0's 128-byte RCCL id
+    to the other ranks (control plane); pass `id_bytes` to skip even that (env / file / MPI launchers)."""
+
+    def __init__(self, backend, staging_words, rank=None, world=None, id_bytes=None):
+        self.L = backend.L
+        if id_bytes is None:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(), dist.get_world_size()
+            box = [None]
+            if rank == 0:
+                buf = (C.c_uint8 * 128)()
+                backend._ck(self.L.cm_rccl_unique_id(buf))
+                box[0] = bytes(buf)
+            dist.broadcast_object_list(box, src=0)
+            id_bytes = box[0]
+        self.rank, self.world = rank, world
+        self.h = C.c_void_p()
+        backend._ck(self.L.cm_rccl_comm_create((C.c_uint8 * 128)(*id_bytes), C.c_uint32(rank), C.c_uint32(world),
+                                                C.c_uint64(staging_words), C.byref(self.h)))
+        self.L.cm_rccl_comm_view.restype = C.POINTER(CmComm)
+        self.c = self.L.cm_rccl_comm_view(self.h).contents
+        self.calls = 0
+        self.bytes_moved = 0      # (not counted on this path: nothing passes through Python)
+
+    def free(self):
+        if self.h:
+            self.L.cm_rccl_comm_destroy(self.h)
+            self.h = None
+
+
 def prove_sharded(backend, dev_input, comm, cfg=None):
     """cm_prove_sharded: every rank of comm's group calls this with the SAME input; returns this rank's copy of the proof."""
     h = C.c_void_p()
@@ -136,6 +173,9 @@ def main():
     ap.add_argument("--mixed-iters", type=int, default=0,
                     help="prove the all-opcode loop (cairo_m_amd/workloads.py, BASELINE configs[4]) with this many iterations instead")
     ap.add_argument("--dist-backend", default="nccl")
+    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
+                    help="torch: collectives through torch.distributed callbacks (blocking); rccl: the library's own stream-ordered "
+                         "RCCL communicator (cm_rccl_comm_create) — needs one GPU per rank")
     ap.add_argument("--force-device", type=int, default=-1, help="every rank uses this GPU (tests: ranks sharing one GPU over gloo)")
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--out", default="", help="rank r writes its proof words to <out>.<r>.npy")
@@ -159,7 +199,7 @@ def main():
     else:
         inp = synth_fibonacci(a.fib_n)
     owner, words = shard_plan(inp, dist.get_world_size(), be.L)
-    comm = TorchComm(words, device=local)
+    comm = RcclComm(be, words) if a.comm == "rccl" else TorchComm(words, device=local)
     dev = be.upload_input(inp)
     p = prove_sharded(be, dev, comm)          # warm-up + the proof that is written out
     w = p.words().copy()

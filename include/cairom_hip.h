@@ -275,10 +275,25 @@ typedef struct cm_comm {
   uint64_t buf_words;                /* capacity of each staging buffer (cm_shard_plan reports what a proof needs) */
   int32_t (*all_to_all_v)(void* ctx, const uint64_t* send_words, const uint64_t* recv_words);
   int32_t (*all_gather)(void* ctx, uint64_t words_per_rank);
+  /* Optional (zero / NULL = the blocking form above).  CM_COMM_STREAM_ORDERED: the callbacks only ENQUEUE the exchange on the
+   * stream given through set_stream (the prover calls it once with its own stream) and return at once; the prover then neither
+   * drains its stream before a collective nor waits after it — everything stays ordered on that one stream. */
+  uint32_t flags;
+  int32_t (*set_stream)(void* ctx, cm_stream_t stream);
 } cm_comm;
+#define CM_COMM_STREAM_ORDERED 1u
 /* host code (no GPU): which rank owns which component, and the staging capacity (words) a sharded proof of `input` needs */
 int32_t cm_shard_plan(const cm_prover_input* input, uint32_t world, int32_t owner[CM_N_COMPONENTS], uint64_t* staging_words);
 int32_t cm_prove_sharded(const cm_device_input* input, const cm_pcs_config* config, const cm_comm* comm, cm_proof** out);
+/* In-library cm_comm on RCCL (xGMI inside a node), stream-ordered: no host synchronisation around an exchange, nothing but
+ * the library in the data path.  Rank 0 makes the 128-byte id (cm_rccl_unique_id) and the launcher hands it to every rank;
+ * every rank creates its communicator with the staging capacity cm_shard_plan reports and passes cm_rccl_comm_view() to
+ * cm_prove_sharded.  librccl.so is loaded on first use (dlopen; a copy the process already mapped is reused). */
+typedef struct cm_rccl_comm cm_rccl_comm;
+int32_t cm_rccl_unique_id(uint8_t id_out[128]);
+int32_t cm_rccl_comm_create(const uint8_t id[128], uint32_t rank, uint32_t world, uint64_t staging_words, cm_rccl_comm** out);
+const cm_comm* cm_rccl_comm_view(const cm_rccl_comm* c);
+int32_t cm_rccl_comm_destroy(cm_rccl_comm* c);
 /* Segment pipeline: prove n independent segments with up to `inflight` (1..8) proofs in flight on the
  * GPU (persistent worker threads inside the library, one stream set / device pool each).  outs[i] = proof of
  * inputs[i]; on error the first failure is returned and the proofs already built stay in outs (free them). */

@@ -149,6 +149,14 @@ pub struct cm_comm {
     pub buf_words: u64,
     pub all_to_all_v: Option<unsafe extern "C" fn(ctx: *mut c_void, send_words: *const u64, recv_words: *const u64) -> i32>,
     pub all_gather: Option<unsafe extern "C" fn(ctx: *mut c_void, words_per_rank: u64) -> i32>,
+    /// CM_COMM_STREAM_ORDERED (1): the callbacks enqueue on the stream given through `set_stream` and do not block
+    pub flags: u32,
+    pub set_stream: Option<unsafe extern "C" fn(ctx: *mut c_void, stream: cm_stream_t) -> i32>,
+}
+pub const CM_COMM_STREAM_ORDERED: u32 = 1;
+#[repr(C)]
+pub struct cm_rccl_comm {
+    _private: [u8; 0],
 }
 
 unsafe extern "C" {
@@ -203,6 +211,10 @@ unsafe extern "C" {
     pub fn cm_verify_proof_words(words: *const u32, n_words: u64, expected: *const cm_pcs_config) -> i32;
     pub fn cm_shard_plan(input: *const cm_prover_input, world: u32, owner: *mut i32, staging_words: *mut u64) -> i32;
     pub fn cm_prove_sharded(input: *const cm_device_input, config: *const cm_pcs_config, comm: *const cm_comm, out: *mut *mut cm_proof) -> i32;
+    pub fn cm_rccl_unique_id(id_out: *mut u8) -> i32;
+    pub fn cm_rccl_comm_create(id: *const u8, rank: u32, world: u32, staging_words: u64, out: *mut *mut cm_rccl_comm) -> i32;
+    pub fn cm_rccl_comm_view(c: *const cm_rccl_comm) -> *const cm_comm;
+    pub fn cm_rccl_comm_destroy(c: *mut cm_rccl_comm) -> i32;
     pub fn cm_prove_many(inputs: *const *const cm_device_input, n: u32, config: *const cm_pcs_config, inflight: u32, outs: *mut *mut cm_proof) -> i32;
     pub fn cm_set_preprocessed_cache(on: i32) -> i32;
     pub fn cm_set_twiddle_cache(on: i32) -> i32;

@@ -22,10 +22,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_sharded(world, fib_n, out, mixed_iters=0):
+def _run_sharded(world, fib_n, out, mixed_iters=0, comm="torch"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "-m", "cairo_m_amd.sharded", "--fib-n", str(fib_n), "--dist-backend", "gloo",
-           "--force-device", "0", "--steps", "0", "--out", out, "--mixed-iters", str(mixed_iters)]
+           "--force-device", "0", "--steps", "0", "--out", out, "--mixed-iters", str(mixed_iters), "--comm", comm]
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -68,4 +68,21 @@ def test_sharded_all_opcode_proof_equals_single_gpu_proof(backend, oracle, tmp_p
         diff = np.nonzero(got != want)[0]
         assert diff.size == 0, f"rank {r}: first differing words {diff[:8]} of {got.size}"
     assert oracle.verify(want)[0] == 0
+    inp.free()
+
+
+@pytest.mark.parametrize("fib_n", [50, 100_000])
+def test_in_library_rccl_comm_world_1(backend, oracle, tmp_path, fib_n):
+    """The library's own stream-ordered RCCL communicator (cm_rccl_comm_create: ncclAllGather / grouped ncclSend + ncclRecv on
+    the prover's stream, no host synchronisation): the test box has ONE GPU and RCCL refuses two ranks on one device, so this
+    runs the whole sharded path — every pack, collective and unpack — through librccl with world = 1 and requires the proof to
+    equal the single-GPU one.  (Multi-rank bit-exactness is covered over gloo above; multi-rank RCCL needs a multi-GPU node.)"""
+    inp = synth_fibonacci(fib_n)
+    p = backend.prove(inp)
+    want = p.words().copy()
+    p.free()
+    out = str(tmp_path / "proof")
+    _run_sharded(1, fib_n, out, comm="rccl")
+    got = np.load(f"{out}.0.npy")
+    assert got.size == want.size and np.array_equal(got, want)
     inp.free()
