@@ -1024,10 +1024,15 @@ struct SegmentProver {
       // the GPU busy; its root comes back together with the root of tree 1.  Forked from the stream position after the
       // trace-generation launches so that its chain does not queue in front of them.
       pp_fork.reset(new Fork(st));
-      P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
+      (void)pp_fork->stream(Fork::N - 1);   // the side stream waits for THIS point of the main stream (trace generation done)
     }
     P.tick("trace_gen");
+    // tree 1 first: its large transforms start as soon as the trace exists and keep the GPU busy while the host issues tree 0's
+    // chain of small launches (enqueued first, that chain delayed the first tree-1 kernel by the host time of ~30 launches)
+    static const bool tree1_first = getenv("CM_TREE0_FIRST") == nullptr;   // A/B switch
+    if (build_tree0 && !tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
     P.commit_enqueue(P.trees[1], &tr_evals, false, st);
+    if (build_tree0 && tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
     // Root 0 first (transcript order, prover.rs:70-82: root 0, claim, root 1): tree 0 has been running on its side stream next
     // to all of the above; its root is copied on THAT stream and waited for here, while the GPU is still busy with tree 1.
     if (pp_fork) {
