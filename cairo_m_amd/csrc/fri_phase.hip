@@ -1,0 +1,204 @@
+// FRI commit phase of the segment prover (stwo `prove`, reached from crates/prover/src/prover.rs:131): first-layer tree over the
+// DEEP quotient columns, circle / line folds, one Merkle tree per inner layer, the last layer's polynomial — with the
+// Fiat-Shamir steps between the layers on the device (k_chan_mix_root_draw; the host replays them afterwards and cross-checks).
+// The decommitment planner of the FRI trees lives with the phase's declaration (prover_common.hpp: FriPhase::plan_decommit /
+// finish_decommit, MerkleTree::plan_decommit in merkle_tree.hpp).
+#include "prover_common.hpp"
+
+namespace cm {
+
+void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
+                      const std::function<void()>& while_gpu_busy) {
+  hipStream_t st = P.st;
+  Channel& ch = P.ch;
+  // ---- FRI commit ----
+  // The whole commit phase is enqueued without a host round trip: after each layer's Merkle tree a 1-thread
+  // kernel does the transcript step (mix_root, draw the folding challenge) on a device copy of the channel,
+  // and the fold kernels read the challenge from device memory.  The host replays the same steps on its own
+  // channel afterwards from the recorded roots and checks that the challenges agree.
+  const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup_factor;
+  uint32_t layer_log = q_logs[0] - 1;
+  const uint32_t n_inner = layer_log > last_log ? layer_log - last_log : 0;
+  DevBuf d_chan(64), d_alphas((size_t)(n_inner + 1) * 16), d_roots((size_t)(n_inner + 1) * 32);
+  {
+    uint32_t cw[9];
+    memcpy(cw, ch.digest.data(), 32);
+    cw[8] = ch.n_sent;
+    stage_upload(d_chan.p, cw, sizeof(cw), st);
+  }
+  // every layer above the single-launch tail is allocated up front so that the column tables of all their
+  // Merkle trees (and of the first-layer tree) travel in ONE host->device copy
+  std::vector<std::unique_ptr<InnerLayer>> pre;
+  DevBuf fri_tables;
+  {
+    UploadBatch ub;
+    std::vector<const uint32_t*> cols;
+    std::vector<uint32_t> logs;
+    for (size_t k = 0; k < quotients.size(); k++) for (int c = 0; c < 4; c++) { cols.push_back(quotients[k].ptrs[c]); logs.push_back(q_logs[k]); }
+    first_tree.prepare(cols, logs);
+    ub.add(first_tree.cols, &first_tree.d_cols_view);
+    for (uint32_t l = layer_log; l > last_log && l > fri_tail_log(); l--) {
+      std::unique_ptr<InnerLayer> il(new InnerLayer());
+      il->log = l;
+      il->eval.alloc(std::vector<uint32_t>(4, l), st, false);
+      std::vector<const uint32_t*> lc(il->eval.ptrs.begin(), il->eval.ptrs.end());
+      il->tree.prepare(lc, std::vector<uint32_t>(4, l));
+      ub.add(il->tree.cols, &il->tree.d_cols_view);
+      pre.push_back(std::move(il));
+    }
+    fri_tables = ub.flush(st);
+    first_tree.commit_prepared(st);
+    chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
+  }
+  ColumnSet layer;
+  bool layer_is_blank = !pre.empty();   // pre[0] is written (not accumulated into) by the first circle fold: no memset
+  if (pre.empty()) {
+    layer.alloc(std::vector<uint32_t>(4, layer_log), st, false);
+    CM_HIP(hipMemsetAsync(layer.buf.p, 0, layer.buf.bytes, st));
+  }
+  size_t qi = 0, pi = 0;
+  const QM31 unused_alpha;
+  while (layer_log > last_log) {
+    if (layer_log <= fri_tail_log()) {
+      // every remaining layer in one launch (k_fri_tail); buffers are laid out here so that the decommitment
+      // code sees ordinary InnerLayer objects afterwards
+      FriTailArgs ta;
+      memset(&ta, 0, sizeof(ta));
+      ta.tw = view(*P.tw);
+      ta.top_log = layer_log; ta.last_log = last_log;
+      ta.first_index = (uint32_t)inner.size() + 1;
+      ta.chan = d_chan.u32(); ta.alphas = d_alphas.u32(); ta.roots = d_roots.u32();
+      for (uint32_t l = layer_log; l > last_log; l--) {
+        std::unique_ptr<InnerLayer> il(new InnerLayer());
+        il->log = l;
+        if (l == layer_log) il->eval = std::move(layer);
+        else il->eval.alloc(std::vector<uint32_t>(4, l), st, false);
+        FriTailLayer& tl = ta.layers[l];
+        for (int c = 0; c < 4; c++) tl.cols[c] = il->eval.ptrs[c];
+        while (qi < quotients.size() && q_logs[qi] - 1 == l) {
+          CM_CHECK(tl.circle[0] == nullptr, "fri: two quotient groups of one size");
+          for (int c = 0; c < 4; c++) tl.circle[c] = quotients[qi].ptrs[c];
+          qi++;
+        }
+        MerkleTree& mt = il->tree;
+        mt.cols.assign(il->eval.ptrs.begin(), il->eval.ptrs.end());
+        mt.col_logs.assign(4, l);
+        mt.layers.resize(l + 1);
+        for (uint32_t k = 0; k <= l; k++) { mt.layers[k].alloc((size_t)32 << k); tl.merkle[k] = mt.layers[k].u32(); }
+        inner.push_back(std::move(il));
+      }
+      layer = ColumnSet();
+      layer.alloc(std::vector<uint32_t>(4, last_log), st, false);
+      for (int c = 0; c < 4; c++) ta.layers[last_log].cols[c] = layer.ptrs[c];
+      fri_tail(ta, st);
+      layer_log = last_log;
+      break;
+    }
+    // layers above the tail: buffers and tree tables were prepared above (pre[pi])
+    InnerLayer* cur = pre[pi].get();
+    while (qi < quotients.size() && q_logs[qi] - 1 == layer_log) {
+      const uint32_t* src[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
+      uint32_t* dst[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
+      fold_circle_into_line(dst, src, q_logs[qi], *P.tw, unused_alpha, !layer_is_blank, st, d_alphas.u32());
+      layer_is_blank = false;
+      qi++;
+    }
+    CM_CHECK(!layer_is_blank, "fri: the first layer received no quotient column");
+    cur->tree.commit_prepared(st);
+    const size_t li = inner.size() + 1;
+    chan_mix_root_draw(d_chan.u32(), cur->tree.layers[0].u32(), d_alphas.u32() + 4 * li, d_roots.u32() + 8 * li, st);
+    // fold into the next layer: the next pre-allocated one, or a fresh buffer that the tail / last layer takes over
+    uint32_t* dst[4];
+    if (pi + 1 < pre.size()) {
+      for (int c = 0; c < 4; c++) dst[c] = pre[pi + 1]->eval.ptrs[c];
+    } else {
+      layer = ColumnSet();
+      layer.alloc(std::vector<uint32_t>(4, layer_log - 1), st, false);
+      for (int c = 0; c < 4; c++) dst[c] = layer.ptrs[c];
+    }
+    const uint32_t* src[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
+    // the quotient columns of the next layer's size are folded in by the same kernel (the single-launch tail does its own)
+    const bool next_outside_tail = pi + 1 < pre.size();
+    if (next_outside_tail && qi < quotients.size() && q_logs[qi] == layer_log &&
+        !(qi + 1 < quotients.size() && q_logs[qi + 1] == layer_log)) {
+      const uint32_t* circ[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
+      fold_line_and_circle(dst, src, circ, layer_log, *P.tw, st, d_alphas.u32() + 4 * li, d_alphas.u32());
+      qi++;
+    } else {
+      fold_line(dst, src, layer_log, *P.tw, unused_alpha, st, d_alphas.u32() + 4 * li);
+    }
+    layer_log--;
+    inner.push_back(std::move(pre[pi]));
+    pi++;
+  }
+  CM_CHECK(qi == quotients.size(), "fri: not every quotient column was folded");
+  while_gpu_busy();   // host-only work of the caller, overlapped with the quotient / FRI kernels enqueued above
+
+  // last layer (2^last_log values): interpolate on the host, keep 2^log_last_layer coefficients
+  {
+    uint32_t n = 1u << last_log;
+    const uint32_t* c4[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
+    std::vector<uint32_t> pos(n);
+    for (uint32_t i = 0; i < n; i++) pos[i] = i;
+    std::vector<QM31> vals;
+    // challenges, roots and the last layer come back in ONE round trip (pinned slots; a large last layer falls back to the
+    // batched gather)
+    CM_CHECK((n_inner + 1) * 4 <= PIN_ROOTS - PIN_ALPHAS && (n_inner + 1) * 8 <= PIN_LAST_LAYER - PIN_ROOTS, "fri: too many layers");
+    const uint32_t* h_alphas = pinned_words() + PIN_ALPHAS;
+    const uint32_t* h_roots = pinned_words() + PIN_ROOTS;
+    CM_HIP(hipMemcpyAsync((void*)h_alphas, d_alphas.p, (size_t)(n_inner + 1) * 16, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync((void*)h_roots, d_roots.p, (size_t)(n_inner + 1) * 32, hipMemcpyDeviceToHost, st));
+    if (4 * n <= PIN_WORDS - PIN_LAST_LAYER) {
+      uint32_t* ll = pinned_words() + PIN_LAST_LAYER;
+      for (int k = 0; k < 4; k++) CM_HIP(hipMemcpyAsync(ll + k * n, c4[k], n * 4, hipMemcpyDeviceToHost, st));
+      CM_HIP(hipStreamSynchronize(st));
+      for (uint32_t i = 0; i < n; i++) {
+        uint32_t w4[4] = {ll[i], ll[n + i], ll[2 * n + i], ll[3 * n + i]};
+        vals.push_back(QM31::from_u32(w4));
+      }
+    } else {
+      GatherBatch gb;
+      QGather g = plan_gather_q(c4, pos, gb);
+      gb.run(st);  // synchronises the stream: roots / challenges are on the host now
+      finish_gather_q(g, gb, vals);
+    }
+    // host replay of the device-side transcript steps
+    CM_CHECK(inner.size() == n_inner, "fri: layer count mismatch");
+    for (size_t li = 0; li <= n_inner; li++) {
+      hostch::Hash32 root;
+      memcpy(root.data(), &h_roots[8 * li], 32);
+      ch.mix_root(root);
+      QM31 alpha = ch.draw_felt();
+      CM_CHECK(alpha == QM31::from_u32(&h_alphas[4 * li]), "fri: device transcript diverged from the host channel");
+      if (li == 0) pf.fri_first.commitment = root;
+      else inner[li - 1]->root = root;
+    }
+    for (uint32_t l = 0; l < last_log; l++) {
+      uint32_t stride = 1u << l;
+      for (uint32_t h = 0; h < (n >> (l + 1)); h++) {
+        // LineDomain(half_odds(last_log)) doubled l times: coset half_odds(last_log - l); point bitrev(h)
+        uint32_t clog_ = last_log - l;
+        uint32_t idx = subgroup_gen_index(clog_ + 2) + subgroup_gen_index(clog_) * bit_reverse(h, clog_ - 1);
+        M31 xinv = inv(point_at_index(idx).x);
+        for (uint32_t k = 0; k < stride; k++) {
+          uint32_t i0 = (h << (l + 1)) + k, i1 = i0 + stride;
+          QM31 a = vals[i0], b = vals[i1];
+          vals[i0] = a + b;
+          vals[i1] = (a - b) * xinv;
+        }
+      }
+    }
+    // `vals` sits in bit-reversed evaluation order, so after the in-place transform position p holds the coefficient of
+    // the basis element of degree p (= LinePoly::into_ordered_coefficients); the proof keeps the first 2^bound of them
+    // in LinePoly's own bit-reversed order (from_ordered_coefficients).
+    M31 ninv = inv(M31::from_u32(n));
+    uint32_t keep = 1u << cfg.log_last_layer_degree_bound;
+    for (uint32_t i = keep; i < n; i++) CM_CHECK(vals[i].is_zero(), "fri: last layer has invalid degree");
+    pf.last_layer_poly.assign(keep, QM31());
+    for (uint32_t i = 0; i < keep; i++) pf.last_layer_poly[bit_reverse(i, cfg.log_last_layer_degree_bound)] = vals[i] * ninv;
+    pf.last_layer_log_size = cfg.log_last_layer_degree_bound;
+    ch.mix_felts(pf.last_layer_poly.data(), pf.last_layer_poly.size());
+  }
+}
+
+}  // namespace cm

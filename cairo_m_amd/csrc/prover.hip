@@ -4,15 +4,9 @@
 // every pass over trace data (trace gen, LogUp, IFFT/LDE, Merkle, constraints, OODS sampling, DEEP
 // quotients, FRI folds, PoW search, decommit gathers) is a kernel.  No CPU fallback exists.
 #include "../../include/cairom_hip.h"
-#include "engine.hpp"
-#include "merkle_tree.hpp"
+#include "prover_common.hpp"
 #include "air_kernels.hpp"
-#include "fri_kernels.hpp"
 #include "gpu_air.hpp"
-#include "host_channel.hpp"
-#include "framing.hpp"
-#include "proof.hpp"
-#include "kprof.hpp"
 #include "point_eval.hpp"
 #include "host_adapter.hpp"
 #include "shard_kernels.hpp"
@@ -29,8 +23,6 @@
 #include <functional>
 
 namespace cm {
-
-using hostch::Channel;
 
 static inline uint32_t log_size_for(uint64_t n) {  // max(LOG_N_LANES, ceil_log2(n))
   uint32_t l = 4;
@@ -146,195 +138,6 @@ void download_input(const DeviceInput& d, host::ProverInputOwned& o) {
   down(o.final_tree, d.fin_tree, m.n_final_tree);
 }
 
-// ---- column sets -------------------------------------------------------------------------------------------
-constexpr size_t COL_SKEW_WORDS_DEFAULT = 0;   // A/B: CM_COL_SKEW_BYTES
-struct ColumnSet {
-  std::vector<uint32_t> logs;
-  std::vector<uint32_t*> ptrs;
-  DevBuf buf, d_ptrs;
-  uint32_t** d_view = nullptr;  // device pointer table living in somebody else's upload (UploadBatch)
-  // Column skew: the columns of a set are powers of two long, so without padding row r of EVERY column has the same address
-  // modulo the column size — a kernel that reads one row of many columns (Merkle leaves, DEEP quotients, constraints, LogUp:
-  // every lane-coalesced 256-byte run of a wave) then keeps hitting the same HBM channel / bank group.  Large columns are
-  // therefore laid out `skew_words()` apart in addition to their length (a multiple of 64 words: runs stay 256-byte aligned).
-  static size_t skew_words() {
-    static const size_t w = getenv("CM_COL_SKEW_BYTES") ? (size_t)atol(getenv("CM_COL_SKEW_BYTES")) / 4 : COL_SKEW_WORDS_DEFAULT;
-    return w & ~(size_t)63;
-  }
-  void alloc(const std::vector<uint32_t>& logs_, hipStream_t st, bool upload_ptrs = true, bool contiguous = false) {
-    logs = logs_;
-    const size_t skew = contiguous ? 0 : skew_words();
-    size_t total = 0;
-    for (auto l : logs) total += ((size_t)1 << l) + (l >= 14 ? skew : 0);
-    buf.alloc(total * 4);
-    ptrs.resize(logs.size());
-    size_t off = 0;
-    for (size_t i = 0; i < logs.size(); i++) { ptrs[i] = buf.u32() + off; off += ((size_t)1 << logs[i]) + (logs[i] >= 14 ? skew : 0); }
-    d_view = nullptr;
-    if (upload_ptrs) d_ptrs = upload(ptrs, st);
-  }
-  uint32_t* const* dev(size_t first = 0) const {
-    if (d_view) return d_view + first;
-    CM_CHECK(d_ptrs.p, "ColumnSet::dev(): pointer table was not uploaded");
-    return d_ptrs.as<uint32_t*>() + first;
-  }
-  size_t size() const { return logs.size(); }
-};
-
-// groups column indices by log size (descending) — used to batch FFT launches
-static std::map<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> by_log(const std::vector<uint32_t>& logs) {
-  std::map<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> m;
-  for (uint32_t i = 0; i < logs.size(); i++) m[logs[i]].push_back(i);
-  return m;
-}
-
-struct CommittedTree {
-  ColumnSet coeffs, lde;
-  MerkleTree merkle;
-  hostch::Hash32 root;
-  DevBuf tables;  // one upload: pointer tables of coeffs / lde / the FFT groups / the Merkle column order
-};
-
-constexpr uint32_t FFT_CHUNK_MB_DEFAULT = 0;   // Infinity-Cache blocking of the transform sweeps (commit_enqueue); A/B: CM_FFT_CHUNK_MB
-static std::atomic<int> g_transcript_log{0};     // cm_set_transcript_log: proofs record every Fiat-Shamir step (ProofData::transcript)
-static std::atomic<int> g_proofs_in_flight{0};   // proofs being made by cm_prove_many runners right now (0 outside of it)
-struct Prover {
-  hipStream_t st = 0;
-  cm_pcs_config cfg;
-  Twiddles* tw = nullptr;
-  Channel ch;
-  CommittedTree trees[4];
-  std::vector<double> phase_ms;
-  std::chrono::steady_clock::time_point t0;
-
-  // Phase boundaries are HIP events on the prover stream, read back at the end of the proof: a host-side
-  // hipStreamSynchronize per phase drained the GPU at boundaries that need no host round trip (constraints ->
-  // composition commit, quotients -> FRI).  CM_HOST_TRACE=1 restores the synchronising form and prints host / wait times.
-  std::vector<hipEvent_t> evs;
-  static std::vector<hipEvent_t>& event_cache() { static thread_local std::vector<hipEvent_t> c; return c; }
-  hipEvent_t next_event() {
-    auto& c = event_cache();
-    if (evs.size() == c.size()) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); c.push_back(e); }
-    evs.push_back(c[evs.size()]);
-    return evs.back();
-  }
-  void start() {
-    t0 = std::chrono::steady_clock::now();
-    CM_HIP(hipEventRecord(next_event(), st));
-  }
-  void tick(const char* name) {
-    static const bool trace = getenv("CM_HOST_TRACE") != nullptr;
-    CM_HIP(hipEventRecord(next_event(), st));
-    if (!trace) return;
-    auto te = std::chrono::steady_clock::now();
-    CM_HIP(hipStreamSynchronize(st));
-    auto t1 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[phase] %-20s host %8.1f us, then waited %8.1f us for the GPU\n", name,
-            std::chrono::duration<double, std::micro>(te - t0).count(), std::chrono::duration<double, std::micro>(t1 - te).count());
-    t0 = t1;
-  }
-  void finish() {   // the stream is idle (the decommitment gather has been read back)
-    CM_HIP(hipEventSynchronize(evs.back()));
-    for (size_t k = 1; k < evs.size(); k++) {
-      float ms = 0;
-      CM_HIP(hipEventElapsedTime(&ms, evs[k - 1], evs[k]));
-      phase_ms.push_back(ms);
-    }
-  }
-
-  // IFFT src(evals, trace domain) -> tree.coeffs; LDE -> tree.lde; Merkle; mix root.
-  // If `in_place`, coeffs aliases src (src is consumed).
-  void commit(CommittedTree& t, ColumnSet* evals, bool from_coeffs) {
-    commit_enqueue(t, evals, from_coeffs, st);
-    commit_finish(t);
-  }
-  // the root comes back on the prover stream (which has joined the stream the tree was built on) and goes into the transcript
-  void commit_finish(CommittedTree& t) {
-    t.merkle.root(t.root.data(), st);
-    ch.mix_root(t.root);
-  }
-  // everything of a commitment except the root read-back, on stream `s` (tree 0 is built on a side stream while the
-  // execution trace is generated: both are chains of small launches)
-  // small_evals_in_place: with from_coeffs, the SMALL columns of t.coeffs (small_commit_serves) still hold evaluations —
-  // the caller interpolated only the large ones — and the fused small-column kernel interpolates them in place
-  void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true,
-                      bool small_evals_in_place = false) {
-    const std::vector<uint32_t> logs = from_coeffs ? t.coeffs.logs : evals->logs;
-    UploadBatch ub;
-    if (!from_coeffs) { t.coeffs.alloc(logs, s, false); ub.add(t.coeffs.ptrs, &t.coeffs.d_view); }
-    std::vector<uint32_t> lde_logs(logs);
-    for (auto& l : lde_logs) l += cfg.log_blowup_factor;
-    t.lde.alloc(lde_logs, s, false);
-    ub.add(t.lde.ptrs, &t.lde.d_view);
-    // pointer table of all size groups of the tree: [src | coeffs | lde] per group
-    struct Grp { uint32_t log, n; size_t off; };
-    std::vector<Grp> grps;
-    std::vector<const uint32_t*> table;
-    for (auto& kv : by_log(logs)) {
-      Grp g{kv.first, (uint32_t)kv.second.size(), table.size()};
-      for (auto i : kv.second) table.push_back(from_coeffs ? nullptr : evals->ptrs[i]);
-      for (auto i : kv.second) table.push_back(t.coeffs.ptrs[i]);
-      for (auto i : kv.second) table.push_back(t.lde.ptrs[i]);
-      grps.push_back(g);
-    }
-    const uint32_t** d_table = nullptr;
-    ub.add(table, &d_table);
-    std::vector<const uint32_t*> cols(t.lde.ptrs.begin(), t.lde.ptrs.end());
-    if (with_merkle) {        // (the sharded prover hashes row slices of the LDE instead: prover_sharded.inc)
-      t.merkle.prepare(cols, t.lde.logs);
-      ub.add(t.merkle.cols, &t.merkle.d_cols_view);
-    }
-    // small columns of every size: ONE fused interpolate + extend launch for all of them (k_small_commit)
-    std::vector<SmallCommitJob> sjobs;
-    uint32_t small_max = 0;
-    for (size_t i = 0; i < logs.size(); i++)
-      if (small_commit_serves(logs[i], cfg.log_blowup_factor)) {
-        const uint32_t* src = !from_coeffs ? evals->ptrs[i] : small_evals_in_place ? t.coeffs.ptrs[i] : nullptr;
-        sjobs.push_back(SmallCommitJob{src, t.coeffs.ptrs[i], t.lde.ptrs[i], logs[i], inv(M31::from_u32(1u << logs[i])).v});
-        small_max = std::max(small_max, logs[i]);
-      }
-    SmallCommitJob* d_sjobs = nullptr;
-    if (!sjobs.empty()) ub.add(sjobs, &d_sjobs);
-    t.tables = ub.flush(s);   // ONE host->device copy for the whole tree
-    small_commit(d_sjobs, (uint32_t)sjobs.size(), small_max, cfg.log_blowup_factor, *tw, s);
-    for (auto& g : grps) {
-      if (small_commit_serves(g.log, cfg.log_blowup_factor)) continue;
-      const uint32_t* const* dsrc = d_table + g.off;
-      uint32_t* const* dco = (uint32_t* const*)(d_table + g.off + g.n);
-      uint32_t* const* dld = (uint32_t* const*)(d_table + g.off + 2 * g.n);
-      // Infinity-Cache blocking: the four sweeps of a column (IFFT 2 passes, LDE 2 passes) are issued back to back for a CHUNK
-      // of columns whose working set (evaluations + coefficients + LDE) fits the 256 MiB L3, so every sweep after the first
-      // reads what the previous one just wrote from the on-die cache instead of HBM.  CM_FFT_CHUNK_MB: working-set budget
-      // (0 = whole group per sweep, the round-2 order).
-      static const uint32_t chunk_mb = getenv("CM_FFT_CHUNK_MB") ? (uint32_t)atoi(getenv("CM_FFT_CHUNK_MB")) : FFT_CHUNK_MB_DEFAULT;
-      uint32_t per = g.n;
-      if (chunk_mb) {
-        const uint64_t col_bytes = ((uint64_t)4 << g.log) * (from_coeffs ? 1 : 2) + ((uint64_t)4 << (g.log + cfg.log_blowup_factor));
-        per = (uint32_t)std::max<uint64_t>(1, ((uint64_t)chunk_mb << 20) / col_bytes);
-        if (per >= g.n || (g.log < 16)) per = g.n;
-      }
-      for (uint32_t c0 = 0; c0 < g.n; c0 += per) {
-        const uint32_t nc = std::min(per, g.n - c0);
-        if (!from_coeffs) interpolate_oop(dsrc + c0, dco + c0, nc, g.log, *tw, s);
-        evaluate((const uint32_t* const*)dco + c0, dld + c0, nc, g.log, g.log + cfg.log_blowup_factor, *tw, s);
-      }
-    }
-    if (with_merkle) t.merkle.commit_prepared(s);
-  }
-  // Host pacing.  With the transcript steps behind a tree on the device the host COULD enqueue the whole next phase while the
-  // tree is still being built — but the next phase forks over side streams, and fork waits that sit blocked at the head of
-  // the other hardware queues for milliseconds slow the dispatch of the running stream's ~100 small launches: +0.2 ms per
-  // tree (CM_PACE=0 shows it; even 0.8 ms of blocked waits cost 50-80 us).  So the host lets the stream drain behind the
-  // device-side step and only then enqueues the next phase: one launch latency instead of two or three host round trips.
-  // With several proofs in flight (cm_prove_many) other proofs' kernels fill the dispatch slack and running ahead is the
-  // better choice (10.3 vs 10.5 ms per proof with 4 in flight), so pacing applies to a lone proof only.
-  void pace() {
-    static const int mode = getenv("CM_PACE") ? atoi(getenv("CM_PACE")) : -1;   // 0 = always run ahead, 1 = always drain (A/B)
-    const bool drain = mode == 1 || (mode != 0 && g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);
-    if (drain) CM_HIP(hipStreamSynchronize(st));
-  }
-};
-
 // Optional cache of tree 0.  The preprocessed columns are constants (preprocessed/mod.rs:75-82), so their
 // coefficients, LDE and Merkle tree are the same for every proof of one PCS config.  OFF by default — a proof then
 // recomputes them like the reference does (prover.rs:70-73) and bench.py times that; cm_set_preprocessed_cache(1) or
@@ -357,15 +160,6 @@ struct PreprocessedCache {
 };
 static thread_local PreprocessedCache tl_pp_cache;
 
-// FRI layers of at most 2^fri_tail_log() points are all handled by one single-block launch (k_fri_tail).
-static uint32_t fri_tail_log() {
-  static const uint32_t v = [] {
-    const char* e = getenv("CM_FRI_TAIL_LOG");
-    uint32_t x = e ? (uint32_t)atoi(e) : FRI_TAIL_DEFAULT_LOG;
-    return std::min(std::max(x, 1u), FRI_TAIL_MAX_LOG);
-  }();
-  return v;
-}
 
 // CM_NO_SMALL_BATCH=1: one launch per small component again (A/B of the batched small-component kernels)
 static bool no_small_batch() { static const bool v = getenv("CM_NO_SMALL_BATCH") != nullptr; return v; }
@@ -414,320 +208,6 @@ static F coset_vanishing_canonic(uint32_t log, CPoint<F> p) {
   F x = p.x;
   for (uint32_t i = 1; i < log; i++) x = double_x(x);
   return x;
-}
-
-struct Queries {
-  std::vector<uint32_t> positions;
-  uint32_t log_domain_size;
-  // Queries::generate: n_queries draws of log_domain_size bits, sorted and de-duplicated (BTreeSet order)
-  template <class Ch>
-  static Queries draw(Ch& ch, uint32_t n_queries, uint32_t log_domain_size) {
-    Queries q;
-    q.log_domain_size = log_domain_size;
-    std::vector<uint32_t>& s = q.positions;
-    s.reserve(n_queries);
-    const uint32_t mask = (1u << log_domain_size) - 1;
-    uint32_t cnt = 0;
-    bool done = false;
-    while (!done) {
-      auto b = ch.draw_random_bytes();
-      for (int k = 0; k < 8 && !done; k++) {
-        uint32_t w;
-        memcpy(&w, b.data() + 4 * k, 4);
-        s.push_back(w & mask);
-        if (++cnt == n_queries) done = true;
-      }
-    }
-    std::sort(s.begin(), s.end());
-    s.erase(std::unique(s.begin(), s.end()), s.end());
-    return q;
-  }
-  Queries fold(uint32_t n) const {
-    Queries q;
-    q.log_domain_size = log_domain_size - n;
-    for (auto p : positions) { uint32_t f = p >> n; if (q.positions.empty() || q.positions.back() != f) q.positions.push_back(f); }
-    return q;
-  }
-};
-
-// 4-coordinate values at `pos` of a SecureColumnByCoords, through a GatherBatch
-struct QGather { size_t w0 = 0, n = 0; };
-static QGather plan_gather_q(const uint32_t* const col4[4], const std::vector<uint32_t>& pos, GatherBatch& gb) {
-  QGather g;
-  g.w0 = gb.word_addrs.size();
-  g.n = pos.size();
-  for (auto p : pos) for (int k = 0; k < 4; k++) gb.add_word(col4[k] + p);
-  return g;
-}
-static void finish_gather_q(const QGather& g, const GatherBatch& gb, std::vector<QM31>& out) {
-  out.reserve(out.size() + g.n);
-  for (size_t i = 0; i < g.n; i++) out.push_back(QM31::from_u32(&gb.words[g.w0 + 4 * i]));
-}
-// compute_decommitment_positions_and_witness_evals (fold step 1): decommitment positions + witness requests
-static QGather plan_fri_positions(const uint32_t* const col4[4], const std::vector<uint32_t>& queries, std::vector<uint32_t>& positions,
-                                  GatherBatch& gb) {
-  std::vector<uint32_t> wpos;
-  wpos.reserve(queries.size());
-  positions.reserve(2 * queries.size());
-  size_t i = 0;
-  while (i < queries.size()) {
-    uint32_t start = (queries[i] >> 1) << 1;
-    size_t j = i;
-    while (j < queries.size() && (queries[j] >> 1) == (queries[i] >> 1)) j++;
-    size_t qi = i;
-    for (uint32_t pos = start; pos < start + 2; pos++) {
-      positions.push_back(pos);
-      if (qi < j && queries[qi] == pos) { qi++; continue; }
-      wpos.push_back(pos);
-    }
-    i = j;
-  }
-  return plan_gather_q(col4, wpos, gb);
-}
-
-// FRI commit phase of stwo `prove` (prover.rs:131): first-layer tree over the DEEP quotient columns, circle / line folds, one
-// tree per inner layer, the last layer's polynomial — with the transcript steps between the layers on the device.  Shared by
-// the single-GPU prover and the sharded one (where FRI is replicated on every rank).  Leaves the trees and layer evaluations
-// in place for the decommitment.
-struct FriPhase {
-  struct InnerLayer { ColumnSet eval; uint32_t log; MerkleTree tree; hostch::Hash32 root; };
-  MerkleTree first_tree;
-  std::vector<std::unique_ptr<InnerLayer>> inner;
-  void commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
-              const std::function<void()>& while_gpu_busy);
-  // Decommitment of the FRI trees (first layer over the quotient columns, then one tree per inner layer): decommitment
-  // positions + witness evaluations of every layer are requested through the caller's GatherBatch (one gather launch for the
-  // whole proof), finish_decommit() distributes what came back.
-  std::vector<QGather> first_w, inner_w;
-  DecommitPlan first_plan;
-  std::vector<DecommitPlan> inner_plan;
-  void plan_decommit(const Queries& queries, const std::map<uint32_t, std::vector<uint32_t>>& qpos, const std::vector<ColumnSet>& quotients,
-                     const std::vector<uint32_t>& q_logs, GatherBatch& gb) {
-    std::map<uint32_t, std::vector<uint32_t>> first_dpos;
-    for (size_t k = 0; k < quotients.size(); k++) {
-      const uint32_t* c4[4] = {quotients[k].ptrs[0], quotients[k].ptrs[1], quotients[k].ptrs[2], quotients[k].ptrs[3]};
-      std::vector<uint32_t> pos;
-      first_w.push_back(plan_fri_positions(c4, qpos.at(q_logs[k]), pos, gb));
-      first_dpos[q_logs[k]] = std::move(pos);
-    }
-    first_plan = first_tree.plan_decommit(first_dpos, gb);
-    Queries lq = queries.fold(1);
-    for (auto& il : inner) {
-      const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
-      std::vector<uint32_t> pos;
-      inner_w.push_back(plan_fri_positions(c4, lq.positions, pos, gb));
-      inner_plan.push_back(il->tree.plan_decommit(il->log, pos, gb));
-      lq = lq.fold(1);
-    }
-  }
-  void finish_decommit(const GatherBatch& gb, ProofData& pf) const {
-    for (auto& g : first_w) finish_gather_q(g, gb, pf.fri_first.fri_witness);
-    {
-      std::vector<uint32_t> qv;
-      MerkleTree::finish_decommit(first_plan, gb, qv, pf.fri_first.decommitment);
-    }
-    for (size_t i = 0; i < inner.size(); i++) {
-      FriLayerProofData lp;
-      finish_gather_q(inner_w[i], gb, lp.fri_witness);
-      std::vector<uint32_t> qv;
-      MerkleTree::finish_decommit(inner_plan[i], gb, qv, lp.decommitment);
-      lp.commitment = inner[i]->root;
-      pf.fri_inner.push_back(std::move(lp));
-    }
-  }
-};
-void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
-                      const std::function<void()>& while_gpu_busy) {
-  hipStream_t st = P.st;
-  Channel& ch = P.ch;
-  // ---- FRI commit ----
-  // The whole commit phase is enqueued without a host round trip: after each layer's Merkle tree a 1-thread
-  // kernel does the transcript step (mix_root, draw the folding challenge) on a device copy of the channel,
-  // and the fold kernels read the challenge from device memory.  The host replays the same steps on its own
-  // channel afterwards from the recorded roots and checks that the challenges agree.
-  const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup_factor;
-  uint32_t layer_log = q_logs[0] - 1;
-  const uint32_t n_inner = layer_log > last_log ? layer_log - last_log : 0;
-  DevBuf d_chan(64), d_alphas((size_t)(n_inner + 1) * 16), d_roots((size_t)(n_inner + 1) * 32);
-  {
-    uint32_t cw[9];
-    memcpy(cw, ch.digest.data(), 32);
-    cw[8] = ch.n_sent;
-    stage_upload(d_chan.p, cw, sizeof(cw), st);
-  }
-  // every layer above the single-launch tail is allocated up front so that the column tables of all their
-  // Merkle trees (and of the first-layer tree) travel in ONE host->device copy
-  std::vector<std::unique_ptr<InnerLayer>> pre;
-  DevBuf fri_tables;
-  {
-    UploadBatch ub;
-    std::vector<const uint32_t*> cols;
-    std::vector<uint32_t> logs;
-    for (size_t k = 0; k < quotients.size(); k++) for (int c = 0; c < 4; c++) { cols.push_back(quotients[k].ptrs[c]); logs.push_back(q_logs[k]); }
-    first_tree.prepare(cols, logs);
-    ub.add(first_tree.cols, &first_tree.d_cols_view);
-    for (uint32_t l = layer_log; l > last_log && l > fri_tail_log(); l--) {
-      std::unique_ptr<InnerLayer> il(new InnerLayer());
-      il->log = l;
-      il->eval.alloc(std::vector<uint32_t>(4, l), st, false);
-      std::vector<const uint32_t*> lc(il->eval.ptrs.begin(), il->eval.ptrs.end());
-      il->tree.prepare(lc, std::vector<uint32_t>(4, l));
-      ub.add(il->tree.cols, &il->tree.d_cols_view);
-      pre.push_back(std::move(il));
-    }
-    fri_tables = ub.flush(st);
-    first_tree.commit_prepared(st);
-    chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
-  }
-  ColumnSet layer;
-  bool layer_is_blank = !pre.empty();   // pre[0] is written (not accumulated into) by the first circle fold: no memset
-  if (pre.empty()) {
-    layer.alloc(std::vector<uint32_t>(4, layer_log), st, false);
-    CM_HIP(hipMemsetAsync(layer.buf.p, 0, layer.buf.bytes, st));
-  }
-  size_t qi = 0, pi = 0;
-  const QM31 unused_alpha;
-  while (layer_log > last_log) {
-    if (layer_log <= fri_tail_log()) {
-      // every remaining layer in one launch (k_fri_tail); buffers are laid out here so that the decommitment
-      // code sees ordinary InnerLayer objects afterwards
-      FriTailArgs ta;
-      memset(&ta, 0, sizeof(ta));
-      ta.tw = view(*P.tw);
-      ta.top_log = layer_log; ta.last_log = last_log;
-      ta.first_index = (uint32_t)inner.size() + 1;
-      ta.chan = d_chan.u32(); ta.alphas = d_alphas.u32(); ta.roots = d_roots.u32();
-      for (uint32_t l = layer_log; l > last_log; l--) {
-        std::unique_ptr<InnerLayer> il(new InnerLayer());
-        il->log = l;
-        if (l == layer_log) il->eval = std::move(layer);
-        else il->eval.alloc(std::vector<uint32_t>(4, l), st, false);
-        FriTailLayer& tl = ta.layers[l];
-        for (int c = 0; c < 4; c++) tl.cols[c] = il->eval.ptrs[c];
-        while (qi < quotients.size() && q_logs[qi] - 1 == l) {
-          CM_CHECK(tl.circle[0] == nullptr, "fri: two quotient groups of one size");
-          for (int c = 0; c < 4; c++) tl.circle[c] = quotients[qi].ptrs[c];
-          qi++;
-        }
-        MerkleTree& mt = il->tree;
-        mt.cols.assign(il->eval.ptrs.begin(), il->eval.ptrs.end());
-        mt.col_logs.assign(4, l);
-        mt.layers.resize(l + 1);
-        for (uint32_t k = 0; k <= l; k++) { mt.layers[k].alloc((size_t)32 << k); tl.merkle[k] = mt.layers[k].u32(); }
-        inner.push_back(std::move(il));
-      }
-      layer = ColumnSet();
-      layer.alloc(std::vector<uint32_t>(4, last_log), st, false);
-      for (int c = 0; c < 4; c++) ta.layers[last_log].cols[c] = layer.ptrs[c];
-      fri_tail(ta, st);
-      layer_log = last_log;
-      break;
-    }
-    // layers above the tail: buffers and tree tables were prepared above (pre[pi])
-    InnerLayer* cur = pre[pi].get();
-    while (qi < quotients.size() && q_logs[qi] - 1 == layer_log) {
-      const uint32_t* src[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
-      uint32_t* dst[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
-      fold_circle_into_line(dst, src, q_logs[qi], *P.tw, unused_alpha, !layer_is_blank, st, d_alphas.u32());
-      layer_is_blank = false;
-      qi++;
-    }
-    CM_CHECK(!layer_is_blank, "fri: the first layer received no quotient column");
-    cur->tree.commit_prepared(st);
-    const size_t li = inner.size() + 1;
-    chan_mix_root_draw(d_chan.u32(), cur->tree.layers[0].u32(), d_alphas.u32() + 4 * li, d_roots.u32() + 8 * li, st);
-    // fold into the next layer: the next pre-allocated one, or a fresh buffer that the tail / last layer takes over
-    uint32_t* dst[4];
-    if (pi + 1 < pre.size()) {
-      for (int c = 0; c < 4; c++) dst[c] = pre[pi + 1]->eval.ptrs[c];
-    } else {
-      layer = ColumnSet();
-      layer.alloc(std::vector<uint32_t>(4, layer_log - 1), st, false);
-      for (int c = 0; c < 4; c++) dst[c] = layer.ptrs[c];
-    }
-    const uint32_t* src[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
-    // the quotient columns of the next layer's size are folded in by the same kernel (the single-launch tail does its own)
-    const bool next_outside_tail = pi + 1 < pre.size();
-    if (next_outside_tail && qi < quotients.size() && q_logs[qi] == layer_log &&
-        !(qi + 1 < quotients.size() && q_logs[qi + 1] == layer_log)) {
-      const uint32_t* circ[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
-      fold_line_and_circle(dst, src, circ, layer_log, *P.tw, st, d_alphas.u32() + 4 * li, d_alphas.u32());
-      qi++;
-    } else {
-      fold_line(dst, src, layer_log, *P.tw, unused_alpha, st, d_alphas.u32() + 4 * li);
-    }
-    layer_log--;
-    inner.push_back(std::move(pre[pi]));
-    pi++;
-  }
-  CM_CHECK(qi == quotients.size(), "fri: not every quotient column was folded");
-  while_gpu_busy();   // host-only work of the caller, overlapped with the quotient / FRI kernels enqueued above
-
-  // last layer (2^last_log values): interpolate on the host, keep 2^log_last_layer coefficients
-  {
-    uint32_t n = 1u << last_log;
-    const uint32_t* c4[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
-    std::vector<uint32_t> pos(n);
-    for (uint32_t i = 0; i < n; i++) pos[i] = i;
-    std::vector<QM31> vals;
-    // challenges, roots and the last layer come back in ONE round trip (pinned slots; a large last layer falls back to the
-    // batched gather)
-    CM_CHECK((n_inner + 1) * 4 <= PIN_ROOTS - PIN_ALPHAS && (n_inner + 1) * 8 <= PIN_LAST_LAYER - PIN_ROOTS, "fri: too many layers");
-    const uint32_t* h_alphas = pinned_words() + PIN_ALPHAS;
-    const uint32_t* h_roots = pinned_words() + PIN_ROOTS;
-    CM_HIP(hipMemcpyAsync((void*)h_alphas, d_alphas.p, (size_t)(n_inner + 1) * 16, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync((void*)h_roots, d_roots.p, (size_t)(n_inner + 1) * 32, hipMemcpyDeviceToHost, st));
-    if (4 * n <= PIN_WORDS - PIN_LAST_LAYER) {
-      uint32_t* ll = pinned_words() + PIN_LAST_LAYER;
-      for (int k = 0; k < 4; k++) CM_HIP(hipMemcpyAsync(ll + k * n, c4[k], n * 4, hipMemcpyDeviceToHost, st));
-      CM_HIP(hipStreamSynchronize(st));
-      for (uint32_t i = 0; i < n; i++) {
-        uint32_t w4[4] = {ll[i], ll[n + i], ll[2 * n + i], ll[3 * n + i]};
-        vals.push_back(QM31::from_u32(w4));
-      }
-    } else {
-      GatherBatch gb;
-      QGather g = plan_gather_q(c4, pos, gb);
-      gb.run(st);  // synchronises the stream: roots / challenges are on the host now
-      finish_gather_q(g, gb, vals);
-    }
-    // host replay of the device-side transcript steps
-    CM_CHECK(inner.size() == n_inner, "fri: layer count mismatch");
-    for (size_t li = 0; li <= n_inner; li++) {
-      hostch::Hash32 root;
-      memcpy(root.data(), &h_roots[8 * li], 32);
-      ch.mix_root(root);
-      QM31 alpha = ch.draw_felt();
-      CM_CHECK(alpha == QM31::from_u32(&h_alphas[4 * li]), "fri: device transcript diverged from the host channel");
-      if (li == 0) pf.fri_first.commitment = root;
-      else inner[li - 1]->root = root;
-    }
-    for (uint32_t l = 0; l < last_log; l++) {
-      uint32_t stride = 1u << l;
-      for (uint32_t h = 0; h < (n >> (l + 1)); h++) {
-        // LineDomain(half_odds(last_log)) doubled l times: coset half_odds(last_log - l); point bitrev(h)
-        uint32_t clog_ = last_log - l;
-        uint32_t idx = subgroup_gen_index(clog_ + 2) + subgroup_gen_index(clog_) * bit_reverse(h, clog_ - 1);
-        M31 xinv = inv(point_at_index(idx).x);
-        for (uint32_t k = 0; k < stride; k++) {
-          uint32_t i0 = (h << (l + 1)) + k, i1 = i0 + stride;
-          QM31 a = vals[i0], b = vals[i1];
-          vals[i0] = a + b;
-          vals[i1] = (a - b) * xinv;
-        }
-      }
-    }
-    // `vals` sits in bit-reversed evaluation order, so after the in-place transform position p holds the coefficient of
-    // the basis element of degree p (= LinePoly::into_ordered_coefficients); the proof keeps the first 2^bound of them
-    // in LinePoly's own bit-reversed order (from_ordered_coefficients).
-    M31 ninv = inv(M31::from_u32(n));
-    uint32_t keep = 1u << cfg.log_last_layer_degree_bound;
-    for (uint32_t i = keep; i < n; i++) CM_CHECK(vals[i].is_zero(), "fri: last layer has invalid degree");
-    pf.last_layer_poly.assign(keep, QM31());
-    for (uint32_t i = 0; i < keep; i++) pf.last_layer_poly[bit_reverse(i, cfg.log_last_layer_degree_bound)] = vals[i] * ninv;
-    pf.last_layer_log_size = cfg.log_last_layer_degree_bound;
-    ch.mix_felts(pf.last_layer_poly.data(), pf.last_layer_poly.size());
-  }
 }
 
 // log2 rows of every component, known from the input lengths (Claim::log_sizes)

@@ -1,0 +1,343 @@
+// Shared pieces of the segment provers (single-GPU prover.hip, sharded prover_sharded.inc) and of the FRI phase
+// (fri_phase.hip): column arenas, committed trees, the per-proof driver state `Prover` (stream, channel, phase events,
+// commitment of one tree), query sets and the FRI phase's interface.
+#pragma once
+#include "../../include/cairom_hip.h"
+#include "engine.hpp"
+#include "merkle_tree.hpp"
+#include "fri_kernels.hpp"
+#include "host_channel.hpp"
+#include "framing.hpp"
+#include "proof.hpp"
+#include "kprof.hpp"
+#include <atomic>
+#include <chrono>
+#include <memory>
+#include <map>
+#include <algorithm>
+#include <functional>
+
+namespace cm {
+
+using hostch::Channel;
+
+// ---- column sets -------------------------------------------------------------------------------------------
+constexpr size_t COL_SKEW_WORDS_DEFAULT = 0;   // A/B: CM_COL_SKEW_BYTES
+struct ColumnSet {
+  std::vector<uint32_t> logs;
+  std::vector<uint32_t*> ptrs;
+  DevBuf buf, d_ptrs;
+  uint32_t** d_view = nullptr;  // device pointer table living in somebody else's upload (UploadBatch)
+  // Column skew: the columns of a set are powers of two long, so without padding row r of EVERY column has the same address
+  // modulo the column size — a kernel that reads one row of many columns (Merkle leaves, DEEP quotients, constraints, LogUp:
+  // every lane-coalesced 256-byte run of a wave) then keeps hitting the same HBM channel / bank group.  Large columns are
+  // therefore laid out `skew_words()` apart in addition to their length (a multiple of 64 words: runs stay 256-byte aligned).
+  static size_t skew_words() {
+    static const size_t w = getenv("CM_COL_SKEW_BYTES") ? (size_t)atol(getenv("CM_COL_SKEW_BYTES")) / 4 : COL_SKEW_WORDS_DEFAULT;
+    return w & ~(size_t)63;
+  }
+  void alloc(const std::vector<uint32_t>& logs_, hipStream_t st, bool upload_ptrs = true, bool contiguous = false) {
+    logs = logs_;
+    const size_t skew = contiguous ? 0 : skew_words();
+    size_t total = 0;
+    for (auto l : logs) total += ((size_t)1 << l) + (l >= 14 ? skew : 0);
+    buf.alloc(total * 4);
+    ptrs.resize(logs.size());
+    size_t off = 0;
+    for (size_t i = 0; i < logs.size(); i++) { ptrs[i] = buf.u32() + off; off += ((size_t)1 << logs[i]) + (logs[i] >= 14 ? skew : 0); }
+    d_view = nullptr;
+    if (upload_ptrs) d_ptrs = upload(ptrs, st);
+  }
+  uint32_t* const* dev(size_t first = 0) const {
+    if (d_view) return d_view + first;
+    CM_CHECK(d_ptrs.p, "ColumnSet::dev(): pointer table was not uploaded");
+    return d_ptrs.as<uint32_t*>() + first;
+  }
+  size_t size() const { return logs.size(); }
+};
+
+// groups column indices by log size (descending) — used to batch FFT launches
+inline std::map<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> by_log(const std::vector<uint32_t>& logs) {
+  std::map<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> m;
+  for (uint32_t i = 0; i < logs.size(); i++) m[logs[i]].push_back(i);
+  return m;
+}
+
+struct CommittedTree {
+  ColumnSet coeffs, lde;
+  MerkleTree merkle;
+  hostch::Hash32 root;
+  DevBuf tables;  // one upload: pointer tables of coeffs / lde / the FFT groups / the Merkle column order
+};
+
+constexpr uint32_t FFT_CHUNK_MB_DEFAULT = 0;   // Infinity-Cache blocking of the transform sweeps (commit_enqueue); A/B: CM_FFT_CHUNK_MB
+inline std::atomic<int> g_transcript_log{0};     // cm_set_transcript_log: proofs record every Fiat-Shamir step (ProofData::transcript)
+inline std::atomic<int> g_proofs_in_flight{0};   // proofs being made by cm_prove_many runners right now (0 outside of it)
+struct Prover {
+  hipStream_t st = 0;
+  cm_pcs_config cfg;
+  Twiddles* tw = nullptr;
+  Channel ch;
+  CommittedTree trees[4];
+  std::vector<double> phase_ms;
+  std::chrono::steady_clock::time_point t0;
+
+  // Phase boundaries are HIP events on the prover stream, read back at the end of the proof: a host-side
+  // hipStreamSynchronize per phase drained the GPU at boundaries that need no host round trip (constraints ->
+  // composition commit, quotients -> FRI).  CM_HOST_TRACE=1 restores the synchronising form and prints host / wait times.
+  std::vector<hipEvent_t> evs;
+  static std::vector<hipEvent_t>& event_cache() { static thread_local std::vector<hipEvent_t> c; return c; }
+  hipEvent_t next_event() {
+    auto& c = event_cache();
+    if (evs.size() == c.size()) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); c.push_back(e); }
+    evs.push_back(c[evs.size()]);
+    return evs.back();
+  }
+  void start() {
+    t0 = std::chrono::steady_clock::now();
+    CM_HIP(hipEventRecord(next_event(), st));
+  }
+  void tick(const char* name) {
+    static const bool trace = getenv("CM_HOST_TRACE") != nullptr;
+    CM_HIP(hipEventRecord(next_event(), st));
+    if (!trace) return;
+    auto te = std::chrono::steady_clock::now();
+    CM_HIP(hipStreamSynchronize(st));
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[phase] %-20s host %8.1f us, then waited %8.1f us for the GPU\n", name,
+            std::chrono::duration<double, std::micro>(te - t0).count(), std::chrono::duration<double, std::micro>(t1 - te).count());
+    t0 = t1;
+  }
+  void finish() {   // the stream is idle (the decommitment gather has been read back)
+    CM_HIP(hipEventSynchronize(evs.back()));
+    for (size_t k = 1; k < evs.size(); k++) {
+      float ms = 0;
+      CM_HIP(hipEventElapsedTime(&ms, evs[k - 1], evs[k]));
+      phase_ms.push_back(ms);
+    }
+  }
+
+  // IFFT src(evals, trace domain) -> tree.coeffs; LDE -> tree.lde; Merkle; mix root.
+  // If `in_place`, coeffs aliases src (src is consumed).
+  void commit(CommittedTree& t, ColumnSet* evals, bool from_coeffs) {
+    commit_enqueue(t, evals, from_coeffs, st);
+    commit_finish(t);
+  }
+  // the root comes back on the prover stream (which has joined the stream the tree was built on) and goes into the transcript
+  void commit_finish(CommittedTree& t) {
+    t.merkle.root(t.root.data(), st);
+    ch.mix_root(t.root);
+  }
+  // everything of a commitment except the root read-back, on stream `s` (tree 0 is built on a side stream while the
+  // execution trace is generated: both are chains of small launches)
+  // small_evals_in_place: with from_coeffs, the SMALL columns of t.coeffs (small_commit_serves) still hold evaluations —
+  // the caller interpolated only the large ones — and the fused small-column kernel interpolates them in place
+  void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true,
+                      bool small_evals_in_place = false) {
+    const std::vector<uint32_t> logs = from_coeffs ? t.coeffs.logs : evals->logs;
+    UploadBatch ub;
+    if (!from_coeffs) { t.coeffs.alloc(logs, s, false); ub.add(t.coeffs.ptrs, &t.coeffs.d_view); }
+    std::vector<uint32_t> lde_logs(logs);
+    for (auto& l : lde_logs) l += cfg.log_blowup_factor;
+    t.lde.alloc(lde_logs, s, false);
+    ub.add(t.lde.ptrs, &t.lde.d_view);
+    // pointer table of all size groups of the tree: [src | coeffs | lde] per group
+    struct Grp { uint32_t log, n; size_t off; };
+    std::vector<Grp> grps;
+    std::vector<const uint32_t*> table;
+    for (auto& kv : by_log(logs)) {
+      Grp g{kv.first, (uint32_t)kv.second.size(), table.size()};
+      for (auto i : kv.second) table.push_back(from_coeffs ? nullptr : evals->ptrs[i]);
+      for (auto i : kv.second) table.push_back(t.coeffs.ptrs[i]);
+      for (auto i : kv.second) table.push_back(t.lde.ptrs[i]);
+      grps.push_back(g);
+    }
+    const uint32_t** d_table = nullptr;
+    ub.add(table, &d_table);
+    std::vector<const uint32_t*> cols(t.lde.ptrs.begin(), t.lde.ptrs.end());
+    if (with_merkle) {        // (the sharded prover hashes row slices of the LDE instead: prover_sharded.inc)
+      t.merkle.prepare(cols, t.lde.logs);
+      ub.add(t.merkle.cols, &t.merkle.d_cols_view);
+    }
+    // small columns of every size: ONE fused interpolate + extend launch for all of them (k_small_commit)
+    std::vector<SmallCommitJob> sjobs;
+    uint32_t small_max = 0;
+    for (size_t i = 0; i < logs.size(); i++)
+      if (small_commit_serves(logs[i], cfg.log_blowup_factor)) {
+        const uint32_t* src = !from_coeffs ? evals->ptrs[i] : small_evals_in_place ? t.coeffs.ptrs[i] : nullptr;
+        sjobs.push_back(SmallCommitJob{src, t.coeffs.ptrs[i], t.lde.ptrs[i], logs[i], inv(M31::from_u32(1u << logs[i])).v});
+        small_max = std::max(small_max, logs[i]);
+      }
+    SmallCommitJob* d_sjobs = nullptr;
+    if (!sjobs.empty()) ub.add(sjobs, &d_sjobs);
+    t.tables = ub.flush(s);   // ONE host->device copy for the whole tree
+    small_commit(d_sjobs, (uint32_t)sjobs.size(), small_max, cfg.log_blowup_factor, *tw, s);
+    for (auto& g : grps) {
+      if (small_commit_serves(g.log, cfg.log_blowup_factor)) continue;
+      const uint32_t* const* dsrc = d_table + g.off;
+      uint32_t* const* dco = (uint32_t* const*)(d_table + g.off + g.n);
+      uint32_t* const* dld = (uint32_t* const*)(d_table + g.off + 2 * g.n);
+      // Infinity-Cache blocking: the four sweeps of a column (IFFT 2 passes, LDE 2 passes) are issued back to back for a CHUNK
+      // of columns whose working set (evaluations + coefficients + LDE) fits the 256 MiB L3, so every sweep after the first
+      // reads what the previous one just wrote from the on-die cache instead of HBM.  CM_FFT_CHUNK_MB: working-set budget
+      // (0 = whole group per sweep, the round-2 order).
+      static const uint32_t chunk_mb = getenv("CM_FFT_CHUNK_MB") ? (uint32_t)atoi(getenv("CM_FFT_CHUNK_MB")) : FFT_CHUNK_MB_DEFAULT;
+      uint32_t per = g.n;
+      if (chunk_mb) {
+        const uint64_t col_bytes = ((uint64_t)4 << g.log) * (from_coeffs ? 1 : 2) + ((uint64_t)4 << (g.log + cfg.log_blowup_factor));
+        per = (uint32_t)std::max<uint64_t>(1, ((uint64_t)chunk_mb << 20) / col_bytes);
+        if (per >= g.n || (g.log < 16)) per = g.n;
+      }
+      for (uint32_t c0 = 0; c0 < g.n; c0 += per) {
+        const uint32_t nc = std::min(per, g.n - c0);
+        if (!from_coeffs) interpolate_oop(dsrc + c0, dco + c0, nc, g.log, *tw, s);
+        evaluate((const uint32_t* const*)dco + c0, dld + c0, nc, g.log, g.log + cfg.log_blowup_factor, *tw, s);
+      }
+    }
+    if (with_merkle) t.merkle.commit_prepared(s);
+  }
+  // Host pacing.  With the transcript steps behind a tree on the device the host COULD enqueue the whole next phase while the
+  // tree is still being built — but the next phase forks over side streams, and fork waits that sit blocked at the head of
+  // the other hardware queues for milliseconds slow the dispatch of the running stream's ~100 small launches: +0.2 ms per
+  // tree (CM_PACE=0 shows it; even 0.8 ms of blocked waits cost 50-80 us).  So the host lets the stream drain behind the
+  // device-side step and only then enqueues the next phase: one launch latency instead of two or three host round trips.
+  // With several proofs in flight (cm_prove_many) other proofs' kernels fill the dispatch slack and running ahead is the
+  // better choice (10.3 vs 10.5 ms per proof with 4 in flight), so pacing applies to a lone proof only.
+  void pace() {
+    static const int mode = getenv("CM_PACE") ? atoi(getenv("CM_PACE")) : -1;   // 0 = always run ahead, 1 = always drain (A/B)
+    const bool drain = mode == 1 || (mode != 0 && g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);
+    if (drain) CM_HIP(hipStreamSynchronize(st));
+  }
+};
+
+// FRI layers of at most 2^fri_tail_log() points are all handled by one single-block launch (k_fri_tail).
+inline uint32_t fri_tail_log() {
+  static const uint32_t v = [] {
+    const char* e = getenv("CM_FRI_TAIL_LOG");
+    uint32_t x = e ? (uint32_t)atoi(e) : FRI_TAIL_DEFAULT_LOG;
+    return std::min(std::max(x, 1u), FRI_TAIL_MAX_LOG);
+  }();
+  return v;
+}
+
+struct Queries {
+  std::vector<uint32_t> positions;
+  uint32_t log_domain_size;
+  // Queries::generate: n_queries draws of log_domain_size bits, sorted and de-duplicated (BTreeSet order)
+  template <class Ch>
+  static Queries draw(Ch& ch, uint32_t n_queries, uint32_t log_domain_size) {
+    Queries q;
+    q.log_domain_size = log_domain_size;
+    std::vector<uint32_t>& s = q.positions;
+    s.reserve(n_queries);
+    const uint32_t mask = (1u << log_domain_size) - 1;
+    uint32_t cnt = 0;
+    bool done = false;
+    while (!done) {
+      auto b = ch.draw_random_bytes();
+      for (int k = 0; k < 8 && !done; k++) {
+        uint32_t w;
+        memcpy(&w, b.data() + 4 * k, 4);
+        s.push_back(w & mask);
+        if (++cnt == n_queries) done = true;
+      }
+    }
+    std::sort(s.begin(), s.end());
+    s.erase(std::unique(s.begin(), s.end()), s.end());
+    return q;
+  }
+  Queries fold(uint32_t n) const {
+    Queries q;
+    q.log_domain_size = log_domain_size - n;
+    for (auto p : positions) { uint32_t f = p >> n; if (q.positions.empty() || q.positions.back() != f) q.positions.push_back(f); }
+    return q;
+  }
+};
+
+// 4-coordinate values at `pos` of a SecureColumnByCoords, through a GatherBatch
+struct QGather { size_t w0 = 0, n = 0; };
+inline QGather plan_gather_q(const uint32_t* const col4[4], const std::vector<uint32_t>& pos, GatherBatch& gb) {
+  QGather g;
+  g.w0 = gb.word_addrs.size();
+  g.n = pos.size();
+  for (auto p : pos) for (int k = 0; k < 4; k++) gb.add_word(col4[k] + p);
+  return g;
+}
+inline void finish_gather_q(const QGather& g, const GatherBatch& gb, std::vector<QM31>& out) {
+  out.reserve(out.size() + g.n);
+  for (size_t i = 0; i < g.n; i++) out.push_back(QM31::from_u32(&gb.words[g.w0 + 4 * i]));
+}
+// compute_decommitment_positions_and_witness_evals (fold step 1): decommitment positions + witness requests
+inline QGather plan_fri_positions(const uint32_t* const col4[4], const std::vector<uint32_t>& queries, std::vector<uint32_t>& positions,
+                                  GatherBatch& gb) {
+  std::vector<uint32_t> wpos;
+  wpos.reserve(queries.size());
+  positions.reserve(2 * queries.size());
+  size_t i = 0;
+  while (i < queries.size()) {
+    uint32_t start = (queries[i] >> 1) << 1;
+    size_t j = i;
+    while (j < queries.size() && (queries[j] >> 1) == (queries[i] >> 1)) j++;
+    size_t qi = i;
+    for (uint32_t pos = start; pos < start + 2; pos++) {
+      positions.push_back(pos);
+      if (qi < j && queries[qi] == pos) { qi++; continue; }
+      wpos.push_back(pos);
+    }
+    i = j;
+  }
+  return plan_gather_q(col4, wpos, gb);
+}
+
+// FRI commit phase of stwo `prove` (prover.rs:131): first-layer tree over the DEEP quotient columns, circle / line folds, one
+// tree per inner layer, the last layer's polynomial — with the transcript steps between the layers on the device.  Shared by
+// the single-GPU prover and the sharded one (where FRI is replicated on every rank).  Leaves the trees and layer evaluations
+// in place for the decommitment.
+struct FriPhase {
+  struct InnerLayer { ColumnSet eval; uint32_t log; MerkleTree tree; hostch::Hash32 root; };
+  MerkleTree first_tree;
+  std::vector<std::unique_ptr<InnerLayer>> inner;
+  void commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
+              const std::function<void()>& while_gpu_busy);
+  // Decommitment of the FRI trees (first layer over the quotient columns, then one tree per inner layer): decommitment
+  // positions + witness evaluations of every layer are requested through the caller's GatherBatch (one gather launch for the
+  // whole proof), finish_decommit() distributes what came back.
+  std::vector<QGather> first_w, inner_w;
+  DecommitPlan first_plan;
+  std::vector<DecommitPlan> inner_plan;
+  void plan_decommit(const Queries& queries, const std::map<uint32_t, std::vector<uint32_t>>& qpos, const std::vector<ColumnSet>& quotients,
+                     const std::vector<uint32_t>& q_logs, GatherBatch& gb) {
+    std::map<uint32_t, std::vector<uint32_t>> first_dpos;
+    for (size_t k = 0; k < quotients.size(); k++) {
+      const uint32_t* c4[4] = {quotients[k].ptrs[0], quotients[k].ptrs[1], quotients[k].ptrs[2], quotients[k].ptrs[3]};
+      std::vector<uint32_t> pos;
+      first_w.push_back(plan_fri_positions(c4, qpos.at(q_logs[k]), pos, gb));
+      first_dpos[q_logs[k]] = std::move(pos);
+    }
+    first_plan = first_tree.plan_decommit(first_dpos, gb);
+    Queries lq = queries.fold(1);
+    for (auto& il : inner) {
+      const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
+      std::vector<uint32_t> pos;
+      inner_w.push_back(plan_fri_positions(c4, lq.positions, pos, gb));
+      inner_plan.push_back(il->tree.plan_decommit(il->log, pos, gb));
+      lq = lq.fold(1);
+    }
+  }
+  void finish_decommit(const GatherBatch& gb, ProofData& pf) const {
+    for (auto& g : first_w) finish_gather_q(g, gb, pf.fri_first.fri_witness);
+    {
+      std::vector<uint32_t> qv;
+      MerkleTree::finish_decommit(first_plan, gb, qv, pf.fri_first.decommitment);
+    }
+    for (size_t i = 0; i < inner.size(); i++) {
+      FriLayerProofData lp;
+      finish_gather_q(inner_w[i], gb, lp.fri_witness);
+      std::vector<uint32_t> qv;
+      MerkleTree::finish_decommit(inner_plan[i], gb, qv, lp.decommitment);
+      lp.commitment = inner[i]->root;
+      pf.fri_inner.push_back(std::move(lp));
+    }
+  }
+};
+}  // namespace cm
