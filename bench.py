@@ -24,13 +24,17 @@ ALL_CPUS = os.sched_getaffinity(0)   # what the oracle's child process gets, wha
 
 FIB_N = 419_000          # 10*n + 12 = 4,190,012 VM steps (~2^22), one segment
 HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Integer-ALU ceilings of the two dominant kernel classes, from the measured gfx950 issue rates
-# (tools/valu_lab.hip: VOP2 int 2 cycles, VOP3 int 4 cycles, v_mad_u64_u32 5 cycles per wave-instruction per SIMD,
-# 1024 SIMDs, ~1.9 GHz sustained): a Blake2s compression is ~2890 issue cycles per wave, an M31 butterfly
-# (multiply + add + sub, arithmetic only) ~35.  DESIGN.md §3.
-ALU_PEAK = {"k_merkle_layer": (1024 * 1.9e9 / 2890 * 64, "Blake2s compressions/s"),
-            "k_fft_pass<fft>": (1024 * 1.9e9 / 35 * 64, "M31 butterflies/s"),
-            "k_fft_pass<ifft>": (1024 * 1.9e9 / 35 * 64, "M31 butterflies/s")}
+# Integer-ALU ceilings of the two dominant kernel classes, from the chip-wide lane-op rates tools/valu_lab.hip measures on gfx950
+# (profiles/r03k_valu_lab.txt, no clock assumption): VOP2 v_xor 65.9 T, v_add 64.0 T lane-ops/s; VOP3 v_alignbit 37.9 T,
+# v_add3 35.85 T; v_mad_u64_u32 31.46 T.  A Blake2s compression is 336 xor + 160 add + 320 alignbit + 160 add3 per lane
+# (the plain op mix; the shipped kernel replaces 80 xor + 80 alignbit by 160 SDWA xors, which the lab rates would price
+# HIGHER although the kernel measures 5 % faster — the ceiling keeps the plain mix); an M31 butterfly is one mad_u64 + ~10 VOP2.
+_VOP2, _ADD, _ALIGN, _ADD3, _MAD64 = 65.9e12, 64.0e12, 37.9e12, 35.85e12, 31.46e12
+_B2S_PEAK = 1.0 / (336 / _VOP2 + 160 / _ADD + 320 / _ALIGN + 160 / _ADD3)       # ~4.9e10 compressions/s
+_BFLY_PEAK = 1.0 / (1 / _MAD64 + 10 / _VOP2)
+ALU_PEAK = {"k_merkle_layer": (_B2S_PEAK, "Blake2s compressions/s"),
+            "k_fft_pass<fft>": (_BFLY_PEAK, "M31 butterflies/s"),
+            "k_fft_pass<ifft>": (_BFLY_PEAK, "M31 butterflies/s")}
 MODEL_BYTES_PER_CELL = 52.0  # SURVEY §8d algorithmic-bytes model for the whole path
 
 
@@ -426,7 +430,8 @@ def main():
                         "avg_launch_ms": k["ms"] / k["calls"], "launches": k["calls"],
                         "alu": ({"unit": ALU_PEAK[name][1], "achieved": k.get("work", 0.0) / (k["ms"] * 1e-3),
                                  "peak": ALU_PEAK[name][0], "frac": k.get("work", 0.0) / (k["ms"] * 1e-3) / ALU_PEAK[name][0],
-                                 "note": "this class is integer-VALU-bound, not HBM-bound (DESIGN.md §3); peak from measured gfx950 issue rates"}
+                                 "note": "this class is integer-VALU-bound, not HBM-bound (DESIGN.md §3); peak = 1 / sum(ops_i / measured lane-op rate_i), "
+                                         "rates from profiles/r03k_valu_lab.txt (tools/valu_lab.hip)"}
                                 if name in ALU_PEAK and k.get("work") else None),
                         "algorithmic_bytes_per_launch": k["bytes"] / k["calls"],
                         "whole_path_model": {"bytes_per_cell": MODEL_BYTES_PER_CELL,

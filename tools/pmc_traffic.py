@@ -26,7 +26,7 @@ import sys
 CLASSES = [
     (r"k_fft_pass(_r8|_rb)?<(false|0)", "k_fft_pass<fft>"),
     (r"k_fft_pass(_r8|_rb)?<(true|1)", "k_fft_pass<ifft>"),
-    (r"k_merkle_layer", "k_merkle_layer"),
+    (r"k_merkle_layer|k_merkle_narrow", "k_merkle_layer"),   # one kprof class: the narrow-layer kernel serves the same launches
     (r"k_merkle_multi", "k_merkle_multi"),
     (r"k_merkle_tail", "k_merkle_tail"),
     (r"k_quotients", "k_quotients"),
