@@ -50,8 +50,11 @@ void eval_at_point_batch(const uint32_t* const* d_coeffs, uint32_t ncols, uint32
                          uint32_t* d_scratch, uint32_t* d_out, hipStream_t st);
 
 // every (log size, point) sampling group of a proof in three launches; d_out receives 4 * ncols words per job
-struct EapJob { uint32_t log_n, ncols; const uint32_t* const* d_coeffs; QM31 px, py; uint32_t* d_out; };
-void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st);
+struct EapJob { uint32_t log_n, ncols; const uint32_t* const* d_coeffs; QM31 px, py; uint32_t* d_out;
+                bool has_shift = false; uint32_t shift_x = 0, shift_y = 0; };
+// d_oods_t != null: every job samples at the OODS point derived ON THE DEVICE from the felt at d_oods_t (4 words; the draw of
+// CirclePoint::get_random_point), plus the job's M31 shift (has_shift: the previous-row mask point) — px / py are ignored
+void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st, const uint32_t* d_oods_t = nullptr);
 
 // Merkle
 void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
@@ -196,10 +199,10 @@ struct DevBuf {
 // synchronised and until the next call on this thread.
 const void* stage_download_async(const void* src, size_t bytes, hipStream_t st);
 // 1024 pinned words per host thread; fixed slots (words): 0 range-check flag, 2-3 grind nonce, 8-15 Merkle root,
-// 16-23 root of tree 0, 32-175 claimed sums, 256-351 FRI challenges, 384-575 FRI roots, 640-1023 last FRI layer
+// 16-23 root of tree 0, 32-175 claimed sums, 208-211 the OODS felt of the device-side step, 256-351 FRI challenges, 384-575 FRI roots, 640-1023 last FRI layer
 uint32_t* pinned_words();
 constexpr uint32_t INTERACTION_POW_BITS = 2;   // relations::INTERACTION_POW_BITS (prover.rs:90, verifier.rs:55-58)
-enum PinnedSlot : uint32_t { PIN_FLAG = 0, PIN_NONCE = 2, PIN_ROOT = 8, PIN_ROOT0 = 16, PIN_SUMS = 32, PIN_ROOT2 = 176, PIN_COEFF = 184, PIN_STEP1 = 192, PIN_ALPHAS = 256, PIN_ROOTS = 384,
+enum PinnedSlot : uint32_t { PIN_FLAG = 0, PIN_NONCE = 2, PIN_ROOT = 8, PIN_ROOT0 = 16, PIN_SUMS = 32, PIN_ROOT2 = 176, PIN_COEFF = 184, PIN_STEP1 = 192, PIN_STEP3 = 208, PIN_ALPHAS = 256, PIN_ROOTS = 384,
                             PIN_LAST_LAYER = 640, PIN_WORDS = 1024 };
 // Small host->device uploads (pointer arrays, coefficients, positions) go through a pinned staging ring
 // and hipMemcpyAsync on the launch stream: no host sync, no pageable-copy stall.

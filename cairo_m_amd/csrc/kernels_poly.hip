@@ -291,8 +291,23 @@ struct EapJobDev {
   uint32_t block_begin;          // first block of this job in k_eval_partial_multi
   uint32_t col_begin;            // first (job, column) index of this job in k_reduce_partials_multi
   uint32_t ngroups;              // chunk groups per column
+  uint32_t shift_x, shift_y, has_shift;   // device-side OODS point: the job samples at oods + (shift_x, shift_y) (M31 point)
   uint32_t maps[32 * 4];         // QM31 factor of index bit k
 };
+// OODS point on the device (CirclePoint::get_random_point: t = draw_felt(); x = (1 - t^2) / (1 + t^2), y = 2t / (1 + t^2)) from
+// the felt the device-side transcript step left in HBM, shifted per job, expanded into the per-bit factors [y, x, pi(x), ...]:
+// the evaluation kernels start right behind the composition tree, without waiting for the host to see root 3.
+__global__ void __launch_bounds__(64) k_oods_maps(EapJobDev* __restrict__ jobs, uint32_t nj, const uint32_t* __restrict__ t4) {
+  const uint32_t k = threadIdx.x;
+  if (k >= nj) return;
+  EapJobDev& jb = jobs[k];
+  const QM31 t = QM31::from_u32(t4), t2 = t * t, iv = inv(t2 + M31(1));
+  CPoint<QM31> p{(QM31(M31(1)) - t2) * iv, (t + t) * iv};
+  if (jb.has_shift) p = cadd(p, CPoint<QM31>{QM31(M31(jb.shift_x)), QM31(M31(jb.shift_y))});
+  p.y.to_u32(jb.maps);
+  QM31 x = p.x;
+  for (uint32_t b = 1; b < jb.log_n; b++) { x.to_u32(jb.maps + 4 * b); x = double_x(x); }
+}
 __global__ void __launch_bounds__(256) k_point_tables_multi(const EapJobDev* __restrict__ jobs, uint32_t* __restrict__ scratch) {
   const EapJobDev& jb = jobs[blockIdx.y];
   const uint32_t low = jb.log_n < EAP2_LOW_BITS ? jb.log_n : EAP2_LOW_BITS;
@@ -562,7 +577,7 @@ void eval_at_point_batch(const uint32_t* const* d_coeffs, uint32_t ncols, uint32
   CM_HIP(hipGetLastError());
 }
 
-void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st) {
+void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st, const uint32_t* d_oods_t) {
   if (jobs.empty()) return;
 
   std::vector<EapJobDev> dj(jobs.size());
@@ -583,16 +598,23 @@ void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st) {
     CM_CHECK(words < ((size_t)1 << 32), "eval_at_point_multi: scratch too large");
     d.block_begin = blocks; blocks += j.ncols * ngroups;
     d.col_begin = cols; cols += j.ncols;
-    j.py.to_u32(d.maps);
-    QM31 x = j.px;
-    for (uint32_t b = 1; b < j.log_n; b++) { x.to_u32(d.maps + 4 * b); x = double_x(x); }
+    if (d_oods_t) {   // the point comes from the device (k_oods_maps): px / py carry the M31 shift of the job, or nothing
+      d.has_shift = j.has_shift ? 1u : 0u;
+      d.shift_x = j.shift_x; d.shift_y = j.shift_y;
+    } else {
+      j.py.to_u32(d.maps);
+      QM31 x = j.px;
+      for (uint32_t b = 1; b < j.log_n; b++) { x.to_u32(d.maps + 4 * b); x = double_x(x); }
+    }
     max_tab_blocks = std::max(max_tab_blocks, ((1u << std::max(low, high)) + 255) / 256);
     bytes += 4.0 * j.ncols * (double)((size_t)1 << j.log_n);
   }
   DevBuf d_jobs = upload(dj, st), scratch(words * 4);
   const EapJobDev* djp = d_jobs.as<EapJobDev>();
   const uint32_t nj = (uint32_t)jobs.size();
+  CM_CHECK(nj <= 64, "eval_at_point_multi: more than 64 sampling groups");
   KProfScope kp("k_eval_at_point", bytes, st);
+  if (d_oods_t) hipLaunchKernelGGL(k_oods_maps, dim3(1), dim3(64), 0, st, d_jobs.as<EapJobDev>(), nj, d_oods_t);
   hipLaunchKernelGGL(k_point_tables_multi, dim3(max_tab_blocks, nj, 2), dim3(256), 0, st, djp, scratch.u32());
   CM_CHECK(nj <= 64, "eval_at_point_multi: more than 64 sampling groups");
   EapStarts bstart, cstart;

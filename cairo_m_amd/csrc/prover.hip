@@ -284,8 +284,9 @@ static void check_composition_at_oods(const ProofData& pf, const std::vector<siz
   if (sum != comp) throw CmError(10, "ConstraintsNotSatisfied: composition polynomial does not match the constraints at the OODS point");
 }
 // the OODS point from one drawn felt t: ((1 - t^2) / (1 + t^2), 2t / (1 + t^2))
-static CPoint<QM31> draw_oods_point(Channel& ch) {
+static CPoint<QM31> draw_oods_point(Channel& ch, QM31* t_out = nullptr) {
   QM31 t = ch.draw_felt();
+  if (t_out) *t_out = t;
   QM31 t2 = t * t;
   QM31 iv = inv(t2 + M31(1));
   CPoint<QM31> p;
@@ -891,10 +892,46 @@ struct SegmentProver {
         (j.refs[i].prev ? sidx_prev : sidx_cur)[j.refs[i].t][j.refs[i].c] = (uint32_t)(j.out_off + i);
     pf.sampled_values.resize(4);
     for (int t = 0; t < 4; t++) pf.sampled_values[t].resize(P.trees[t].coeffs.size());
+    // Device-side OODS step (A/B: CM_HOST_OODS=1 restores the host form): the channel state after the coefficient draw is still
+    // in HBM (d_step2), so mix_root(root 3) + the draw of CirclePoint::get_random_point run on the device right behind the
+    // composition tree, k_oods_maps turns the felt into every job's point and per-bit factors, and the evaluation kernels
+    // start without the host having seen root 3 (it used to cost the host replay + the launches: ~60 us of idle GPU).  The host
+    // replays the same steps when root 3 arrives and checks the drawn felt.
+    static const bool dev_oods = getenv("CM_HOST_OODS") == nullptr;
+    static thread_local hipEvent_t ev_root3 = nullptr;
+    if (dev_oods) P.tick("composition_commit");
+    const uint32_t* oods_w = nullptr;
+    DevBuf d_step3;
+    if (dev_oods) {
+      d_step3.alloc(4 * (4 + 8));
+      uint32_t* d_chan = d_step2.u32();
+      chan_mix_root_draw(d_chan, P.trees[3].merkle.layers[0].u32(), d_step3.u32(), d_step3.u32() + 4, st);
+      // root 3 and the felt come back HERE in stream order — in front of the evaluation kernels enqueued next
+      CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT, P.trees[3].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, st));
+      CM_HIP(hipMemcpyAsync(pinned_words() + PIN_STEP3, d_step3.p, 16, hipMemcpyDeviceToHost, st));
+      if (!ev_root3) CM_HIP(hipEventCreateWithFlags(&ev_root3, hipEventDisableTiming));
+      CM_HIP(hipEventRecord(ev_root3, st));
+      std::vector<EapJob> ej;
+      for (auto& j : ojobs) {
+        EapJob e{j.log, (uint32_t)j.refs.size(), d_oods_table.as<const uint32_t*>() + j.off, QM31(), QM31(), d_oods_out.u32() + 4 * j.out_off};
+        if (j.prev) {
+          CPoint<M31> step = point_at_index(subgroup_gen_index(j.log));
+          e.has_shift = true; e.shift_x = step.x.v; e.shift_y = (-step.y).v;
+        }
+        ej.push_back(e);
+      }
+      eval_at_point_multi(ej, st, d_step3.u32());
+      oods_w = (const uint32_t*)stage_download_async(d_oods_out.p, n_oods_out * 16, st);
+    }
     // ONE round trip for two roots: root 3 is waited for; root 2 and the random coefficient of the device-side step are
     // already in pinned memory.  Host replay in transcript order.
     ht.mark("composition: enqueued, waiting for root 3");
-    P.trees[3].merkle.root(P.trees[3].root.data(), st);
+    if (dev_oods) {   // the root comes back behind the tree, NOT behind the evaluation kernels enqueued after it
+      CM_HIP(hipEventSynchronize(ev_root3));
+      memcpy(P.trees[3].root.data(), pinned_words() + PIN_ROOT, 32);
+    } else {
+      P.trees[3].merkle.root(P.trees[3].root.data(), st);
+    }
     ht.mark("composition: root 3 arrived");
     {
       memcpy(P.trees[2].root.data(), pinned_words() + PIN_ROOT2, 32);
@@ -906,7 +943,7 @@ struct SegmentProver {
     }
     ch.mix_root(P.trees[3].root);
     ht.mark("composition: host replay of the coefficient step");
-    P.tick("composition_commit");
+    if (!dev_oods) P.tick("composition_commit");
 
     // host side of compute_fri_quotients for every size group, packed into ONE upload:
     // [column pointers | out pointers | col_index | coef_c | batches] per group, 16-byte aligned
@@ -920,7 +957,11 @@ struct SegmentProver {
 
     ht.mark("(composition commit done)");
     // ---- OODS sampling ----
-    oods = draw_oods_point(ch);
+    {
+      QM31 t;
+      oods = draw_oods_point(ch, &t);
+      if (dev_oods) CM_CHECK(t == QM31::from_u32(pinned_words() + PIN_STEP3), "oods: device transcript diverged from the host channel");
+    }
     ht.mark("oods: point drawn");
     std::map<uint32_t, CPoint<QM31>> prev_points;
     {
@@ -940,9 +981,9 @@ struct SegmentProver {
           ej.push_back(EapJob{j.log, (uint32_t)j.refs.size(), d_oods_table.as<const uint32_t*>() + j.off, j.pt.x, j.pt.y,
                               dout.u32() + 4 * j.out_off});
         }
-        eval_at_point_multi(ej, st);
+        if (!dev_oods) eval_at_point_multi(ej, st);   // (device form: already running, from the felt of the device-side step)
       }
-      const uint32_t* w = (const uint32_t*)stage_download_async(dout.p, n_out * 16, st);   // read after the sync below
+      const uint32_t* w = dev_oods ? oods_w : (const uint32_t*)stage_download_async(dout.p, n_out * 16, st);   // read after the sync below
       ht.mark("oods: enqueued");
       // ---- while the evaluation kernels run: everything about the sampled values and the DEEP quotients
       // (compute_fri_quotients) that does not depend on the values themselves ----
