@@ -218,6 +218,77 @@ __device__ __forceinline__ void merkle_node_quad(const uint32_t* children, const
   }
 }
 
+// ---- wide layers: hundreds of columns on a few nodes (the 2^5-row layer of the interaction tree carries the ~1000 interaction
+// columns of the idle components: 66 chained compressions per node) ------------------------------------------------------------
+// The chain of a node is sequential, and a lone wave runs one quad-lane compression in ~0.7 us (tools/chain_lab.hip) — but with
+// the message words fetched inside the chain every 16-column block also waited for a pointer load and a column load from HBM
+// (~1.4 us per block, twice the hashing).  Here the whole BLOCK streams the layer's columns through LDS, one group of NT x R words
+// ahead of the hashing quads: the column pointers are copied to LDS once, group g + 1 is loaded into registers before the quads
+// hash group g and written to the other half of a double buffer afterwards, so no memory latency is left on the chain.
+constexpr uint32_t WIDE_PTR_CAP = 2048;   // columns whose pointers fit the LDS table (16 KiB)
+constexpr uint32_t WIDE_MIN_COLS = 48;    // below this a layer pays its one or two loads directly
+template <int NT, int R>
+struct WideLds {
+  unsigned long long ptrs[WIDE_PTR_CAP];
+  uint32_t buf[2][NT * R];   // group-local column-major: word (c, node) of a group at (c << log_n) + node
+};
+template <int NT, int R>
+__device__ __forceinline__ bool wide_layer_ok(uint32_t ncols, uint32_t log_n) {
+  return ncols >= WIDE_MIN_COLS && ncols <= WIDE_PTR_CAP && (16u << log_n) <= (uint32_t)(NT * R) && (4u << log_n) <= (uint32_t)NT;
+}
+// Every thread of the block calls this (barriers inside); the quad of lanes (node_local, q) of an `active` thread owns node
+// node0 + node_local of the layer and returns its hash words h[q], h[4 + q].  `children` = the node's 16 child words or null.
+template <bool RFC, int NT, int R>
+__device__ __forceinline__ void merkle_wide_quad(WideLds<NT, R>& w, const uint32_t* children, bool active,
+                                                 const uint32_t* const* __restrict__ cols, uint32_t c_begin, uint32_t c_end, uint32_t node0,
+                                                 uint32_t log_n, uint32_t node_local, uint32_t q, uint32_t tid, uint32_t& h0, uint32_t& h1) {
+  const uint32_t ncols = c_end - c_begin;
+  for (uint32_t c = tid; c < ncols; c += NT) w.ptrs[c] = (unsigned long long)cols[c_begin + c];
+  __syncthreads();
+  const uint32_t gcols = (uint32_t)(NT * R) >> log_n;                 // columns of a group: a multiple of 16
+  const uint32_t chunks = (ncols + 15u) >> 4, gchunks = gcols >> 4, ngroups = (chunks + gchunks - 1) / gchunks;
+  const uint32_t nmask = (1u << log_n) - 1u;
+  uint32_t v[R];
+#define CM_WIDE_ISSUE(g)                                                                        \
+  _Pragma("unroll") for (uint32_t k = 0; k < (uint32_t)R; k++) {                                \
+    const uint32_t e = tid + k * NT, cl = (g) * gcols + (e >> log_n);                           \
+    v[k] = cl < ncols ? CM_GCOL((const uint32_t*)w.ptrs[cl < ncols ? cl : 0u])[node0 + (e & nmask)] : 0u; \
+  }
+#define CM_WIDE_PUT(g)                                                                          \
+  _Pragma("unroll") for (uint32_t k = 0; k < (uint32_t)R; k++) w.buf[(g) & 1u][tid + k * NT] = v[k];
+  CM_WIDE_ISSUE(0u)
+  CM_WIDE_PUT(0u)
+  __syncthreads();
+  NodeFrame<RFC> fr(children != nullptr, ncols);
+  fr.init_quad(q, h0, h1);
+  uint32_t m[16];
+  if (active && children) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = children[k];
+    fr.absorb_quad(h0, h1, m, q, 64);
+  }
+#pragma unroll 1
+  for (uint32_t g = 0; g < ngroups; g++) {
+    const bool more = g + 1 < ngroups;
+    if (more) { CM_WIDE_ISSUE(g + 1u) }   // in flight while the quads hash group g
+    if (active) {
+      const uint32_t* b = w.buf[g & 1u];
+      const uint32_t j_end = min(gchunks, chunks - g * gchunks);
+#pragma unroll 1
+      for (uint32_t j = 0; j < j_end; j++) {
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) m[k] = b[((j * 16u + k) << log_n) + node_local];   // columns past the end were staged as zeros
+        const uint32_t c0 = (g * gchunks + j) * 16u;
+        fr.absorb_quad(h0, h1, m, q, 4u * min(16u, ncols - c0));
+      }
+    }
+    if (more) { CM_WIDE_PUT(g + 1u) }
+    __syncthreads();
+  }
+#undef CM_WIDE_ISSUE
+#undef CM_WIDE_PUT
+}
+
 // K consecutive layers (top_log, top_log-1, ..., top_log-K+1) in one launch.  A block hashes 256 nodes of the
 // top layer, keeps them in LDS, then 128 parents, 64 grand-parents, ...  Every layer is written to HBM (the
 // decommitment gathers need it) but intermediate layers are never re-read from HBM, and a 2^22 tree needs
@@ -285,15 +356,18 @@ __global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
   uint32_t* buf[2];  // layer top -> A (<= 256 nodes), top-1 -> B (<= 128), top-2 -> A, ...
   buf[0] = bufA;
   buf[1] = bufB;
+  __shared__ WideLds<1024, 4> wide;
   const uint32_t node = threadIdx.x >> 2, q = threadIdx.x & 3u;
   int cur = 0;
   for (int l = (int)a.top_log; l >= 0; l--) {
     const uint32_t n = 1u << l;
+    const bool from_global = (l == (int)a.top_log);
+    const uint32_t* ch = (!from_global || a.prev) ? (from_global ? a.prev + (size_t)node * 16 : buf[cur ^ 1] + node * 16) : nullptr;
+    uint32_t h0, h1;
+    const bool is_wide = wide_layer_ok<1024, 4>(a.col_end[l] - a.col_begin[l], (uint32_t)l);   // block-uniform
+    if (is_wide) merkle_wide_quad<RFC, 1024, 4>(wide, ch, node < n, a.cols, a.col_begin[l], a.col_end[l], 0u, (uint32_t)l, node, q, threadIdx.x, h0, h1);
     if (node < n) {
-      const bool from_global = (l == (int)a.top_log);
-      const uint32_t* ch = (!from_global || a.prev) ? (from_global ? a.prev + (size_t)node * 16 : buf[cur ^ 1] + node * 16) : nullptr;
-      uint32_t h0, h1;
-      merkle_node_quad<RFC>(ch, a.cols, a.col_begin[l], a.col_end[l], node, q, h0, h1);
+      if (!is_wide) merkle_node_quad<RFC>(ch, a.cols, a.col_begin[l], a.col_end[l], node, q, h0, h1);
       uint32_t* o = a.layers[l] + (size_t)node * 8;
       o[q] = h0; o[4 + q] = h1;
       buf[cur][node * 8 + q] = h0; buf[cur][node * 8 + 4 + q] = h1;
@@ -311,6 +385,7 @@ __global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
   __shared__ uint32_t bufA[256 * 8];
   __shared__ uint32_t bufB[128 * 8];
   __shared__ uint32_t s_last;
+  __shared__ WideLds<256, 16> wide;   // phase 2 only
   uint32_t* buf[2];
   buf[0] = bufA;
   buf[1] = bufB;
@@ -366,15 +441,26 @@ __global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
   cur = 0;
   for (int l = base_log - 1; l >= 0; l--) {
     const uint32_t n = 1u << l;
-    // 256 threads = 64 quads: loop when the layer has more nodes
-    for (uint32_t nd = node; nd < n; nd += 64) {
-      const bool from_global = (l == base_log - 1);
-      const uint32_t* ch = from_global ? a.layers[base_log] + (size_t)nd * 16 : buf[cur ^ 1] + nd * 16;
+    const bool from_global = (l == base_log - 1);
+    if (wide_layer_ok<256, 16>(a.col_end[l] - a.col_begin[l], (uint32_t)l)) {   // block-uniform; n <= 64 here
+      const uint32_t* ch = from_global ? a.layers[base_log] + (size_t)node * 16 : buf[cur ^ 1] + node * 16;
       uint32_t h0, h1;
-      merkle_node_quad<RFC>(ch, a.cols, a.col_begin[l], a.col_end[l], nd, q, h0, h1);
-      uint32_t* o = a.layers[l] + (size_t)nd * 8;
-      o[q] = h0; o[4 + q] = h1;
-      buf[cur][nd * 8 + q] = h0; buf[cur][nd * 8 + 4 + q] = h1;
+      merkle_wide_quad<RFC, 256, 16>(wide, ch, node < n, a.cols, a.col_begin[l], a.col_end[l], 0u, (uint32_t)l, node, q, tid, h0, h1);
+      if (node < n) {
+        uint32_t* o = a.layers[l] + (size_t)node * 8;
+        o[q] = h0; o[4 + q] = h1;
+        buf[cur][node * 8 + q] = h0; buf[cur][node * 8 + 4 + q] = h1;
+      }
+    } else {
+      // 256 threads = 64 quads: loop when the layer has more nodes
+      for (uint32_t nd = node; nd < n; nd += 64) {
+        const uint32_t* ch = from_global ? a.layers[base_log] + (size_t)nd * 16 : buf[cur ^ 1] + nd * 16;
+        uint32_t h0, h1;
+        merkle_node_quad<RFC>(ch, a.cols, a.col_begin[l], a.col_end[l], nd, q, h0, h1);
+        uint32_t* o = a.layers[l] + (size_t)nd * 8;
+        o[q] = h0; o[4 + q] = h1;
+        buf[cur][nd * 8 + q] = h0; buf[cur][nd * 8 + 4 + q] = h1;
+      }
     }
     __syncthreads();
     cur ^= 1;
@@ -387,30 +473,17 @@ template <bool RFC>
 __global__ void __launch_bounds__(256) k_merkle_layer_quad(uint32_t log_size, const uint32_t* __restrict__ prev,
                                                            const uint32_t* const* __restrict__ cols, uint32_t n_cols,
                                                            uint32_t* __restrict__ out) {
+  __shared__ WideLds<256, 16> wide;
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   const uint32_t i = t >> 2, q = t & 3u;
-  if (i >= (1u << log_size)) return;  // whole quads drop out together
-  NodeFrame<RFC> fr(prev != nullptr, n_cols);
+  const uint32_t n = 1u << log_size;
   uint32_t h0, h1;
-  fr.init_quad(q, h0, h1);
-  uint32_t m[16];
-  if (prev) {
-    const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
-    uint4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
-    m[0] = x0.x; m[1] = x0.y; m[2] = x0.z; m[3] = x0.w; m[4] = x1.x; m[5] = x1.y; m[6] = x1.z; m[7] = x1.w;
-    m[8] = x2.x; m[9] = x2.y; m[10] = x2.z; m[11] = x2.w; m[12] = x3.x; m[13] = x3.y; m[14] = x3.z; m[15] = x3.w;
-    fr.absorb_quad(h0, h1, m, q, 64);
-  }
-  uint32_t c0 = 0;
-  for (; c0 + 16 <= n_cols; c0 += 16) {
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = CM_GCOL(cols[c0 + k])[i];
-    fr.absorb_quad(h0, h1, m, q, 64);
-  }
-  if (c0 < n_cols) {
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? CM_GCOL(cols[c0 + k])[i] : 0u;
-    fr.absorb_quad(h0, h1, m, q, 4u * (n_cols - c0));
+  if (log_size >= 6 && wide_layer_ok<256, 16>(n_cols, 6u)) {   // full blocks of 64 nodes: the block streams its columns through LDS
+    merkle_wide_quad<RFC, 256, 16>(wide, prev ? prev + (size_t)i * 16 : nullptr, true, cols, 0u, n_cols, blockIdx.x * 64u, 6u, threadIdx.x >> 2, q,
+                                   threadIdx.x, h0, h1);
+  } else {
+    if (i >= n) return;  // whole quads drop out together
+    merkle_node_quad<RFC>(prev ? prev + (size_t)i * 16 : nullptr, cols, 0u, n_cols, i, q, h0, h1);
   }
   out[(size_t)i * 8 + q] = h0;
   out[(size_t)i * 8 + 4 + q] = h1;
