@@ -153,8 +153,13 @@ hipStream_t thread_main_stream();
 // launches of one phase run concurrently instead of serialising 34 tiny kernels on one stream.
 // Fork f(main); launch on f.stream(i) ...; f.join();  — every side stream first waits for everything
 // enqueued on `main` before the fork, and `main` waits for all side work at join().
+// stream(Fork::MAIN) is the main stream itself: the LONGEST job of a region goes there — it starts without the cross-queue
+// hand-over of the fork (event -> barrier packet on another hardware queue: 15-50 us on gfx950) and, finishing last, finds the
+// side streams' join events already signalled (A/B: CM_FORK_MAIN=0 sends it to a side stream like everything else).
 struct Fork {
   static constexpr int N = 8;
+  static constexpr int MAIN = 1 << 20;
+  static int main_or(int side_index);   // MAIN, or side_index when CM_FORK_MAIN=0
   hipStream_t main;
   uint32_t used = 0;
   bool joined = false;

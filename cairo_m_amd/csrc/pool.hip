@@ -186,7 +186,12 @@ SideStreams& side() { static thread_local SideStreams* s = new SideStreams(); re
 }  // namespace
 
 Fork::Fork(hipStream_t main_stream) : main(main_stream) { CM_HIP(hipEventRecord(side().fork_ev, main)); }
+int Fork::main_or(int side_index) {
+  static const bool on = !(getenv("CM_FORK_MAIN") && atoi(getenv("CM_FORK_MAIN")) == 0);
+  return on ? MAIN : side_index;
+}
 hipStream_t Fork::stream(int i) {
+  if (i == MAIN) return main;
   i = ((i % N) + N) % N;
   SideStreams& ss = side();
   if (!(used & (1u << i))) {

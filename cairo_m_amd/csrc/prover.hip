@@ -482,7 +482,8 @@ struct SegmentProver {
       for (int pos = 0; pos < air::N_OPCODE_COMPONENTS; pos++) {
         const int c = by_size[pos];
         if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
-        hipStream_t sc = fk.stream(spos++ % (Fork::N - 2));
+        hipStream_t sc = fk.stream(spos == 0 ? Fork::main_or(0) : spos % (Fork::N - 2));   // by_size: the first one is the largest
+        spos++;
         launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
         launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, sc);
       }
@@ -585,7 +586,8 @@ struct SegmentProver {
         jobs[c].log_size = clog[c];
         if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
         launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
-                     drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos++ % (Fork::N - 1)));
+                     drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos == 0 ? Fork::main_or(0) : spos % (Fork::N - 1)));
+        spos++;
       }
       fk.join();
       kreg.close();
@@ -804,14 +806,14 @@ struct SegmentProver {
         for (int c : it->second) {
           if (std::find(small_cids.begin(), small_cids.end(), c) != small_cids.end()) { one_stream = false; continue; }
           // the components of a size group share its accumulator: one stream for all of them; slotted ones are independent
-          hipStream_t sc = slot_of[c] >= 0 ? fk.stream(cplan[5 + (small_rr++ % 3)]) : fk.stream(cplan[gi % 4]);
+          hipStream_t sc = slot_of[c] >= 0 ? fk.stream(cplan[5 + (small_rr++ % 3)]) : fk.stream(gi == 0 ? Fork::main_or(cplan[0]) : cplan[gi % 4]);
           if (slot_of[c] >= 0) one_stream = false;
           launch_constraints(c, cargs[c], sc);
         }
         // DomainEvaluationAccumulator::finalize starts here for such a group: its accumulator is interpolated on the same
         // stream right behind its constraint kernels — no second fork/join region for the large accumulators
         if (one_stream && early_interp) {
-          interpolate(accs.at(it->first).dev(), 4, it->first, *P.tw, fk.stream(cplan[gi % 4]));
+          interpolate(accs.at(it->first).dev(), 4, it->first, *P.tw, fk.stream(gi == 0 ? Fork::main_or(cplan[0]) : cplan[gi % 4]));
           acc_interpolated.insert(it->first);
         }
       }
@@ -1101,7 +1103,8 @@ struct SegmentProver {
       // they hide under the large groups instead of trailing them (they ended the region ~90 us after the last large kernel);
       // the large groups follow by descending size, one stream each
       for (auto& qa : qargs) if (qa.first.log_size < 14) launch_quotients(qa.first, qa.second, fkq.stream(Fork::N - 1));
-      for (auto& qa : qargs) if (qa.first.log_size >= 14) launch_quotients(qa.first, qa.second, fkq.stream(qk++ % (Fork::N - 1)));
+      for (auto& qa : qargs)
+        if (qa.first.log_size >= 14) { launch_quotients(qa.first, qa.second, fkq.stream(qk == 0 ? Fork::main_or(0) : qk % (Fork::N - 1))); qk++; }
       fkq.join();
       kregq.close();
     }
