@@ -32,6 +32,10 @@ HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s 
 _VOP2, _ADD, _ALIGN, _ADD3, _MAD64 = 65.9e12, 64.0e12, 37.9e12, 35.85e12, 31.46e12
 _B2S_PEAK = 1.0 / (336 / _VOP2 + 160 / _ADD + 320 / _ALIGN + 160 / _ADD3)       # ~4.9e10 compressions/s
 _BFLY_PEAK = 1.0 / (1 / _MAD64 + 10 / _VOP2)
+# What the hardware actually sustains on that op mix: the shipped per-lane compression looping on registers only (no loads, no
+# stores) on every CU, 2-8 waves per SIMD — tools/chain_lab.hip, profiles/r03w_chain_lab.txt: 3.78-3.91e10 compressions/s with 16
+# extra xors per compression (~1.5 %).  The single-op lane rates above do not add up when VOP2 / VOP3 / SDWA ops alternate.
+B2S_REGISTER_ONLY = 3.85e10
 ALU_PEAK = {"k_merkle_layer": (_B2S_PEAK, "Blake2s compressions/s"),
             "k_fft_pass<fft>": (_BFLY_PEAK, "M31 butterflies/s"),
             "k_fft_pass<ifft>": (_BFLY_PEAK, "M31 butterflies/s")}
@@ -430,6 +434,11 @@ def main():
                         "avg_launch_ms": k["ms"] / k["calls"], "launches": k["calls"],
                         "alu": ({"unit": ALU_PEAK[name][1], "achieved": k.get("work", 0.0) / (k["ms"] * 1e-3),
                                  "peak": ALU_PEAK[name][0], "frac": k.get("work", 0.0) / (k["ms"] * 1e-3) / ALU_PEAK[name][0],
+                                 **({"register_only_rate": B2S_REGISTER_ONLY,
+                                     "frac_of_register_only": k.get("work", 0.0) / (k["ms"] * 1e-3) / B2S_REGISTER_ONLY,
+                                     "register_only_note": "the same compression code looping on registers only, whole GPU (tools/chain_lab.hip, "
+                                                           "profiles/r03w_chain_lab.txt): the rate no Merkle kernel can exceed with this op mix"}
+                                    if name == "k_merkle_layer" else {}),
                                  "note": "this class is integer-VALU-bound, not HBM-bound (DESIGN.md §3); peak = 1 / sum(ops_i / measured lane-op rate_i), "
                                          "rates from profiles/r03k_valu_lab.txt (tools/valu_lab.hip)"}
                                 if name in ALU_PEAK and k.get("work") else None),

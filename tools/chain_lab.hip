@@ -162,6 +162,14 @@ int main() {
     printf("threads %4u  us per chained compression: quad %.3f  quad without selects %.3f  one lane per node %.3f  quad with DPP operands %.3f\n", threads,
            q0 * 1e3 / n, q1 * 1e3 / n, t2 * 1e3 / n, f3 * 1e3 / n);
   }
+  // whole-GPU rate of the per-lane compression with everything in registers (no loads, no stores): the ceiling the Merkle layer
+  // kernels can approach — 8 / 4 / 2 waves per SIMD
+  for (uint32_t blocks : {256u * 8u, 256u * 4u, 256u * 2u}) {
+    const uint32_t nn = 400;
+    float tt = time_ms([&] { hipLaunchKernelGGL(k_chain<2>, dim3(blocks), dim3(256), 0, 0, d, nn); });
+    printf("%u blocks x 256 threads: %.3e compressions/s (register-only per-lane chain, 16 extra xors per compression)\n", blocks,
+           (double)blocks * 256.0 * nn / (tt * 1e-3));
+  }
   hipLaunchKernelGGL(k_chain_f<true>, dim3(1), dim3(64), 0, 0, d, 100u);
   std::vector<uint32_t> host(1024);
   CK(hipMemcpy(host.data(), d, 4096, hipMemcpyDeviceToHost));
