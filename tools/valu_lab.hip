@@ -133,6 +133,33 @@ __global__ void __launch_bounds__(256) k_mad64(uint32_t* out, uint32_t s0, uint3
 typedef void (*kern_t)(uint32_t*, uint32_t, uint32_t);
 struct K { const char* name; kern_t fn; };
 
+// ---- op MIXES: do the single-op rates add up when VOP2 and VOP3 alternate?  (They do not: the Blake2s compression looping on
+// registers reaches 3.85e10/s where the sum of its ops' single rates gives 4.9e10 — tools/chain_lab.hip.) ----
+#define DEFMIX(NAME, BODY, OPS)                                                                \
+  __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t s0, uint32_t s1) {      \
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    uint32_t b = s0 ^ threadIdx.x, c = s1 + blockIdx.x;                                       \
+    for (int it = 0; it < N_ITER; it++) { REP8(BODY) }                                        \
+    out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;             \
+  }                                                                                           \
+  static const int NAME##_ops = OPS;
+#define ALL8(L) L(a0) L(a1) L(a2) L(a3) L(a4) L(a5) L(a6) L(a7)
+#define PAIR_XA(a) L_XOR(a) L_ALIGNBIT(a)
+// xor and alignbit alternate every instruction (each pair dependent, 8 independent accumulators)
+DEFMIX(k_mix_xa_alt, ALL8(PAIR_XA), 16)
+// the same ops in groups of 8 of one kind
+DEFMIX(k_mix_xa_grp, ALL8(L_XOR) ALL8(L_ALIGNBIT), 16)
+// one G-like sequence per accumulator: add3, xor, alignbit, add, xor, alignbit (the Blake2s ratio), alternating kinds ...
+#define SEQ_G(a) L_ADD3(a) L_XOR(a) L_ALIGNBIT(a) L_ADD(a) L_XOR(a) L_ALIGNBIT(a)
+DEFMIX(k_mix_g_alt, ALL8(SEQ_G), 48)
+// ... and grouped by kind across the 8 accumulators
+DEFMIX(k_mix_g_grp, ALL8(L_ADD3) ALL8(L_XOR) ALL8(L_ALIGNBIT) ALL8(L_ADD) ALL8(L_XOR) ALL8(L_ALIGNBIT), 48)
+// groups of 4 (what the four independent G functions of a Blake2s half-round allow)
+#define ALL4A(L) L(a0) L(a1) L(a2) L(a3)
+#define ALL4B(L) L(a4) L(a5) L(a6) L(a7)
+DEFMIX(k_mix_g_grp4, ALL4A(L_ADD3) ALL4A(L_XOR) ALL4A(L_ALIGNBIT) ALL4A(L_ADD) ALL4A(L_XOR) ALL4A(L_ALIGNBIT)
+                     ALL4B(L_ADD3) ALL4B(L_XOR) ALL4B(L_ALIGNBIT) ALL4B(L_ADD) ALL4B(L_XOR) ALL4B(L_ALIGNBIT), 48)
+
 int main() {
   K ks[] = {{"v_cndmask_b32 (vcc set by v_cmp)", k_cndmask_vcc}, {"v_cndmask_b32_e64 (sgpr mask)", k_cndmask_e64},
             {"csub: sub + min (pair = 1 op)", k_csub_min}, {"csub: sub_co + cndmask (pair = 1 op)", k_csub_cnd},
@@ -164,6 +191,23 @@ int main() {
     // cycles per wave-instruction per SIMD at 2.4 GHz: 1024 SIMDs, 64 lanes per wave instruction
     double cyc = (2.4e9 * 1024.0) / (tops * 1e12 / 64.0);
     printf("%-36s %7.2f T lane-ops/s   %5.2f cycles / wave-instruction / SIMD (at 2.4 GHz)\n", k.name, tops, cyc);
+  }
+  struct KM { const char* name; void (*fn)(uint32_t*, uint32_t, uint32_t); int ops; } ms_[] = {
+      {"mix xor,alignbit alternating", k_mix_xa_alt, k_mix_xa_alt_ops}, {"mix 8 xor then 8 alignbit", k_mix_xa_grp, k_mix_xa_grp_ops},
+      {"mix add3,xor,align,add,xor,align per chain", k_mix_g_alt, k_mix_g_alt_ops}, {"same ops grouped by kind x8", k_mix_g_grp, k_mix_g_grp_ops},
+      {"same ops grouped by kind x4", k_mix_g_grp4, k_mix_g_grp4_ops}};
+  for (auto& k : ms_) {
+    hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, out, 3u, 5u);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, out, 3u, 5u);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    double lane_ops = 4.0 * blocks * 256.0 * N_ITER * 8.0 * k.ops;
+    double tops = lane_ops / (ms * 1e-3) / 1e12;
+    printf("%-44s %7.2f T lane-ops/s   %5.3f ns / wave-instruction / SIMD\n", k.name, tops, 1024.0 * 64.0 / (tops * 1e12) * 1e9);
   }
   return 0;
 }
