@@ -32,10 +32,12 @@ HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s 
 _VOP2, _ADD, _ALIGN, _ADD3, _MAD64 = 65.9e12, 64.0e12, 37.9e12, 35.85e12, 31.46e12
 _B2S_PEAK = 1.0 / (336 / _VOP2 + 160 / _ADD + 320 / _ALIGN + 160 / _ADD3)       # ~4.9e10 compressions/s
 _BFLY_PEAK = 1.0 / (1 / _MAD64 + 10 / _VOP2)
-# What the hardware actually sustains on that op mix: the shipped per-lane compression looping on registers only (no loads, no
-# stores) on every CU, 2-8 waves per SIMD — tools/chain_lab.hip, profiles/r03w_chain_lab.txt: 3.78-3.91e10 compressions/s with 16
-# extra xors per compression (~1.5 %).  The single-op lane rates above do not add up when VOP2 / VOP3 / SDWA ops alternate.
-B2S_REGISTER_ONLY = 3.85e10
+# What the hardware actually sustains on that op mix: the per-lane compression looping on registers only (no loads, no stores) on
+# every CU at 8 waves per SIMD — tools/chain_lab.hip, profiles/r03w_chain_lab.txt: 3.78e10 compressions/s in the order the compiler
+# emits, 4.08e10 with the four G functions of a half-round issued in lockstep (the best order found; in the Merkle kernels
+# themselves that order changes nothing).  The single-op lane rates above do not add up when VOP2 / VOP3 / SDWA ops alternate and
+# when dependent instructions follow each other (profiles/r03w_valu_lab.txt, the "mix" lines).
+B2S_REGISTER_ONLY = 4.08e10
 ALU_PEAK = {"k_merkle_layer": (_B2S_PEAK, "Blake2s compressions/s"),
             "k_fft_pass<fft>": (_BFLY_PEAK, "M31 butterflies/s"),
             "k_fft_pass<ifft>": (_BFLY_PEAK, "M31 butterflies/s")}
