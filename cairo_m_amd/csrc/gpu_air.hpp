@@ -136,14 +136,62 @@ struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
   __device__ QM31 combine(int r, const M31* v, int n) { return dev_combine(rels, r, v, n); }
   __device__ QM31 ef_from(M31 m) { return QM31(m); }
   __device__ void on_entry(int, M31, const M31*, int) {}
-  __device__ void emit_batch(bool, QM31 num, QM31 den) {
-    QM31 v = prev + num * inv(den);
-    CM_GCOL_W(out[4 * batch + 0])[row] = v.a.a.v;
-    CM_GCOL_W(out[4 * batch + 1])[row] = v.a.b.v;
-    CM_GCOL_W(out[4 * batch + 2])[row] = v.b.a.v;
-    CM_GCOL_W(out[4 * batch + 3])[row] = v.b.b.v;
-    prev = v;
-    batch++;
+  // The batches of a row are buffered, up to LOGUP_INV_GROUP at a time, and their denominators inverted TOGETHER: a QM31 inverse
+  // is conj / norm with one M31 inversion (37 multiplications by Fermat) at the bottom; Montgomery's trick replaces the group's
+  // M31 inversions by one inversion + 3 multiplications each.  Every index below is a compile-time constant after inlining (the
+  // stream of a component is straight-line code), so the buffers live in registers.  CM_LOGUP_INV_GROUP=1: one inversion per batch.
+#ifndef CM_LOGUP_INV_GROUP
+#define CM_LOGUP_INV_GROUP 6
+#endif
+  static constexpr int G = CM_LOGUP_INV_GROUP;
+  QM31 bn[G], bd[G];
+  int cnt = 0;
+  // (the buffer is a shift register — slot 0 = the newest batch — so that every array index is a constant even before the
+  // compiler has promoted `cnt`: a `bn[cnt]` store keeps the whole evaluator in scratch memory)
+  __device__ __forceinline__ void emit_batch(bool, QM31 num, QM31 den) {
+#pragma unroll
+    for (int k = G - 1; k > 0; k--) { bn[k] = bn[k - 1]; bd[k] = bd[k - 1]; }
+    bn[0] = num; bd[0] = den; cnt++;
+    if (cnt == G) flush();
+  }
+  __device__ __forceinline__ void flush() {
+    const int n = cnt;
+    if (n == 0) return;
+    CM31 d[G];
+    M31 nr[G], pre[G], ni[G];
+    M31 all;
+#pragma unroll
+    for (int k = 0; k < G; k++)
+      if (k < n) {
+        d[k] = bd[k].a * bd[k].a - mul_R(bd[k].b * bd[k].b);
+#if defined(__HIP_DEVICE_COMPILE__)
+        nr[k] = m31_fold64((unsigned long long)d[k].a.v * d[k].a.v + (unsigned long long)d[k].b.v * d[k].b.v);
+#else
+        nr[k] = d[k].a * d[k].a + d[k].b * d[k].b;
+#endif
+        pre[k] = k == 0 ? nr[0] : pre[k - 1] * nr[k];
+        all = pre[k];
+      }
+    M31 t = inv(all);
+#pragma unroll
+    for (int k = G - 1; k >= 0; k--)
+      if (k < n) {
+        ni[k] = k == 0 ? t : t * pre[k - 1];
+        if (k > 0) t = t * nr[k];
+      }
+#pragma unroll
+    for (int k = G - 1; k >= 0; k--)   // oldest batch first
+      if (k < n) {
+        const CM31 di(d[k].a * ni[k], -(d[k].b * ni[k]));
+        const QM31 v = prev + bn[k] * QM31(bd[k].a * di, -(bd[k].b * di));
+        CM_GCOL_W(out[4 * batch + 0])[row] = v.a.a.v;
+        CM_GCOL_W(out[4 * batch + 1])[row] = v.a.b.v;
+        CM_GCOL_W(out[4 * batch + 2])[row] = v.b.a.v;
+        CM_GCOL_W(out[4 * batch + 3])[row] = v.b.b.v;
+        prev = v;
+        batch++;
+      }
+    cnt = 0;
   }
 };
 
