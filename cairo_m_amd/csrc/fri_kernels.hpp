@@ -46,6 +46,13 @@ void fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[4],
 // d_alpha != null: the folding challenge is read from device memory (4 u32) instead of `alpha`
 void fold_line(uint32_t* const out[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw, const QM31& alpha,
                hipStream_t st, const uint32_t* d_alpha = nullptr);
+// Row-range forms (sharded FRI: a rank folds its own slice; folds are pair-local, so rows [2 i0, 2 (i0 + n_out)) of the source
+// give rows [i0, i0 + n_out) of the result): dst / out / src point at arrays that hold ONLY that range.
+void fold_circle_into_line_rows(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw,
+                                const QM31& alpha, bool accumulate, uint32_t i0, uint32_t n_out, hipStream_t st,
+                                const uint32_t* d_alpha = nullptr);
+void fold_line_rows(uint32_t* const out[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw, const QM31& alpha,
+                    uint32_t i0, uint32_t n_out, hipStream_t st, const uint32_t* d_alpha = nullptr);
 
 // Tail of the FRI commit phase in ONE launch (one 1024-thread block): for every remaining layer
 // (2^top_log ... 2^(last_log+1) values) fold the pending circle quotients in, build the layer's Merkle

@@ -8,7 +8,7 @@
 namespace cm {
 
 void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
-                      const std::function<void()>& while_gpu_busy) {
+                      const std::function<void()>& while_gpu_busy, const FriResume* resume) {
   hipStream_t st = P.st;
   Channel& ch = P.ch;
   // ---- FRI commit ----
@@ -17,7 +17,8 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
   // and the fold kernels read the challenge from device memory.  The host replays the same steps on its own
   // channel afterwards from the recorded roots and checks that the challenges agree.
   const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup_factor;
-  uint32_t layer_log = q_logs[0] - 1;
+  uint32_t layer_log = resume ? resume->layer_log : q_logs[0] - 1;
+  if (resume) { have_first = false; inner_fold0 = 1 + resume->n_inner_before; }
   const uint32_t n_inner = layer_log > last_log ? layer_log - last_log : 0;
   DevBuf d_chan(64), d_alphas((size_t)(n_inner + 1) * 16), d_roots((size_t)(n_inner + 1) * 32);
   {
@@ -34,29 +35,42 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
     UploadBatch ub;
     std::vector<const uint32_t*> cols;
     std::vector<uint32_t> logs;
-    for (size_t k = 0; k < quotients.size(); k++) for (int c = 0; c < 4; c++) { cols.push_back(quotients[k].ptrs[c]); logs.push_back(q_logs[k]); }
-    first_tree.prepare(cols, logs);
-    ub.add(first_tree.cols, &first_tree.d_cols_view);
+    if (!resume) {
+      for (size_t k = 0; k < quotients.size(); k++) for (int c = 0; c < 4; c++) { cols.push_back(quotients[k].ptrs[c]); logs.push_back(q_logs[k]); }
+      first_tree.prepare(cols, logs);
+      ub.add(first_tree.cols, &first_tree.d_cols_view);
+    }
     for (uint32_t l = layer_log; l > last_log && l > fri_tail_log(); l--) {
       std::unique_ptr<InnerLayer> il(new InnerLayer());
       il->log = l;
-      il->eval.alloc(std::vector<uint32_t>(4, l), st, false);
+      if (resume && resume->layer && l == layer_log) il->eval = std::move(*resume->layer);
+      else il->eval.alloc(std::vector<uint32_t>(4, l), st, false);
       std::vector<const uint32_t*> lc(il->eval.ptrs.begin(), il->eval.ptrs.end());
       il->tree.prepare(lc, std::vector<uint32_t>(4, l));
       ub.add(il->tree.cols, &il->tree.d_cols_view);
       pre.push_back(std::move(il));
     }
     fri_tables = ub.flush(st);
-    first_tree.commit_prepared(st);
-    chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
+    if (!resume) {
+      first_tree.commit_prepared(st);
+      chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
+    } else {
+      uint32_t a4[4];
+      resume->alpha_c.to_u32(a4);
+      stage_upload(d_alphas.p, a4, sizeof(a4), st);   // slot 0 = the circle-fold challenge, as after a first-layer step
+    }
   }
   ColumnSet layer;
-  bool layer_is_blank = !pre.empty();   // pre[0] is written (not accumulated into) by the first circle fold: no memset
+  const bool resumed_layer = resume && resume->layer;
+  bool layer_is_blank = !pre.empty() && !resumed_layer;   // pre[0] is written (not accumulated into) by the first circle fold: no memset
   if (pre.empty()) {
-    layer.alloc(std::vector<uint32_t>(4, layer_log), st, false);
-    CM_HIP(hipMemsetAsync(layer.buf.p, 0, layer.buf.bytes, st));
+    if (resumed_layer) layer = std::move(*resume->layer);
+    else {
+      layer.alloc(std::vector<uint32_t>(4, layer_log), st, false);
+      CM_HIP(hipMemsetAsync(layer.buf.p, 0, layer.buf.bytes, st));
+    }
   }
-  size_t qi = 0, pi = 0;
+  size_t qi = resume ? resume->qi : 0, pi = 0;
   const QM31 unused_alpha;
   while (layer_log > last_log) {
     if (layer_log <= fri_tail_log()) {
@@ -164,7 +178,7 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
     }
     // host replay of the device-side transcript steps
     CM_CHECK(inner.size() == n_inner, "fri: layer count mismatch");
-    for (size_t li = 0; li <= n_inner; li++) {
+    for (size_t li = resume ? 1 : 0; li <= n_inner; li++) {
       hostch::Hash32 root;
       memcpy(root.data(), &h_roots[8 * li], 32);
       ch.mix_root(root);

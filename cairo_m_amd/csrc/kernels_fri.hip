@@ -266,11 +266,13 @@ struct CPtr4 { const uint32_t* p[4]; };
 // dst[i] = dst[i] * alpha^2 + (f0 + f1) + alpha * (f0 - f1) / y_i,  (f0, f1) = src[2i], src[2i+1]
 __global__ void __launch_bounds__(256) k_fold_circle(Ptr4 dst, CPtr4 src, uint32_t log_n, TwiddleView tw, const uint32_t alpha4_0,
                                                      const uint32_t alpha4_1, const uint32_t alpha4_2, const uint32_t alpha4_3,
-                                                     int accumulate, const uint32_t* __restrict__ alpha_dev) {
+                                                     int accumulate, const uint32_t* __restrict__ alpha_dev, uint32_t i0, uint32_t n_out) {
+  // (i0, n_out): the launch computes outputs [i0, i0 + n_out) of the fold into arrays that hold just that row range
+  // (sharded FRI: dst / src are a rank's slices); the whole layer is i0 = 0, n_out = 2^(log_n - 1)
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (1u << (log_n - 1))) return;
+  if (i >= n_out) return;
   QM31 alpha = alpha_dev ? QM31::from_u32(alpha_dev) : QM31(M31(alpha4_0), M31(alpha4_1), M31(alpha4_2), M31(alpha4_3));
-  M31 yinv(tw.iytw[(1u << (log_n - 1)) + i] >> 1);
+  M31 yinv(tw.iytw[(1u << (log_n - 1)) + i0 + i] >> 1);
   QM31 f0 = ld4(src.p, 2 * i), f1 = ld4(src.p, 2 * i + 1);
   QM31 v = (f0 + f1) + alpha * ((f0 - f1) * yinv);
   if (accumulate) v = ld4(dst.p, i) * (alpha * alpha) + v;
@@ -279,12 +281,12 @@ __global__ void __launch_bounds__(256) k_fold_circle(Ptr4 dst, CPtr4 src, uint32
 // out[i] = (f0 + f1) + alpha * (f0 - f1) / x_i on LineDomain(half_odds(log_n))
 __global__ void __launch_bounds__(256) k_fold_line(Ptr4 out, CPtr4 src, uint32_t log_n, TwiddleView tw, const uint32_t alpha4_0,
                                                    const uint32_t alpha4_1, const uint32_t alpha4_2, const uint32_t alpha4_3,
-                                                   const uint32_t* __restrict__ alpha_dev) {
+                                                   const uint32_t* __restrict__ alpha_dev, uint32_t i0, uint32_t n_out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (1u << (log_n - 1))) return;
+  if (i >= n_out) return;
   QM31 alpha = alpha_dev ? QM31::from_u32(alpha_dev) : QM31(M31(alpha4_0), M31(alpha4_1), M31(alpha4_2), M31(alpha4_3));
   uint32_t L = tw.R - (log_n + 1);
-  M31 xinv(tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + i] >> 1);
+  M31 xinv(tw.ixtw[(1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)) + i0 + i] >> 1);
   QM31 f0 = ld4(src.p, 2 * i), f1 = ld4(src.p, 2 * i + 1);
   st4(out.p, i, (f0 + f1) + alpha * ((f0 - f1) * xinv));
 }
@@ -423,22 +425,28 @@ void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st) {
 }
 void fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw,
                            const QM31& alpha, bool accumulate, hipStream_t st, const uint32_t* d_alpha) {
-  CM_CHECK(log_n >= 2 && log_n <= tw.R, "fold_circle: bad log size");
+  fold_circle_into_line_rows(dst, src, log_n, tw, alpha, accumulate, 0u, 1u << (log_n - 1), st, d_alpha);
+}
+void fold_circle_into_line_rows(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw,
+                                const QM31& alpha, bool accumulate, uint32_t i0, uint32_t n_out, hipStream_t st, const uint32_t* d_alpha) {
+  CM_CHECK(log_n >= 2 && log_n <= tw.R && (uint64_t)i0 + n_out <= ((uint64_t)1 << (log_n - 1)), "fold_circle: bad log size / row range");
   Ptr4 d; CPtr4 s;
   for (int i = 0; i < 4; i++) { d.p[i] = dst[i]; s.p[i] = src[i]; }
-  uint32_t n = 1u << (log_n - 1);
-  hipLaunchKernelGGL(k_fold_circle, dim3((n + 255) / 256), dim3(256), 0, st, d, s, log_n, view(tw), alpha.a.a.v, alpha.a.b.v,
-                     alpha.b.a.v, alpha.b.b.v, accumulate ? 1 : 0, d_alpha);
+  hipLaunchKernelGGL(k_fold_circle, dim3((n_out + 255) / 256), dim3(256), 0, st, d, s, log_n, view(tw), alpha.a.a.v, alpha.a.b.v,
+                     alpha.b.a.v, alpha.b.b.v, accumulate ? 1 : 0, d_alpha, i0, n_out);
   CM_HIP(hipGetLastError());
 }
 void fold_line(uint32_t* const out[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw, const QM31& alpha,
                hipStream_t st, const uint32_t* d_alpha) {
-  CM_CHECK(log_n >= 1 && log_n + 1 <= tw.R, "fold_line: bad log size");
+  fold_line_rows(out, src, log_n, tw, alpha, 0u, 1u << (log_n - 1), st, d_alpha);
+}
+void fold_line_rows(uint32_t* const out[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw, const QM31& alpha,
+                    uint32_t i0, uint32_t n_out, hipStream_t st, const uint32_t* d_alpha) {
+  CM_CHECK(log_n >= 1 && log_n + 1 <= tw.R && (uint64_t)i0 + n_out <= ((uint64_t)1 << (log_n - 1)), "fold_line: bad log size / row range");
   Ptr4 d; CPtr4 s;
   for (int i = 0; i < 4; i++) { d.p[i] = out[i]; s.p[i] = src[i]; }
-  uint32_t n = 1u << (log_n - 1);
-  hipLaunchKernelGGL(k_fold_line, dim3((n + 255) / 256), dim3(256), 0, st, d, s, log_n, view(tw), alpha.a.a.v, alpha.a.b.v,
-                     alpha.b.a.v, alpha.b.b.v, d_alpha);
+  hipLaunchKernelGGL(k_fold_line, dim3((n_out + 255) / 256), dim3(256), 0, st, d, s, log_n, view(tw), alpha.a.a.v, alpha.a.b.v,
+                     alpha.b.a.v, alpha.b.b.v, d_alpha, i0, n_out);
   CM_HIP(hipGetLastError());
 }
 void fold_line_and_circle(uint32_t* const out[4], const uint32_t* const src[4], const uint32_t* const circle[4], uint32_t log_n,

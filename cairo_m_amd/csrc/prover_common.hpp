@@ -293,12 +293,24 @@ inline QGather plan_fri_positions(const uint32_t* const col4[4], const std::vect
 // tree per inner layer, the last layer's polynomial — with the transcript steps between the layers on the device.  Shared by
 // the single-GPU prover and the sharded one (where FRI is replicated on every rank).  Leaves the trees and layer evaluations
 // in place for the decommitment.
+// The commit phase picks up BEHIND layers somebody else committed (the sharded prover's row-sharded first layers, whose transcript
+// steps already ran on the host channel): the first-layer tree is skipped and the loop starts at `layer_log`.
+struct FriResume {
+  ColumnSet* layer = nullptr;   // evaluations of layer `layer_log`: line folds done, the circle quotients of that size NOT yet folded in;
+                                // null = nothing folded into it yet (the first inner layer)
+  uint32_t layer_log = 0;
+  size_t qi = 0;                // first quotient group that is not folded yet
+  uint32_t n_inner_before = 0;  // inner layers committed before `layer_log` (their queries are folded away in plan_decommit)
+  QM31 alpha_c;                 // the circle-fold challenge (the first FRI challenge)
+};
 struct FriPhase {
   struct InnerLayer { ColumnSet eval; uint32_t log; MerkleTree tree; hostch::Hash32 root; };
   MerkleTree first_tree;
   std::vector<std::unique_ptr<InnerLayer>> inner;
+  bool have_first = true;       // false after a resumed commit: no first-layer tree here
+  uint32_t inner_fold0 = 1;     // folds between the query domain and inner[0]
   void commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
-              const std::function<void()>& while_gpu_busy);
+              const std::function<void()>& while_gpu_busy, const FriResume* resume = nullptr);
   // Decommitment of the FRI trees (first layer over the quotient columns, then one tree per inner layer): decommitment
   // positions + witness evaluations of every layer are requested through the caller's GatherBatch (one gather launch for the
   // whole proof), finish_decommit() distributes what came back.
@@ -307,15 +319,17 @@ struct FriPhase {
   std::vector<DecommitPlan> inner_plan;
   void plan_decommit(const Queries& queries, const std::map<uint32_t, std::vector<uint32_t>>& qpos, const std::vector<ColumnSet>& quotients,
                      const std::vector<uint32_t>& q_logs, GatherBatch& gb) {
-    std::map<uint32_t, std::vector<uint32_t>> first_dpos;
-    for (size_t k = 0; k < quotients.size(); k++) {
-      const uint32_t* c4[4] = {quotients[k].ptrs[0], quotients[k].ptrs[1], quotients[k].ptrs[2], quotients[k].ptrs[3]};
-      std::vector<uint32_t> pos;
-      first_w.push_back(plan_fri_positions(c4, qpos.at(q_logs[k]), pos, gb));
-      first_dpos[q_logs[k]] = std::move(pos);
+    if (have_first) {
+      std::map<uint32_t, std::vector<uint32_t>> first_dpos;
+      for (size_t k = 0; k < quotients.size(); k++) {
+        const uint32_t* c4[4] = {quotients[k].ptrs[0], quotients[k].ptrs[1], quotients[k].ptrs[2], quotients[k].ptrs[3]};
+        std::vector<uint32_t> pos;
+        first_w.push_back(plan_fri_positions(c4, qpos.at(q_logs[k]), pos, gb));
+        first_dpos[q_logs[k]] = std::move(pos);
+      }
+      first_plan = first_tree.plan_decommit(first_dpos, gb);
     }
-    first_plan = first_tree.plan_decommit(first_dpos, gb);
-    Queries lq = queries.fold(1);
+    Queries lq = queries.fold(inner_fold0);
     for (auto& il : inner) {
       const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
       std::vector<uint32_t> pos;
@@ -325,8 +339,8 @@ struct FriPhase {
     }
   }
   void finish_decommit(const GatherBatch& gb, ProofData& pf) const {
-    for (auto& g : first_w) finish_gather_q(g, gb, pf.fri_first.fri_witness);
-    {
+    if (have_first) {
+      for (auto& g : first_w) finish_gather_q(g, gb, pf.fri_first.fri_witness);
       std::vector<uint32_t> qv;
       MerkleTree::finish_decommit(first_plan, gb, qv, pf.fri_first.decommitment);
     }

@@ -22,11 +22,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_sharded(world, fib_n, out, mixed_iters=0, comm="torch"):
+def _run_sharded(world, fib_n, out, mixed_iters=0, comm="torch", extra_env=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "-m", "cairo_m_amd.sharded", "--fib-n", str(fib_n), "--dist-backend", "gloo",
            "--force-device", "0", "--steps", "0", "--out", out, "--mixed-iters", str(mixed_iters), "--comm", comm]
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return r.stdout
@@ -47,6 +48,26 @@ def test_sharded_proof_equals_single_gpu_proof(backend, oracle, tmp_path, world,
         diff = np.nonzero(got != want)[0]
         assert diff.size == 0, f"rank {r}: first differing words {diff[:8]} of {got.size}"
     assert oracle.verify(want)[0] == 0
+    inp.free()
+
+
+@pytest.mark.parametrize("world,fib_n,stop", [(2, 3_000, 7), (4, 30_000, 8), (8, 30_000, 9), (2, 30_000, 99)])
+def test_sharded_fri_layers_by_row_range(backend, oracle, tmp_path, world, fib_n, stop):
+    """FRI is committed by ROW RANGE above 2^stop rows (first-layer tree over the quotient slices, inner layers folded slice to
+    slice, one 32-byte all-gather per tree), then gathered and finished on every rank.  The default stop is 2^16; here it is
+    lowered (CM_SHARD_FRI_STOP_LOG) so that small proofs run many sharded layers, and set to 99 for the fully replicated FRI of
+    the earlier rounds: the proof never changes."""
+    inp = synth_fibonacci(fib_n)
+    p = backend.prove(inp)
+    want = p.words().copy()
+    p.free()
+    out = str(tmp_path / "proof")
+    log = _run_sharded(world, fib_n, out, extra_env={"CM_SHARD_FRI_STOP_LOG": str(stop)})
+    for r in range(world):
+        got = np.load(f"{out}.{r}.npy")
+        assert got.size == want.size, (r, got.size, want.size, log[-500:])
+        diff = np.nonzero(got != want)[0]
+        assert diff.size == 0, f"rank {r}: first differing words {diff[:8]} of {got.size}"
     inp.free()
 
 
