@@ -294,6 +294,11 @@ static CPoint<QM31> draw_oods_point(Channel& ch, QM31* t_out = nullptr) {
   p.y = (t + t) * iv;
   return p;
 }
+// side streams a fork region spreads its large launches over (A/B: CM_FORK_WIDTH; the join costs one barrier packet per used stream)
+static int fork_width(int dflt) {
+  static const int w = getenv("CM_FORK_WIDTH") ? atoi(getenv("CM_FORK_WIDTH")) : 0;
+  return w > 0 && w < dflt ? w : dflt;
+}
 // =========================================================================================================
 // CM_HOST_TRACE=1: host-side time between marks on stderr (where the GPU sits idle waiting for the host)
 struct HostTrace {
@@ -482,7 +487,7 @@ struct SegmentProver {
       for (int pos = 0; pos < air::N_OPCODE_COMPONENTS; pos++) {
         const int c = by_size[pos];
         if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
-        hipStream_t sc = fk.stream(spos == 0 ? Fork::main_or(0) : spos % (Fork::N - 2));   // by_size: the first one is the largest
+        hipStream_t sc = fk.stream(spos == 0 ? Fork::main_or(0) : spos % fork_width(Fork::N - 2));   // by_size: the first one is the largest
         spos++;
         launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
         launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, sc);
@@ -586,7 +591,7 @@ struct SegmentProver {
         jobs[c].log_size = clog[c];
         if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
         launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
-                     drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos == 0 ? Fork::main_or(0) : spos % (Fork::N - 1)));
+                     drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos == 0 ? Fork::main_or(0) : spos % fork_width(Fork::N - 1)));
         spos++;
       }
       fk.join();
@@ -1104,7 +1109,7 @@ struct SegmentProver {
       // the large groups follow by descending size, one stream each
       for (auto& qa : qargs) if (qa.first.log_size < 14) launch_quotients(qa.first, qa.second, fkq.stream(Fork::N - 1));
       for (auto& qa : qargs)
-        if (qa.first.log_size >= 14) { launch_quotients(qa.first, qa.second, fkq.stream(qk == 0 ? Fork::main_or(0) : qk % (Fork::N - 1))); qk++; }
+        if (qa.first.log_size >= 14) { launch_quotients(qa.first, qa.second, fkq.stream(qk == 0 ? Fork::main_or(0) : qk % fork_width(Fork::N - 1))); qk++; }
       fkq.join();
       kregq.close();
     }

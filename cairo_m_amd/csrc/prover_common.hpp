@@ -330,12 +330,55 @@ struct FriPhase {
       first_plan = first_tree.plan_decommit(first_dpos, gb);
     }
     Queries lq = queries.fold(inner_fold0);
-    for (auto& il : inner) {
-      const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
-      std::vector<uint32_t> pos;
-      inner_w.push_back(plan_fri_positions(c4, lq.positions, pos, gb));
-      inner_plan.push_back(il->tree.plan_decommit(il->log, pos, gb));
-      lq = lq.fold(1);
+    static const bool generic = getenv("CM_FRI_PLAN_GENERIC") != nullptr;   // A/B switch: the per-tree symbolic walk
+    if (generic) {
+      for (auto& il : inner) {
+        const uint32_t* c4[4] = {il->eval.ptrs[0], il->eval.ptrs[1], il->eval.ptrs[2], il->eval.ptrs[3]};
+        std::vector<uint32_t> pos;
+        inner_w.push_back(plan_fri_positions(c4, lq.positions, pos, gb));
+        inner_plan.push_back(il->tree.plan_decommit(il->log, pos, gb));
+        lq = lq.fold(1);
+      }
+      return;
+    }
+    // The inner layers' trees have columns at the leaves only and their decommitment positions are whole sibling pairs, so the
+    // walks of ALL of them come from one family of sets: B[m] = the query positions folded m more times (layer i is queried at
+    // B[i]) and W[m] = the siblings of B[m]'s elements that are not in B[m] themselves, ascending.  Layer i's witness evaluations
+    // sit at W[i]; its tree needs no hash below level L_i - 1 (both leaves of every touched pair are known), and from level L_i - k
+    // exactly the nodes W[i + k] (k = 1 .. L_i - 1: the missing child of every touched parent, parents ascending — Stwo's order).
+    // One pass builds the W lists; every tree then only turns indices into addresses.  (The queried leaf values the generic walk
+    // also fetched were dropped afterwards: the verifier recomputes them.)
+    std::vector<std::vector<uint32_t>> W;
+    {
+      std::vector<uint32_t> B = lq.positions;
+      uint32_t log = lq.log_domain_size;
+      for (;; log--) {
+        std::vector<uint32_t> w;
+        for (size_t j = 0; j < B.size(); j++) {
+          const uint32_t sib = B[j] ^ 1u;
+          const bool present = (j + 1 < B.size() && B[j + 1] == sib) || (j > 0 && B[j - 1] == sib);
+          if (!present) w.push_back(sib);
+        }
+        W.push_back(std::move(w));
+        if (log == 0) break;
+        size_t o = 0;
+        for (size_t j = 0; j < B.size(); j++) { const uint32_t p = B[j] >> 1; if (o == 0 || B[o - 1] != p) B[o++] = p; }
+        B.resize(o);
+      }
+    }
+    for (size_t i = 0; i < inner.size(); i++) {
+      InnerLayer& il = *inner[i];
+      CM_CHECK(il.log + i == lq.log_domain_size, "fri decommit: layer sizes do not follow the query folds");
+      const uint32_t* c4[4] = {il.eval.ptrs[0], il.eval.ptrs[1], il.eval.ptrs[2], il.eval.ptrs[3]};
+      inner_w.push_back(plan_gather_q(c4, W[i], gb));
+      DecommitPlan plan;
+      plan.hash0 = gb.hash_addrs.size();
+      for (uint32_t k = 1; k < il.log; k++) {
+        const uint32_t* layer = il.tree.layers[il.log - k].u32();
+        for (uint32_t idx : W[i + k]) gb.add_hash(layer + (size_t)idx * 8);
+      }
+      plan.n_hash = gb.hash_addrs.size() - plan.hash0;
+      inner_plan.push_back(std::move(plan));
     }
   }
   void finish_decommit(const GatherBatch& gb, ProofData& pf) const {
