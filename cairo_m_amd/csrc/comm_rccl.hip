@@ -36,6 +36,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -55,6 +56,7 @@ Rccl& rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
     r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
     r.Send = (decltype(r.Send))sym("ncclSend");
     r.Recv = (decltype(r.Recv))sym("ncclRecv");
@@ -126,6 +128,12 @@ int32_t rccl_all_to_all_v(void* ctx, const uint64_t* send_words, const uint64_t*
     cm::nccl_ck(r.GroupEnd(), "ncclGroupEnd");
   });
 }
+// cm_comm::abort: this rank failed in the middle of a sharded proof — tear the communicator down so that the peers' pending and
+// next collectives return an error instead of waiting for it (the handle is dead afterwards; cm_rccl_comm_destroy skips it)
+void rccl_abort(void* ctx) {
+  cm_rccl_comm* c = (cm_rccl_comm*)ctx;
+  if (c && c->comm && cm::rccl().CommAbort) { (void)cm::rccl().CommAbort(c->comm); c->comm = nullptr; }
+}
 }  // namespace
 
 extern "C" {
@@ -153,6 +161,7 @@ int32_t cm_rccl_comm_create(const uint8_t id[128], uint32_t rank, uint32_t world
     c->view.all_gather = rccl_all_gather;
     c->view.flags = CM_COMM_STREAM_ORDERED;
     c->view.set_stream = rccl_set_stream;
+    c->view.abort = rccl_abort;
     *out = c.release();
   });
 }

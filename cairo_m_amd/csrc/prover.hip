@@ -1285,7 +1285,12 @@ int32_t cm_prove_sharded(const cm_device_input* input, const cm_pcs_config* conf
     CM_CHECK(comm && comm->all_gather && comm->all_to_all_v && comm->send_buf && comm->recv_buf, "cm_prove_sharded: incomplete cm_comm");
     cm_pcs_config cfg = config ? *config : default_cfg();
     std::unique_ptr<cm_proof> p(new cm_proof());
-    p->d = cm::prove_sharded(*input->d, cfg, *comm);
+    try {
+      p->d = cm::prove_sharded(*input->d, cfg, *comm);
+    } catch (...) {
+      if (comm->abort) comm->abort(comm->ctx);   // the peers are heading for a collective this rank will never join
+      throw;
+    }
     *out = p.release();
   });
 }

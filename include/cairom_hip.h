@@ -261,8 +261,9 @@ int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words, const cm_
  * generation, LogUp, IFFT / LDE, constraint evaluation and OODS sampling; an all-to-all turns the committed LDE columns
  * into row-range ownership, so every rank hashes the Merkle subtree of its rows (sub-roots are all-gathered, the top
  * log2(world) levels are hashed by everyone) and accumulates the DEEP quotients of its rows; partial composition
- * accumulators are reduced across ranks.  The preprocessed tree, the composition tree and FRI are computed by every rank
- * (replicated) in this version.  Every rank returns the same proof, bit-identical to cm_prove_device's.
+ * accumulators are reduced across ranks.  FRI is committed by row range above 2^16 rows (folds are pair-local; a layer's tree
+ * is the rank's subtree + a 32-byte all-gather) and finished on every rank below; the transforms of the preprocessed and the
+ * composition tree are computed by every rank (replicated).  Every rank returns the same proof, bit-identical to cm_prove_device's.
  * The library does no communication itself: the host side (torch.distributed / RCCL in bench.py, anything else
  * elsewhere) provides two blocking collectives over two DEVICE staging buffers it owns.  Layouts are rank-major and
  * contiguous: all_to_all_v sends send_words[d] words to rank d from send_buf (blocks in rank order) and receives
@@ -280,6 +281,10 @@ typedef struct cm_comm {
    * drains its stream before a collective nor waits after it — everything stays ordered on that one stream. */
   uint32_t flags;
   int32_t (*set_stream)(void* ctx, cm_stream_t stream);
+  /* Optional.  Called when THIS rank fails inside cm_prove_sharded, before the error is returned: the other ranks are about to
+   * block in their next collective, and only the communicator can release them (the in-library RCCL communicator calls
+   * ncclCommAbort).  NULL: the host relies on its communicator's own timeout. */
+  void (*abort)(void* ctx);
 } cm_comm;
 #define CM_COMM_STREAM_ORDERED 1u
 /* host code (no GPU): which rank owns which component, and the staging capacity (words) a sharded proof of `input` needs */

@@ -152,6 +152,8 @@ pub struct cm_comm {
     /// CM_COMM_STREAM_ORDERED (1): the callbacks enqueue on the stream given through `set_stream` and do not block
     pub flags: u32,
     pub set_stream: Option<unsafe extern "C" fn(ctx: *mut c_void, stream: cm_stream_t) -> i32>,
+    /// called when this rank fails inside cm_prove_sharded, so that the communicator can release the peers (None: its own timeout)
+    pub abort: Option<unsafe extern "C" fn(ctx: *mut c_void)>,
 }
 pub const CM_COMM_STREAM_ORDERED: u32 = 1;
 #[repr(C)]

@@ -107,3 +107,29 @@ def test_in_library_rccl_comm_world_1(backend, oracle, tmp_path, fib_n):
     got = np.load(f"{out}.0.npy")
     assert got.size == want.size and np.array_equal(got, want)
     inp.free()
+
+
+def test_failing_rank_calls_the_communicator_abort(backend):
+    """cm_comm::abort: a rank that fails inside cm_prove_sharded (here: its all_gather callback reports an error) tells the
+    communicator before the error is returned, so that the peers' next collective does not wait for it for ever."""
+    import ctypes as C
+    from cairo_m_amd.sharded import CmComm, _A2A, _AG, _SETSTREAM, _ABORT, shard_plan
+    inp = synth_fibonacci(50)
+    _, words = shard_plan(inp, 1, backend.L)
+    send, recv = backend.col_alloc(words), backend.col_alloc(words)   # cm_handle = the device address of the words
+    aborted = []
+    a2a = _A2A(lambda ctx, s, r: 1)
+    ag = _AG(lambda ctx, w: 1)
+    ab = _ABORT(lambda ctx: aborted.append(True))
+    comm = CmComm(0, 1, None, int(send), int(recv), words, a2a, ag, 0, _SETSTREAM(), ab)
+    dev = backend.upload_input(inp)
+    out = C.c_void_p()
+    rc = backend.L.cm_prove_sharded(dev, None, C.byref(comm), C.byref(out))
+    assert rc != 0 and aborted == [True], (rc, aborted)
+    buf = C.create_string_buffer(1024)
+    backend.L.cm_last_error(buf, C.c_size_t(1024))
+    assert b"callback failed" in buf.value, buf.value
+    backend.free_input(dev)
+    backend.col_free(send)
+    backend.col_free(recv)
+    inp.free()
