@@ -237,9 +237,9 @@ def main():
                 "unit": "M31 trace cells/s", "bit_identical_to_single_gpu_proof": (tt[1].item() == 0.0) if a.check_single else None,
                 "component_owner": owner, "collectives_per_proof": comm.calls // (a.steps + 1),
                 "MB_sent_per_rank_per_proof": comm.bytes_moved / (a.steps + 1) / 1e6, "phase_ms": phases,
-                "note": "whole components are the sharding unit; Merkle hashing of all four trees and the DEEP quotients are "
-                        "row-sharded; the (cheap) transforms of trees 0 / 3 and FRI are replicated in this version; time = max over "
-                        "ranks of the wall time of `steps` proofs"}))
+                "note": "whole components are the sharding unit; Merkle hashing of all four trees, the DEEP quotients and the FRI "
+                        "layers above 2^16 rows are row-sharded; the (cheap) transforms of trees 0 / 3 and the small FRI layers are "
+                        "replicated; time = max over ranks of the wall time of `steps` proofs"}))
     elif dist.get_rank() == 0:
         print({"world": dist.get_world_size(), "owner": owner, "staging_words": words, "ms": ms, "phase_ms": phases, "cells": cells,
                "comm_calls_per_proof": comm.calls // (a.steps + 1), "comm_MB_per_proof": comm.bytes_moved / (a.steps + 1) / 1e6})
