@@ -294,6 +294,25 @@ static CPoint<QM31> draw_oods_point(Channel& ch, QM31* t_out = nullptr) {
   p.y = (t + t) * iv;
   return p;
 }
+// up to three device ranges zeroed by ONE launch (the constraints phase clears two accumulator sets and the slot buffer right in
+// front of its kernels: three dependent hipMemsetAsync = three packets on the critical path behind the interaction tree)
+struct ZeroRanges { uint4* p[3]; uint64_t n16[3]; };
+__global__ void __launch_bounds__(256) k_zero_ranges(ZeroRanges z) {
+  for (int r = 0; r < 3; r++)
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < z.n16[r]; i += (uint64_t)gridDim.x * 256) z.p[r][i] = make_uint4(0, 0, 0, 0);
+}
+static void zero_ranges(void* const p[3], const size_t bytes[3], hipStream_t st) {
+  ZeroRanges z;
+  uint64_t total = 0;
+  for (int r = 0; r < 3; r++) {
+    CM_CHECK(((uintptr_t)p[r] & 15) == 0 && (bytes[r] & 15) == 0, "zero_ranges: ranges must be 16-byte aligned");
+    z.p[r] = (uint4*)p[r]; z.n16[r] = bytes[r] / 16; total += z.n16[r];
+  }
+  if (!total) return;
+  const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(k_zero_ranges, dim3(blocks), dim3(256), 0, st, z);
+  CM_HIP(hipGetLastError());
+}
 // side streams a fork region spreads its large launches over (A/B: CM_FORK_WIDTH; the join costs one barrier packet per used stream)
 static int fork_width(int dflt) {
   static const int w = getenv("CM_FORK_WIDTH") ? atoi(getenv("CM_FORK_WIDTH")) : 0;
@@ -337,6 +356,7 @@ struct SegmentProver {
   DevBuf d_powers;
   DevBuf d_step1;                            // device-side transcript step after tree 1: {root[8], nonce[2], n_sent, error, z0[4]}
   DevBuf d_step2;                            // device-side transcript step after tree 2: {channel[16], coefficient[4], root[8]}
+  DevBuf d_ctab;                             // composition: every small table of the constraints phase, ONE upload
   CPoint<QM31> oods;
   DevBuf d_oods_table, d_oods_out, d_qblob;  // sampling pointer table, sampled values, DEEP-quotient plan
   size_t o_qjobs = 0, n_qjobs = 0;
@@ -597,7 +617,7 @@ struct SegmentProver {
       fk.join();
       kreg.close();
       logup_finalize_all(jobs, d_sums.u32(), st);
-      static_assert(PIN_SUMS + air::N_COMPONENTS * 4 <= PIN_ALPHAS, "pinned slot layout");
+      static_assert(PIN_SUMS + air::N_COMPONENTS * 4 <= PIN_COEFF, "pinned slot layout");
       const uint32_t* sums = pinned_words() + PIN_SUMS;
       CM_HIP(hipMemcpyAsync((void*)sums, d_sums.p, air::N_COMPONENTS * 16, hipMemcpyDeviceToHost, st));
       // the host only waits for THIS copy (an event), after the tree-2 transforms and hashes have been enqueued behind it:
@@ -677,12 +697,9 @@ struct SegmentProver {
         if (kv.first != comp_log) { accs[kv.first] = AccRef{&acc_rest, rest_logs.size()}; rest_logs.insert(rest_logs.end(), 4, kv.first); }
       CM_CHECK(cgroups.count(comp_log), "composition polynomial log size mismatch");
       accs[comp_log] = AccRef{&acc_top, 0};
-      acc_top.alloc(std::vector<uint32_t>(4, comp_log), st);
-      CM_HIP(hipMemsetAsync(acc_top.buf.p, 0, acc_top.buf.bytes, st));
-      if (!rest_logs.empty()) {
-        acc_rest.alloc(rest_logs, st);
-        CM_HIP(hipMemsetAsync(acc_rest.buf.p, 0, acc_rest.buf.bytes, st));
-      }
+      // (pointer tables: in the phase's one upload below; zeroing: one launch together with the slot buffer)
+      acc_top.alloc(std::vector<uint32_t>(4, comp_log), st, false);
+      if (!rest_logs.empty()) acc_rest.alloc(rest_logs, st, false);
     }
     // The constraints are evaluated on CanonicCoset(log + 1).  With log_blowup_factor = 1 (REGULAR_96_BITS) that is the
     // committed LDE domain and the kernels read the committed columns; with a larger blowup every polynomial is evaluated
@@ -731,13 +748,25 @@ struct SegmentProver {
           slot_words += (size_t)4 * kv.second.size() << kv.first;
           sgroups.push_back(g);
         }
-      DevBuf slots(slot_words * 4), d_slot_tab;
-      if (slot_words) {
-        CM_HIP(hipMemsetAsync(slots.p, 0, slot_words * 4, st));
+      DevBuf slots(((slot_words * 4 + 15) & ~(size_t)15) + 16);
+      if (slot_words)
         for (auto& g : sgroups)
           for (uint32_t k = 0; k < 4 * g.n; k++) slot_tab[g.tab0 + k] = slots.u32() + g.off_words + ((size_t)k << g.el);
-        d_slot_tab = upload(slot_tab, st);
+      {
+        void* const zp[3] = {acc_top.buf.p, acc_rest.buf.p ? acc_rest.buf.p : acc_top.buf.p, slots.p};
+        const size_t zb[3] = {acc_top.buf.bytes & ~(size_t)15, acc_rest.buf.p ? (acc_rest.buf.bytes & ~(size_t)15) : 0, (slot_words * 4 + 15) & ~(size_t)15};
+        zero_ranges(zp, zb, st);
       }
+      // ONE device table for the phase: [acc_top pointers | acc_rest pointers | slot table | small-component arguments | their ids];
+      // its address is known before the arguments (which point into it) are built
+      const size_t o_top = 0, o_rest = 64, o_slot = (o_rest + acc_rest.ptrs.size() * sizeof(void*) + 15) & ~(size_t)15;
+      const size_t o_args = (o_slot + slot_tab.size() * sizeof(void*) + 15) & ~(size_t)15;
+      const size_t o_cids = o_args + air::N_COMPONENTS * sizeof(ConstraintArgs);
+      d_ctab.alloc(o_cids + air::N_COMPONENTS * sizeof(int) + 16);
+      uint8_t* const ctab = d_ctab.as<uint8_t>();
+      acc_top.d_view = (uint32_t**)(ctab + o_top);
+      acc_rest.d_view = (uint32_t**)(ctab + o_rest);
+      uint32_t** const d_slot_tab = (uint32_t**)(ctab + o_slot);
       // arguments of every component first: the small ones (<= 2^SMALL_COMPONENT_MAX_LOG rows) go to ONE batched launch
       // whose argument array has to be uploaded before the fork
       std::vector<ConstraintArgs> cargs(air::N_COMPONENTS);
@@ -753,7 +782,7 @@ struct SegmentProver {
           a.pp = cdom_cols(0, 0);
           a.rels = drel.as<DevRelations>();
           a.coeff = d_powers.u32() + 4 * coff[c];
-          a.acc = slot_of[c] >= 0 ? d_slot_tab.as<uint32_t*>() + 4 * slot_of[c] : accs.at(it->first).dev();
+          a.acc = slot_of[c] >= 0 ? d_slot_tab + 4 * slot_of[c] : accs.at(it->first).dev();
           a.log_size = clog[c];
           a.n_base = info.n_base_constraints;
           (pf.claimed_sums[c] * inv(M31::from_u32(1u << clog[c]))).to_u32(a.cumsum_shift);
@@ -769,7 +798,17 @@ struct SegmentProver {
           }
         }
       }
-      DevBuf d_small_args = upload(small_args, st), d_small_cids = upload(small_cids, st);
+      {
+        std::vector<uint8_t> blob(o_cids + small_cids.size() * sizeof(int));
+        memcpy(blob.data() + o_top, acc_top.ptrs.data(), acc_top.ptrs.size() * sizeof(void*));
+        if (!acc_rest.ptrs.empty()) memcpy(blob.data() + o_rest, acc_rest.ptrs.data(), acc_rest.ptrs.size() * sizeof(void*));
+        if (!slot_tab.empty()) memcpy(blob.data() + o_slot, slot_tab.data(), slot_tab.size() * sizeof(void*));
+        if (!small_args.empty()) memcpy(blob.data() + o_args, small_args.data(), small_args.size() * sizeof(ConstraintArgs));
+        if (!small_cids.empty()) memcpy(blob.data() + o_cids, small_cids.data(), small_cids.size() * sizeof(int));
+        stage_upload(d_ctab.p, blob.data(), blob.size(), st);
+      }
+      const ConstraintArgs* const d_small_args = (const ConstraintArgs*)(ctab + o_args);
+      const int* const d_small_cids = (const int*)(ctab + o_cids);
       // Transcript step on the device (prover.rs:131, stwo prove: mix the interaction root, draw the random coefficient): the
       // channel state goes over in the kernel arguments, k_chan_init_mix_root_draw mixes root 2 and draws the coefficient,
       // k_coeff_powers expands its powers — the constraint kernels start right behind the tree, with no host round trip.  The
@@ -782,8 +821,8 @@ struct SegmentProver {
         uint32_t* d_chan = d_step2.u32();
         chan_init_mix_root_draw(cw, d_chan, P.trees[2].merkle.layers[0].u32(), d_chan + 16, d_chan + 20, st);
         coeff_powers(d_chan + 16, d_powers.u32(), (uint32_t)total_constraints, st);
-        CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT2, d_chan + 20, 32, hipMemcpyDeviceToHost, st));
-        CM_HIP(hipMemcpyAsync(pinned_words() + PIN_COEFF, d_chan + 16, 16, hipMemcpyDeviceToHost, st));
+        static_assert(PIN_COEFF + 4 == PIN_ROOT2, "{coefficient, root 2} come back in one copy");
+        CM_HIP(hipMemcpyAsync(pinned_words() + PIN_COEFF, d_chan + 16, 48, hipMemcpyDeviceToHost, st));
       }
       P.tick("interaction_commit");
       for (int t = 0; t < 3; t++) for (auto l : P.trees[t].coeffs.logs) pf.cells += 1ull << l;
@@ -801,7 +840,7 @@ struct SegmentProver {
         }
         return v;
       }();
-      launch_constraints_small(d_small_args.as<ConstraintArgs>(), d_small_cids.as<int>(), (uint32_t)small_args.size(), small_max_log,
+      launch_constraints_small(d_small_args, d_small_cids, (uint32_t)small_args.size(), small_max_log,
                                fk.stream(cplan[4]));   // first: latency-bound, hidden under the large kernels
       int gi = 0, small_rr = 0;
       static const bool early_interp = getenv("CM_NO_EARLY_ACC_INTERP") == nullptr;   // A/B switch
