@@ -453,7 +453,16 @@ struct SegmentProver {
     } else {
       std::vector<uint32_t> logs(air::PREPROC_LOG, air::PREPROC_LOG + air::N_PREPROC);
       pp_evals.alloc(logs, st);
-      for (int i = 0; i < air::N_PREPROC; i++) launch_preproc(i, logs[i], pp_evals.ptrs[i], st);
+      // The constant columns are generated on the side stream that builds the twiddles and later commits tree 0 (the same HIP
+      // stream: ordered behind one, in front of the other): nothing before the LogUp phase reads them on the main stream, which
+      // starts trace generation ~150 us earlier this way.  CM_PP_MAIN=1: on the main stream (A/B).
+      static const bool pp_side = getenv("CM_PP_MAIN") == nullptr;
+      hipStream_t pps = st;
+      if (pp_side) {
+        if (!tw_fork) tw_fork.reset(new Fork(st));   // (twiddle cache on: nothing else is on that stream yet)
+        pps = tw_fork->stream(Fork::N - 1);
+      }
+      for (int i = 0; i < air::N_PREPROC; i++) launch_preproc(i, logs[i], pp_evals.ptrs[i], pps);
       build_tree0 = true;   // enqueued on a side stream right after the trace-generation launches (below)
     }
     ht.mark("preprocessed enqueued");
