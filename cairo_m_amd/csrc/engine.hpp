@@ -204,7 +204,7 @@ struct DevBuf {
 // synchronised and until the next call on this thread.
 const void* stage_download_async(const void* src, size_t bytes, hipStream_t st);
 // 1024 pinned words per host thread; fixed slots (words): 0 range-check flag, 2-3 grind nonce, 8-15 Merkle root,
-// 16-23 root of tree 0, 32-167 claimed sums, 172-175 random coefficient + 176-183 root of tree 2 (one copy), 208-211 the OODS felt of the device-side step, 256-351 FRI challenges, 384-575 FRI roots, 640-1023 last FRI layer
+// 16-23 root of tree 0, 32-167 claimed sums, 172-175 random coefficient + 176-183 root of tree 2 (one copy), 208-219 the OODS felt + root 3 of the device-side step, 256-351 FRI challenges, 384-575 FRI roots, 640-1023 last FRI layer
 uint32_t* pinned_words();
 constexpr uint32_t INTERACTION_POW_BITS = 2;   // relations::INTERACTION_POW_BITS (prover.rs:90, verifier.rs:55-58)
 enum PinnedSlot : uint32_t { PIN_FLAG = 0, PIN_NONCE = 2, PIN_ROOT = 8, PIN_ROOT0 = 16, PIN_SUMS = 32, PIN_COEFF = 172, PIN_ROOT2 = 176, PIN_STEP1 = 192, PIN_STEP3 = 208, PIN_ALPHAS = 256, PIN_ROOTS = 384,

@@ -20,13 +20,14 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
   uint32_t layer_log = resume ? resume->layer_log : q_logs[0] - 1;
   if (resume) { have_first = false; inner_fold0 = 1 + resume->n_inner_before; }
   const uint32_t n_inner = layer_log > last_log ? layer_log - last_log : 0;
-  DevBuf d_chan(64), d_alphas((size_t)(n_inner + 1) * 16), d_roots((size_t)(n_inner + 1) * 32);
-  {
-    uint32_t cw[9];
-    memcpy(cw, ch.digest.data(), 32);
-    cw[8] = ch.n_sent;
-    stage_upload(d_chan.p, cw, sizeof(cw), st);
-  }
+  // challenges and roots share one buffer ({alphas | roots}: they come back in ONE copy at the end)
+  DevBuf d_ar((size_t)(n_inner + 1) * 48);
+  struct Words { uint32_t* p; uint32_t* u32() const { return p; } };
+  const Words d_alphas{d_ar.u32()}, d_roots{d_ar.u32() + (size_t)(n_inner + 1) * 4};
+  Words d_chan{nullptr};   // the device copy of the channel {digest[8], n_sent}: travels with the tree tables (one upload)
+  std::vector<uint32_t> chan_words(16, 0);
+  memcpy(chan_words.data(), ch.digest.data(), 32);
+  chan_words[8] = ch.n_sent;
   // every layer above the single-launch tail is allocated up front so that the column tables of all their
   // Merkle trees (and of the first-layer tree) travel in ONE host->device copy
   std::vector<std::unique_ptr<InnerLayer>> pre;
@@ -50,6 +51,7 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
       ub.add(il->tree.cols, &il->tree.d_cols_view);
       pre.push_back(std::move(il));
     }
+    ub.add(chan_words, &d_chan.p);
     fri_tables = ub.flush(st);
     if (!resume) {
       first_tree.commit_prepared(st);
@@ -157,14 +159,14 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
     std::vector<QM31> vals;
     // challenges, roots and the last layer come back in ONE round trip (pinned slots; a large last layer falls back to the
     // batched gather)
-    CM_CHECK((n_inner + 1) * 4 <= PIN_ROOTS - PIN_ALPHAS && (n_inner + 1) * 8 <= PIN_LAST_LAYER - PIN_ROOTS, "fri: too many layers");
+    CM_CHECK((n_inner + 1) * 12 <= PIN_LAST_LAYER - PIN_ALPHAS, "fri: too many layers");
     const uint32_t* h_alphas = pinned_words() + PIN_ALPHAS;
-    const uint32_t* h_roots = pinned_words() + PIN_ROOTS;
-    CM_HIP(hipMemcpyAsync((void*)h_alphas, d_alphas.p, (size_t)(n_inner + 1) * 16, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync((void*)h_roots, d_roots.p, (size_t)(n_inner + 1) * 32, hipMemcpyDeviceToHost, st));
+    const uint32_t* h_roots = h_alphas + (size_t)(n_inner + 1) * 4;
+    CM_HIP(hipMemcpyAsync((void*)h_alphas, d_ar.p, (size_t)(n_inner + 1) * 48, hipMemcpyDeviceToHost, st));
     if (4 * n <= PIN_WORDS - PIN_LAST_LAYER) {
       uint32_t* ll = pinned_words() + PIN_LAST_LAYER;
-      for (int k = 0; k < 4; k++) CM_HIP(hipMemcpyAsync(ll + k * n, c4[k], n * 4, hipMemcpyDeviceToHost, st));
+      if (c4[1] == c4[0] + n && c4[2] == c4[0] + 2 * n && c4[3] == c4[0] + 3 * n) CM_HIP(hipMemcpyAsync(ll, c4[0], n * 16, hipMemcpyDeviceToHost, st));   // one arena
+      else for (int k = 0; k < 4; k++) CM_HIP(hipMemcpyAsync(ll + k * n, c4[k], n * 4, hipMemcpyDeviceToHost, st));
       CM_HIP(hipStreamSynchronize(st));
       for (uint32_t i = 0; i < n; i++) {
         uint32_t w4[4] = {ll[i], ll[n + i], ll[2 * n + i], ll[3 * n + i]};

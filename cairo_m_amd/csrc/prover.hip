@@ -365,6 +365,8 @@ struct SegmentProver {
   FriPhase fri;
   struct ORef { int t; uint32_t c; bool prev; };
   struct OJob { uint32_t log; bool prev; CPoint<QM31> pt; std::vector<ORef> refs; size_t off = 0, out_off = 0; };
+  std::vector<OJob> ojobs;                    // sampling jobs, built (and their pointer table uploaded) by oods_prepare()
+  size_t n_oods_out = 0;
   struct QRef { int t; uint32_t c; };
   struct QEntry { uint32_t col; uint32_t sidx; };   // column of the group, index of its sampled value in d_oods_out
   struct QBatch { CPoint<QM31> pt; std::vector<QEntry> entries; };
@@ -903,17 +905,19 @@ struct SegmentProver {
         add_columns_multi(acc_top.dev(), as, 4, st);
       }
       t.coeffs = std::move(acc_top);
+      oods_prepare();   // needs tree 3's coefficient pointers, nothing of its commitment
       P.commit_enqueue(t, nullptr, true, st);
     }
   }
 
-  // OODS point, mask values of every column (eval_at_point), DEEP-quotient plan built while the kernels run
-  void oods_sampling() {
-    // Sampling jobs = (log size, point): every column at the OODS point, plus the previous-row mask
-    // (oods - trace_step(log)) of each component's last LogUp column group.  All jobs share one pointer-table
-    // upload, one scratch buffer and ONE device->host copy of the results.  Everything but the points themselves is
-    // built (and uploaded) here, while tree 3 is being committed; the points follow once its root is in the transcript.
-    std::vector<OJob> ojobs;
+  // Sampling jobs = (log size, point): every column at the OODS point, plus the previous-row mask
+  // (oods - trace_step(log)) of each component's last LogUp column group.  All jobs share one pointer-table
+  // upload, one scratch buffer and ONE device->host copy of the results.  Everything but the points themselves is
+  // built and uploaded HERE, in front of the composition tree's kernels in stream order (called by composition() right
+  // before that tree is enqueued): the table's host->device copy is off the path root 3 -> evaluation kernels.
+  void oods_prepare() {
+    ojobs.clear();
+    n_oods_out = 0;
     {
       std::map<uint32_t, std::vector<ORef>> groups;
       for (int t = 0; t < 4; t++)
@@ -926,7 +930,6 @@ struct SegmentProver {
       }
       for (auto& kv : pgroups) ojobs.push_back(OJob{kv.first, true, {}, kv.second});
     }
-    size_t n_oods_out = 0;
     {
       std::vector<const uint32_t*> table;
       for (auto& j : ojobs) {
@@ -938,6 +941,10 @@ struct SegmentProver {
       d_oods_table = upload(table, st);
       d_oods_out.alloc(n_oods_out * 16);
     }
+  }
+
+  // OODS point, mask values of every column (eval_at_point), DEEP-quotient plan built while the kernels run
+  void oods_sampling() {
     // where the sampled value of (tree, column) lands in d_oods_out: the DEEP-quotient coefficients are computed on the
     // device straight from there (k_quotient_coeffs)
     std::vector<std::vector<uint32_t>> sidx_cur(4), sidx_prev(4);
@@ -962,8 +969,7 @@ struct SegmentProver {
       uint32_t* d_chan = d_step2.u32();
       chan_mix_root_draw(d_chan, P.trees[3].merkle.layers[0].u32(), d_step3.u32(), d_step3.u32() + 4, st);
       // root 3 and the felt come back HERE in stream order — in front of the evaluation kernels enqueued next
-      CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT, P.trees[3].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, st));
-      CM_HIP(hipMemcpyAsync(pinned_words() + PIN_STEP3, d_step3.p, 16, hipMemcpyDeviceToHost, st));
+      CM_HIP(hipMemcpyAsync(pinned_words() + PIN_STEP3, d_step3.p, 48, hipMemcpyDeviceToHost, st));   // {felt[4], root 3 [8]}: one copy
       if (!ev_root3) CM_HIP(hipEventCreateWithFlags(&ev_root3, hipEventDisableTiming));
       CM_HIP(hipEventRecord(ev_root3, st));
       std::vector<EapJob> ej;
@@ -983,7 +989,7 @@ struct SegmentProver {
     ht.mark("composition: enqueued, waiting for root 3");
     if (dev_oods) {   // the root comes back behind the tree, NOT behind the evaluation kernels enqueued after it
       CM_HIP(hipEventSynchronize(ev_root3));
-      memcpy(P.trees[3].root.data(), pinned_words() + PIN_ROOT, 32);
+      memcpy(P.trees[3].root.data(), pinned_words() + PIN_STEP3 + 4, 32);
     } else {
       P.trees[3].merkle.root(P.trees[3].root.data(), st);
     }
