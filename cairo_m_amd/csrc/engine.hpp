@@ -76,6 +76,7 @@ void merkle_layer_quad(uint32_t log_size, const uint32_t* d_prev, const uint32_t
 constexpr uint32_t MERKLE_QUAD_MAX_LOG = 12, MERKLE_QUAD_MIN_COLS = 64;
 // up to MERKLE_MULTI_LEVELS consecutive layers per launch (top layer must have >= 256 nodes)
 constexpr uint32_t MERKLE_MULTI_LEVELS = 4;
+constexpr uint32_t MERKLE_PACE_LOG = 18;     // MerkleTree::pace_ev sits in front of the first layer of at most 2^18 nodes
 constexpr uint32_t MERKLE_MULTI_MAX_TOP = 19;  // layers of 2^19 nodes and more get their own launch
 struct MerkleMultiArgs {
   uint32_t top_log, n_levels;

@@ -80,6 +80,11 @@ struct MerkleTree {
   std::vector<uint32_t> col_logs;        // same order
   DevBuf d_cols;                         // device copy of `cols`
 
+  // Optional: recorded on the commit stream in front of the first layer of at most 2^MERKLE_PACE_LOG nodes — what follows is the
+  // latency-bound top of the tree (~0.15-0.2 ms).  The prover's host thread waits for THIS event, not for the whole tree, before
+  // it enqueues the next phase (Prover::pace): its wake-up and launch latency hide behind the tree top.
+  hipEvent_t pace_ev = nullptr;
+  bool pace_recorded = false;
   const uint32_t* const* d_cols_view = nullptr;  // device copy of `cols` inside somebody else's upload (UploadBatch)
   const uint32_t* const* dcols() const { return d_cols_view ? d_cols_view : d_cols.as<const uint32_t*>(); }
 
@@ -105,7 +110,9 @@ struct MerkleTree {
     size_t ci = 0;
     const int tail_top = (int)std::min<uint32_t>(max_log, MERKLE_TAIL_LOG);
     static const bool use_top = getenv("CM_NO_MERKLE_TOP") == nullptr;   // A/B switch
+    pace_recorded = false;
     for (int log = (int)max_log; log > tail_top;) {
+      if (pace_ev && !pace_recorded && log <= (int)MERKLE_PACE_LOG) { CM_HIP(hipEventRecord(pace_ev, st)); pace_recorded = true; }
       // the whole top of the tree in one launch once no wide layer is left among the per-lane levels
       if (use_top && log <= (int)MERKLE_TOP_MAX_LOG && log >= 9) {
         bool wide_inside = false;

@@ -549,6 +549,7 @@ struct SegmentProver {
     // chain of small launches (enqueued first, that chain delayed the first tree-1 kernel by the host time of ~30 launches)
     static const bool tree1_first = getenv("CM_TREE0_FIRST") == nullptr;   // A/B switch
     if (build_tree0 && !tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
+    P.trees[1].merkle.pace_ev = Prover::pace_event(1);
     P.commit_enqueue(P.trees[1], &tr_evals, false, st);
     if (build_tree0 && tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
     // Root 0 first (transcript order, prover.rs:70-82: root 0, claim, root 1): tree 0 has been running on its side stream next
@@ -579,7 +580,7 @@ struct SegmentProver {
       step_pow_relations(cw, P.trees[1].merkle.layers[0].u32(), INTERACTION_POW_BITS, air::N_RELATIONS, air::MAX_REL_SIZE, rel,
                          rel + 4 * air::N_RELATIONS, d_step1.u32(), st);
       CM_HIP(hipMemcpyAsync(pinned_words() + PIN_STEP1, d_step1.p, 16 * 4, hipMemcpyDeviceToHost, st));
-      P.pace();
+      P.pace(&P.trees[1].merkle);
     }
     P.tick("trace_commit");
 
@@ -655,6 +656,7 @@ struct SegmentProver {
         for (auto& g : grps)
           if (!small_commit_serves(g.log, cfg.log_blowup_factor)) interpolate(d_table.as<uint32_t*>() + g.off, g.n, g.log, *P.tw, st);
       }
+      t.merkle.pace_ev = Prover::pace_event(2);
       P.commit_enqueue(t, nullptr, true, st, true, /*small_evals_in_place=*/true);   // the small columns: interpolated + extended in one launch
     }
     {
@@ -837,7 +839,7 @@ struct SegmentProver {
       }
       P.tick("interaction_commit");
       for (int t = 0; t < 3; t++) for (auto l : P.trees[t].coeffs.logs) pf.cells += 1ull << l;
-      P.pace();
+      P.pace(&P.trees[2].merkle);
       KProfRegion kreg("k_constraints(region)", st);
       Fork fk(st);
       // side-stream plan of the region (A/B: CM_CSTREAMS="g0,g1,g2,g3,small,slot0,slot1,slot2" = stream index of the size

@@ -203,10 +203,22 @@ struct Prover {
   // device-side step and only then enqueues the next phase: one launch latency instead of two or three host round trips.
   // With several proofs in flight (cm_prove_many) other proofs' kernels fill the dispatch slack and running ahead is the
   // better choice (10.3 vs 10.5 ms per proof with 4 in flight), so pacing applies to a lone proof only.
-  void pace() {
+  // `tree`: wait only until that tree's commitment has reached its latency-bound top (MerkleTree::pace_ev) — the fork waits of
+  // the next phase then sit blocked for ~0.2 ms instead of milliseconds, and the host's wake-up + launch latency (~50 us of idle
+  // GPU per site with the full drain) hides behind the tree top.  CM_PACE_EARLY=0: the full drain.
+  void pace(MerkleTree* tree = nullptr) {
     static const int mode = getenv("CM_PACE") ? atoi(getenv("CM_PACE")) : -1;   // 0 = always run ahead, 1 = always drain (A/B)
+    static const bool early = !(getenv("CM_PACE_EARLY") && atoi(getenv("CM_PACE_EARLY")) == 0);
     const bool drain = mode == 1 || (mode != 0 && g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);
-    if (drain) CM_HIP(hipStreamSynchronize(st));
+    if (!drain) return;
+    if (early && tree && tree->pace_ev && tree->pace_recorded) CM_HIP(hipEventSynchronize(tree->pace_ev));
+    else CM_HIP(hipStreamSynchronize(st));
+  }
+  // one event per tree slot, created once per host thread
+  static hipEvent_t pace_event(int slot) {
+    static thread_local hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (!ev[slot]) CM_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+    return ev[slot];
   }
 };
 
