@@ -1213,14 +1213,16 @@ struct SegmentProver {
       gb.run(st);
       ht.mark("decommit: gather run (upload+kernel+d2h)");
       fri.finish_decommit(gb, pf);
+      ht.mark("decommit: finish fri");
       pf.decommitments.resize(4);
       pf.queried_values.resize(4);
       for (int t = 0; t < 4; t++) {
         MerkleTree::finish_decommit(tree_plan[t], gb, pf.queried_values[t], pf.decommitments[t]);
         pf.commitments.push_back(P.trees[t].root);
       }
+      ht.mark("decommit: finish trees");
     }
-    ht.mark("decommit: finish");
+    ht.mark("decommit: finish (locals released)");
     P.tick("decommit");
   }
 };
