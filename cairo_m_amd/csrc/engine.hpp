@@ -149,6 +149,9 @@ void stage_forget_stream(hipStream_t st);
 // The prover's main stream of the calling host thread (created on first use, non-blocking): concurrent proofs
 // from different host threads run on different streams and overlap on the GPU.
 hipStream_t thread_main_stream();
+// side stream i of the calling host thread (the streams Fork hands out), with NO ordering against anything: the caller orders it
+// with events (Prover::commit_enqueue runs the transforms of a commitment there, next to the Merkle launches on the main stream)
+hipStream_t thread_side_stream(int i);
 
 // Fork/join over a small set of side streams (thread-local, created once): independent per-component
 // launches of one phase run concurrently instead of serialising 34 tiny kernels on one stream.

@@ -58,6 +58,9 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile[];   // 2^TL + 2^(TL-5) words
   const uint32_t* __restrict__ src = a.src[blockIdx.y];
   uint32_t* __restrict__ dst = a.dst[blockIdx.y];
+  // raw buffer resources over the two columns (stride 0, no bounds: offsets stay below 2^(n+2) <= 2^30 bytes)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, 0xffffffffu, 0x00020000);
   const uint32_t low_fixed_bits = a.lo - M;
   const uint32_t lowf = blockIdx.x & ((1u << low_fixed_bits) - 1);
   const uint32_t high = blockIdx.x >> low_fixed_bits;
@@ -87,10 +90,25 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
       c[e] = ((g >> b) << (b + k)) | (j << b) | (g & ((1u << b) - 1));
     }
     auto ptile = [&](uint32_t e) -> uint32_t { return pli0 + c[e] + (c[e] >> 5); };
-    auto gel = [&](uint32_t e) -> uint32_t { return gi0 + (((c[e] >> M) << lo) | (c[e] & ((1u << M) - 1))); };
+    // global index of element e = gi0 (per lane) + cgl(e) (the same in every lane: a compile-time constant shifted by the
+    // runtime `lo`).  The HBM accesses of a round are BUFFER instructions: one per-lane byte offset shared by all 2^E accesses
+    // (voffset) plus a scalar offset per element (soffset) — `buffer_load_dword v, v_off, s[rsrc], s_e offen` — instead of a
+    // v_lshl_add_u32 + v_lshl_add_u64 pair per access (two VOP3, one of them 64-bit: 64 of the ~1000 VALU instructions of a
+    // strided 9-layer pass; flat `global_` addressing has no scalar-offset operand and the compiler re-associates a uniform
+    // base pointer back into per-lane 64-bit adds).
+    auto cgl = [&](uint32_t e) -> uint32_t { return ((c[e] >> M) << lo) | (c[e] & ((1u << M) - 1)); };
+    auto gel = [&](uint32_t e) -> uint32_t { return gi0 + cgl(e); };
+    const uint32_t gb0 = gi0 << 2;   // byte offset of the lane inside the column
     const bool staged_in = (rr == 0) && INVERSE && M == 0;
     if (rr == 0 && !staged_in) {
-      if (padded) {
+      if (padded && !INVERSE && a.hi == a.n && a.in_len == (1u << (a.n - 1))) {
+        // extension by two (every LDE of the prover): the upper half of the input is implicit zero padding and the top layer,
+        // applied first, turns every (x, 0) into (x, x) without a twiddle (below) — so only the elements of the LOWER half are
+        // loaded (all of them in range: no bounds test, no select) and the rest is filled in by that layer
+#pragma clang loop unroll(full)
+        for (uint32_t e = 0; e < NE; e++)
+          v[e] = ((e >> (k - 1)) & 1u) ? M31(0u) : M31((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)gb0, (int)(cgl(e) << 2), 0));
+      } else if (padded) {
         // zero-extension without exec-masked loads: out-of-range lanes read element 0 (one cached line) and the
         // value is replaced by a select, so the loads still issue back to back
 #pragma clang loop unroll(full)
@@ -102,7 +120,7 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
         }
       } else {  // no per-element bounds test: the loads issue back to back instead of as exec-masked branches
 #pragma clang loop unroll(full)
-        for (uint32_t e = 0; e < NE; e++) { const uint32_t gi = gel(e); __builtin_assume(gi < (1u << 29)); v[e] = M31(src[gi]); }
+        for (uint32_t e = 0; e < NE; e++) v[e] = M31((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)gb0, (int)(cgl(e) << 2), 0));
       }
     } else {
       if (staged_in) {
@@ -172,7 +190,7 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
       for (uint32_t e = 0; e < NE; e++) {
         M31 o = v[e];
         if (INVERSE && a.scale != 1u) o = sc * o;   // the doubled operand of M31 operator* is the loop-invariant one
-        dst[gel(e)] = o.v;
+        __builtin_amdgcn_raw_buffer_store_b32((int)o.v, rdst, (int)gb0, (int)(cgl(e) << 2), 0);
       }
     } else {
 #ifndef CM_FFT_ABL_NO_LDS  /* tools/fft_lab: cost of the LDS exchanges (results are wrong) */

@@ -9,6 +9,7 @@
 #pragma once
 #include "engine.hpp"
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <array>
 #include <string.h>
@@ -102,8 +103,21 @@ struct MerkleTree {
     d_cols = upload(cols, st);
     commit_prepared(st);
   }
+  // One launch of the commitment: the layers 2^hi .. 2^lo it produces (it reads the columns of exactly those sizes and the
+  // hashes of layer hi + 1).  `pace_before`: the tree's pace event is recorded in front of it.
+  struct CommitLaunch { int hi, lo; bool pace_before; std::function<void(hipStream_t)> run; };
   // after prepare(); the device copy of `cols` is either d_cols or d_cols_view
   void commit_prepared(hipStream_t st) {
+    for (auto& l : plan_commit()) run_launch(l, st);
+  }
+  void run_launch(const CommitLaunch& l, hipStream_t st) {
+    if (l.pace_before && pace_ev) { CM_HIP(hipEventRecord(pace_ev, st)); pace_recorded = true; }
+    l.run(st);
+  }
+  // Allocates every layer and returns the launches of the commitment in order (largest layer first).  The caller may interleave
+  // them with the transforms that produce the columns (Prover::commit_enqueue: launch k only needs the columns of >= 2^lo rows).
+  std::vector<CommitLaunch> plan_commit() {
+    std::vector<CommitLaunch> plan;
     uint32_t max_log = cols.empty() ? 0 : col_logs[0];
     layers.clear();
     layers.resize(max_log + 1);
@@ -111,8 +125,13 @@ struct MerkleTree {
     const int tail_top = (int)std::min<uint32_t>(max_log, MERKLE_TAIL_LOG);
     static const bool use_top = getenv("CM_NO_MERKLE_TOP") == nullptr;   // A/B switch
     pace_recorded = false;
+    bool pace_planned = false;
+    auto push = [&](int hi, int lo, std::function<void(hipStream_t)> f) {
+      const bool pace = !pace_planned && hi <= (int)MERKLE_PACE_LOG;
+      if (pace) pace_planned = true;
+      plan.push_back(CommitLaunch{hi, lo, pace, std::move(f)});
+    };
     for (int log = (int)max_log; log > tail_top;) {
-      if (pace_ev && !pace_recorded && log <= (int)MERKLE_PACE_LOG) { CM_HIP(hipEventRecord(pace_ev, st)); pace_recorded = true; }
       // the whole top of the tree in one launch once no wide layer is left among the per-lane levels
       if (use_top && log <= (int)MERKLE_TOP_MAX_LOG && log >= 9) {
         bool wide_inside = false;
@@ -135,8 +154,8 @@ struct MerkleTree {
             layers[l].alloc((size_t)32 << l);
             a.layers[l] = layers[l].u32();
           }
-          merkle_top(a, st);
-          return;
+          push(log, 0, [a](hipStream_t st) mutable { merkle_top(a, st); });
+          return plan;
         }
       }
       // group of up to MERKLE_MULTI_LEVELS layers per launch (the top layer of a group needs >= 256 nodes)
@@ -163,8 +182,11 @@ struct MerkleTree {
         ci += n_here;
         layers[log].alloc((size_t)32 << log);
         const uint32_t* prev = (log < (int)max_log) ? layers[log + 1].u32() : nullptr;
-        if (wide) merkle_layer_quad((uint32_t)log, prev, dcols() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
-        else merkle_layer((uint32_t)log, prev, dcols() + c0, (uint32_t)(ci - c0), layers[log].u32(), st);
+        const uint32_t* const* dc = dcols() + c0;
+        const uint32_t nc = (uint32_t)(ci - c0);
+        uint32_t* outp = layers[log].u32();
+        if (wide) push(log, log, [=](hipStream_t st) { merkle_layer_quad((uint32_t)log, prev, dc, nc, outp, st); });
+        else push(log, log, [=](hipStream_t st) { merkle_layer((uint32_t)log, prev, dc, nc, outp, st); });
         log--;
         continue;
       }
@@ -183,7 +205,7 @@ struct MerkleTree {
         a.layers[lv] = layers[l].u32();
         bytes += (4.0 * (a.col_end[lv] - a.col_begin[lv]) + 32.0 + ((lv == 0 && a.prev) ? 64.0 : 0.0)) * (double)((size_t)1 << l);
       }
-      merkle_multi(a, bytes, st);
+      push(log, log - levels + 1, [a, bytes](hipStream_t st) { merkle_multi(a, bytes, st); });
       log -= levels;
     }
     {
@@ -199,8 +221,9 @@ struct MerkleTree {
         layers[log].alloc((size_t)32 << log);
         a.layers[log] = layers[log].u32();
       }
-      merkle_tail(a, st);
+      push(tail_top, 0, [a](hipStream_t st) { merkle_tail(a, st); });
     }
+    return plan;
   }
   void root(uint8_t out[32], hipStream_t st) const {
     uint32_t* pin = pinned_words() + PIN_ROOT;

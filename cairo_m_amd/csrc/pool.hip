@@ -185,6 +185,7 @@ struct SideStreams {
 SideStreams& side() { static thread_local SideStreams* s = new SideStreams(); return *s; }
 }  // namespace
 
+hipStream_t thread_side_stream(int i) { return side().s[((i % Fork::N) + Fork::N) % Fork::N]; }
 Fork::Fork(hipStream_t main_stream) : main(main_stream) { CM_HIP(hipEventRecord(side().fork_ev, main)); }
 int Fork::main_or(int side_index) {
   static const bool on = !(getenv("CM_FORK_MAIN") && atoi(getenv("CM_FORK_MAIN")) == 0);

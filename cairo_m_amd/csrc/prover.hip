@@ -550,7 +550,7 @@ struct SegmentProver {
     static const bool tree1_first = getenv("CM_TREE0_FIRST") == nullptr;   // A/B switch
     if (build_tree0 && !tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
     P.trees[1].merkle.pace_ev = Prover::pace_event(1);
-    P.commit_enqueue(P.trees[1], &tr_evals, false, st);
+    P.commit_enqueue(P.trees[1], &tr_evals, false, st, true, false, P.pipe_stream());
     if (build_tree0 && tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
     // Root 0 first (transcript order, prover.rs:70-82: root 0, claim, root 1): tree 0 has been running on its side stream next
     // to all of the above; its root is copied on THAT stream and waited for here, while the GPU is still busy with tree 1.
@@ -640,24 +640,12 @@ struct SegmentProver {
       sums_ready = ev_sums;
     }
     P.tick("interaction_gen");
-    // interpolate in place: coeffs alias the evaluation buffer
+    // interpolate in place: coeffs alias the evaluation buffer (every size group right in front of its extension)
     {
       CommittedTree& t = P.trees[2];
       t.coeffs = std::move(it_evals);
-      {
-        std::vector<uint32_t*> table;
-        struct Grp { uint32_t log, n; size_t off; };
-        std::vector<Grp> grps;
-        for (auto& kv : by_log(t.coeffs.logs)) {
-          grps.push_back(Grp{kv.first, (uint32_t)kv.second.size(), table.size()});
-          for (auto i : kv.second) table.push_back(t.coeffs.ptrs[i]);
-        }
-        DevBuf d_table = upload(table, st);
-        for (auto& g : grps)
-          if (!small_commit_serves(g.log, cfg.log_blowup_factor)) interpolate(d_table.as<uint32_t*>() + g.off, g.n, g.log, *P.tw, st);
-      }
       t.merkle.pace_ev = Prover::pace_event(2);
-      P.commit_enqueue(t, nullptr, true, st, true, /*small_evals_in_place=*/true);   // the small columns: interpolated + extended in one launch
+      P.commit_enqueue(t, nullptr, true, st, true, /*evals_in_place=*/true, P.pipe_stream());
     }
     {
       CM_HIP(hipEventSynchronize(sums_ready));
@@ -908,7 +896,7 @@ struct SegmentProver {
       }
       t.coeffs = std::move(acc_top);
       oods_prepare();   // needs tree 3's coefficient pointers, nothing of its commitment
-      P.commit_enqueue(t, nullptr, true, st);
+      P.commit_enqueue(t, nullptr, true, st, true, false, P.pipe_stream());
     }
   }
 

@@ -130,11 +130,25 @@ struct Prover {
   }
   // everything of a commitment except the root read-back, on stream `s` (tree 0 is built on a side stream while the
   // execution trace is generated: both are chains of small launches)
-  // small_evals_in_place: with from_coeffs, the SMALL columns of t.coeffs (small_commit_serves) still hold evaluations —
-  // the caller interpolated only the large ones — and the fused small-column kernel interpolates them in place
+  // evals_in_place: with from_coeffs, the columns of t.coeffs still hold EVALUATIONS: every size group is interpolated in place
+  // right in front of its extension (the small columns by the fused small-column kernel)
+  // s_tr: SOFTWARE PIPELINE of the commitment (prover.rs:71-73, 80-82, 100-102: `extend_evals` + `commit`).  The transforms run on
+  // `s_tr`, size group by size group from the largest down, the Merkle launches on `s`: the hashing of layer 2^L starts as soon as
+  // the groups of >= 2^L rows are extended, while the next group is still being transformed.  The Blake2s layers are bound by VALU
+  // issue, the transform passes wait on HBM / LDS for ~40 % of their cycles (profiles/r03h_pmc_sq.json) — back to back on one queue
+  // they never met.  `s_tr` must already be ordered behind everything the transforms read (a Fork side stream of `s`); when this
+  // returns `s` is ordered behind all of `s_tr`'s work.  null = everything on `s` (CM_COMMIT_PIPE=0 forces that form: A/B).
   void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true,
-                      bool small_evals_in_place = false) {
+                      bool evals_in_place = false, hipStream_t s_tr = nullptr) {
+    static const bool pipe_on = !(getenv("CM_COMMIT_PIPE") && atoi(getenv("CM_COMMIT_PIPE")) == 0);
+    if (!pipe_on || !with_merkle || s_tr == s) s_tr = nullptr;
     const std::vector<uint32_t> logs = from_coeffs ? t.coeffs.logs : evals->logs;
+    if (s_tr) {   // a tree of ONE large size group (composition, preprocessed-like trees) has nothing to overlap: two cross-queue
+                  // hand-overs (~20 us each) for nothing — composition_commit 0.77 -> 0.81 ms when it went through the pipeline
+      uint32_t big_groups = 0;
+      for (auto& kv : by_log(logs)) if (!small_commit_serves(kv.first, cfg.log_blowup_factor)) big_groups++;
+      if (big_groups < 2) s_tr = nullptr;
+    }
     UploadBatch ub;
     if (!from_coeffs) { t.coeffs.alloc(logs, s, false); ub.add(t.coeffs.ptrs, &t.coeffs.d_view); }
     std::vector<uint32_t> lde_logs(logs);
@@ -164,15 +178,40 @@ struct Prover {
     uint32_t small_max = 0;
     for (size_t i = 0; i < logs.size(); i++)
       if (small_commit_serves(logs[i], cfg.log_blowup_factor)) {
-        const uint32_t* src = !from_coeffs ? evals->ptrs[i] : small_evals_in_place ? t.coeffs.ptrs[i] : nullptr;
+        const uint32_t* src = !from_coeffs ? evals->ptrs[i] : evals_in_place ? t.coeffs.ptrs[i] : nullptr;
         sjobs.push_back(SmallCommitJob{src, t.coeffs.ptrs[i], t.lde.ptrs[i], logs[i], inv(M31::from_u32(1u << logs[i])).v});
         small_max = std::max(small_max, logs[i]);
       }
     SmallCommitJob* d_sjobs = nullptr;
     if (!sjobs.empty()) ub.add(sjobs, &d_sjobs);
     t.tables = ub.flush(s);   // ONE host->device copy for the whole tree
-    small_commit(d_sjobs, (uint32_t)sjobs.size(), small_max, cfg.log_blowup_factor, *tw, s);
-    for (auto& g : grps) {
+    hipStream_t ts = s;       // the stream of the transforms
+    if (s_tr) {               // the tables (and whatever else sits in front of this tree on `s`) first
+      hipEvent_t e = pipe_event();
+      CM_HIP(hipEventRecord(e, s));
+      CM_HIP(hipStreamWaitEvent(s_tr, e, 0));
+      ts = s_tr;
+    }
+    std::vector<MerkleTree::CommitLaunch> plan;
+    size_t next_launch = 0;
+    if (with_merkle && s_tr) plan = t.merkle.plan_commit();
+    // the Merkle launches whose columns all have at least 2^ready_log rows: behind what `ts` holds right now
+    auto hash_ready = [&](int ready_log) {
+      if (!s_tr) return;
+      bool waited = false;
+      while (next_launch < plan.size() && plan[next_launch].lo >= ready_log) {
+        if (!waited) {
+          hipEvent_t e = pipe_event();
+          CM_HIP(hipEventRecord(e, ts));
+          CM_HIP(hipStreamWaitEvent(s, e, 0));
+          waited = true;
+        }
+        t.merkle.run_launch(plan[next_launch++], s);
+      }
+    };
+    small_commit(d_sjobs, (uint32_t)sjobs.size(), small_max, cfg.log_blowup_factor, *tw, ts);
+    for (size_t gi = 0; gi < grps.size(); gi++) {
+      const Grp& g = grps[gi];
       if (small_commit_serves(g.log, cfg.log_blowup_factor)) continue;
       const uint32_t* const* dsrc = d_table + g.off;
       uint32_t* const* dco = (uint32_t* const*)(d_table + g.off + g.n);
@@ -190,11 +229,36 @@ struct Prover {
       }
       for (uint32_t c0 = 0; c0 < g.n; c0 += per) {
         const uint32_t nc = std::min(per, g.n - c0);
-        if (!from_coeffs) interpolate_oop(dsrc + c0, dco + c0, nc, g.log, *tw, s);
-        evaluate((const uint32_t* const*)dco + c0, dld + c0, nc, g.log, g.log + cfg.log_blowup_factor, *tw, s);
+        if (!from_coeffs) interpolate_oop(dsrc + c0, dco + c0, nc, g.log, *tw, ts);
+        else if (evals_in_place) interpolate(dco + c0, nc, g.log, *tw, ts);
+        evaluate((const uint32_t* const*)dco + c0, dld + c0, nc, g.log, g.log + cfg.log_blowup_factor, *tw, ts);
       }
+      // what can be hashed now: every layer above the next (smaller) group that is still to be transformed
+      int next_log = -1;
+      for (size_t gj = gi + 1; gj < grps.size(); gj++)
+        if (!small_commit_serves(grps[gj].log, cfg.log_blowup_factor)) { next_log = (int)(grps[gj].log + cfg.log_blowup_factor); break; }
+      hash_ready(next_log + 1);
     }
-    if (with_merkle) t.merkle.commit_prepared(s);
+    if (with_merkle) {
+      if (s_tr) hash_ready(0);   // (a tree of small columns only: nothing was hashed inside the loop)
+      else t.merkle.commit_prepared(s);
+    }
+  }
+  // the stream the transforms of a pipelined commitment run on (a side stream of the calling thread; A/B: CM_PIPE_STREAM = index)
+  static hipStream_t pipe_stream() {
+    static const int idx = getenv("CM_PIPE_STREAM") ? atoi(getenv("CM_PIPE_STREAM")) : 0;
+    return thread_side_stream(idx);
+  }
+  // events of the commitment pipeline: a ring per host thread (a wait captures the record that precedes it, so a slot may be
+  // re-recorded while an earlier wait on it is still pending)
+  static hipEvent_t pipe_event() {
+    static thread_local std::vector<hipEvent_t> ring;
+    static thread_local size_t pos = 0;
+    if (ring.empty()) {
+      ring.resize(64);
+      for (auto& e : ring) CM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    return ring[pos++ % ring.size()];
   }
   // Host pacing.  With the transcript steps behind a tree on the device the host COULD enqueue the whole next phase while the
   // tree is still being built — but the next phase forks over side streams, and fork waits that sit blocked at the head of
