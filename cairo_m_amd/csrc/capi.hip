@@ -252,6 +252,17 @@ int32_t cm_evaluate(const cm_handle* coeffs, uint32_t n_cols, uint32_t log_n, ui
     CM_HIP(hipStreamSynchronize(S(s)));
   });
 }
+int32_t cm_interpolate_extend(const cm_handle* evals, const cm_handle* coeffs, const cm_handle* lde, uint32_t n_cols, uint32_t log_n,
+                              cm_handle tw, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(tw, "cm_interpolate_extend: null twiddles");
+    DevBuf de = upload(ptrs(evals, n_cols), S(s));
+    DevBuf dc = upload(ptrs(coeffs, n_cols), S(s));
+    DevBuf dl = upload(ptrs(lde, n_cols), S(s));
+    interpolate_extend(de.as<const uint32_t*>(), dc.as<uint32_t*>(), dl.as<uint32_t*>(), n_cols, log_n, *(Twiddles*)(uintptr_t)tw, S(s));
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
 int32_t cm_eval_at_point(const cm_handle* coeffs, uint32_t n_cols, uint32_t log_n, const uint32_t pt_xy[8],
                          uint32_t* out, cm_stream_t s) {
   return guard([&] {

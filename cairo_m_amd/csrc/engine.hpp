@@ -30,6 +30,9 @@ void interpolate_oop(const uint32_t* const* d_src, uint32_t* const* d_dst, uint3
 // coefficients (2^n_in each) -> evaluations on the canonic domain of log n_out (n_out >= n_in)
 void evaluate(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t ncols, uint32_t n_in, uint32_t n_out,
               const Twiddles& tw, hipStream_t st);
+// interpolate + evaluate on the domain of twice the size (extend_evals at log_blowup_factor 1); d_src may equal d_coeffs
+void interpolate_extend(const uint32_t* const* d_src, uint32_t* const* d_coeffs, uint32_t* const* d_lde, uint32_t ncols, uint32_t n,
+                        const Twiddles& tw, hipStream_t st);
 void bit_reverse_columns(uint32_t* const* d_cols, uint32_t ncols, uint32_t n, hipStream_t st);
 // interpolate + extend of small columns of ANY mix of sizes in one launch (one block per column): src (2^log_n evaluations;
 // null = the coefficients are already in `coeffs`; may alias `coeffs`) -> coeffs (2^log_n) -> lde (2^(log_n + blowup));

@@ -49,27 +49,28 @@ struct PassGeom {
   }
 };
 
-template <bool INVERSE, int W, int TL, int E>
-__global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
+// The pass itself, for tile `bx` of the pass `a` describes on columns src -> dst.  PRELOADED: v[] already holds the thread's 2^E
+// elements of the first round (the fused kernel below hands the coefficients over in registers); on return v[] holds what the
+// last round stored (non-staged stores only).
+template <bool INVERSE, int W, int TL, int E, bool PRELOADED>
+__device__ __forceinline__ void fft_pass_rb_body(const FftPassArgs& a, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                 const uint32_t bx, M31 (&v)[1 << E], uint32_t* tile) {
   using G = PassGeom<W, TL, E>;
   constexpr uint32_t M = G::M;
   constexpr uint32_t NE = 1u << E;            // elements per thread
   constexpr uint32_t NT = 1u << (TL - E);     // threads per block
-  extern __shared__ __attribute__((aligned(16))) uint32_t tile[];   // 2^TL + 2^(TL-5) words
-  const uint32_t* __restrict__ src = a.src[blockIdx.y];
-  uint32_t* __restrict__ dst = a.dst[blockIdx.y];
+  static_assert(!PRELOADED || M > 0, "only strided passes take their input in registers");
   // raw buffer resources over the two columns (stride 0, no bounds: offsets stay below 2^(n+2) <= 2^30 bytes)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0xffffffffu, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, 0xffffffffu, 0x00020000);
   const uint32_t low_fixed_bits = a.lo - M;
-  const uint32_t lowf = blockIdx.x & ((1u << low_fixed_bits) - 1);
-  const uint32_t high = blockIdx.x >> low_fixed_bits;
+  const uint32_t lowf = bx & ((1u << low_fixed_bits) - 1);
+  const uint32_t high = bx >> low_fixed_bits;
   const uint32_t base = (high << a.hi) | (lowf << M);
   const uint32_t t = threadIdx.x;
   const uint32_t lo = (M == 0) ? 0u : a.lo;   // the contiguous pass starts at layer 0: fold the shifts away
   const bool padded = a.in_len < (1u << a.n);   // only the first pass of an LDE reads implicit zeros
   auto gidx = [&](uint32_t li) -> uint32_t { return base | ((li >> M) << lo) | (li & ((1u << M) - 1)); };
-  M31 v[NE];
 #pragma clang loop unroll(full)
   for (uint32_t rr = 0; rr < G::NR; rr++) {
     const uint32_t r = INVERSE ? rr : (G::NR - 1 - rr);
@@ -100,7 +101,9 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
     auto gel = [&](uint32_t e) -> uint32_t { return gi0 + cgl(e); };
     const uint32_t gb0 = gi0 << 2;   // byte offset of the lane inside the column
     const bool staged_in = (rr == 0) && INVERSE && M == 0;
-    if (rr == 0 && !staged_in) {
+    if (rr == 0 && PRELOADED) {
+      // (the caller's registers)
+    } else if (rr == 0 && !staged_in) {
       if (padded && !INVERSE && a.hi == a.n && a.in_len == (1u << (a.n - 1))) {
         // extension by two (every LDE of the prover): the upper half of the input is implicit zero padding and the top layer,
         // applied first, turns every (x, 0) into (x, x) without a twiddle (below) — so only the elements of the LOWER half are
@@ -190,6 +193,7 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
       for (uint32_t e = 0; e < NE; e++) {
         M31 o = v[e];
         if (INVERSE && a.scale != 1u) o = sc * o;   // the doubled operand of M31 operator* is the loop-invariant one
+        v[e] = o;
         __builtin_amdgcn_raw_buffer_store_b32((int)o.v, rdst, (int)gb0, (int)(cgl(e) << 2), 0);
       }
     } else {
@@ -209,6 +213,58 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
         }
       }
     }
+  }
+}
+
+template <bool INVERSE, int W, int TL, int E>
+__global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile[];   // 2^TL + 2^(TL-5) words
+  M31 v[1 << E];
+  fft_pass_rb_body<INVERSE, W, TL, E, false>(a, a.src[blockIdx.y], a.dst[blockIdx.y], blockIdx.x, v, tile);
+}
+
+// ---- the last pass of an interpolation and the first pass of the extension by two that follows it, in ONE sweep ------------
+// tree_builder.extend_evals = interpolate + evaluate on the double domain (prover.rs:71-73, 80-82, 100-102).  The inverse
+// transform of 2^n ends with the strided layers [12, n); the forward transform of 2^(n+1) begins with its top layer — (x, 0) ->
+// (x, x) on the zero-padded coefficients, no arithmetic — and the layers [12, n) of BOTH halves: the same tile of coefficients,
+// in the same register layout the inverse pass ends with.  So a block finishes the inverse pass, stores the coefficients (the
+// OODS sampling reads them), keeps them in registers and runs the forward layers of the lower and of the upper half on them.
+// HBM: N words read, N + 2N written, against N + N and N + 2N of the two separate passes: one read of the coefficients less,
+// a fifth of what the pair moved (these strided passes run at the HBM stream rate: removing 8 % of their VALU instructions
+// changed nothing, profiles/r04*).  `inv` is the pass [12, n) of the inverse transform (in place on the coefficient columns),
+// `fwd` the pass [12, n) of the 2^(n+1) forward transform with dst = the extended columns (src unused).
+struct FftFusedArgs { FftPassArgs inv, fwd; };
+template <int W>
+__global__ void __launch_bounds__(1024) k_fft_fused_rb(FftFusedArgs a) {
+  constexpr int TL = 14, E = 4;
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
+  M31 v[1 << E], cf[1 << E];
+  fft_pass_rb_body<true, W, TL, E, false>(a.inv, a.inv.src[blockIdx.y], a.inv.dst[blockIdx.y], blockIdx.x, v, tile);
+#pragma clang loop unroll(full)
+  for (uint32_t e = 0; e < (1u << E); e++) cf[e] = v[e];
+  const uint32_t half_shift = a.fwd.lo - PassGeom<W, TL, E>::M;   // tiles per half = 2^(lo - M)
+  uint32_t* __restrict__ lde = a.fwd.dst[blockIdx.y];
+  fft_pass_rb_body<false, W, TL, E, true>(a.fwd, nullptr, lde, blockIdx.x, v, tile);
+#pragma clang loop unroll(full)
+  for (uint32_t e = 0; e < (1u << E); e++) v[e] = cf[e];
+  fft_pass_rb_body<false, W, TL, E, true>(a.fwd, nullptr, lde, (1u << half_shift) | blockIdx.x, v, tile);
+}
+template <int W>
+static void launch_fused_one(const FftFusedArgs& a, uint32_t ntiles, uint32_t ncols, hipStream_t st) {
+  constexpr size_t lds = ((size_t)4 << 14) + ((size_t)4 << 9);
+  static const hipError_t once = hipFuncSetAttribute((const void*)k_fft_fused_rb<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)once;
+  hipLaunchKernelGGL((k_fft_fused_rb<W>), dim3(ntiles, ncols), dim3(1024), lds, st, a);
+}
+bool fft_fused_serves(uint32_t W) { return W >= 6 && W <= 9; }
+void launch_fft_fused_rb(const FftPassArgs& inv, const FftPassArgs& fwd, uint32_t ntiles, uint32_t ncols, hipStream_t st) {
+  FftFusedArgs a{inv, fwd};
+  switch (inv.hi - inv.lo) {
+    case 6: launch_fused_one<6>(a, ntiles, ncols, st); break;
+    case 7: launch_fused_one<7>(a, ntiles, ncols, st); break;
+    case 8: launch_fused_one<8>(a, ntiles, ncols, st); break;
+    case 9: launch_fused_one<9>(a, ntiles, ncols, st); break;
+    default: break;
   }
 }
 

@@ -528,6 +528,43 @@ void evaluate(const uint32_t* const* d_src, uint32_t* const* d_dst, uint32_t nco
   }
   CM_HIP(hipGetLastError());
 }
+// interpolate (2^n evaluations -> coefficients) + evaluate on the domain of 2^(n+1): tree_builder.extend_evals with
+// log_blowup_factor = 1.  For 2^18 .. 2^21 rows the last pass of the inverse transform and the first pass of the forward one are
+// ONE sweep (k_fft_fused_rb, kernels_fft.hip): [0,12) inverse | [12,n) inverse + top layer + [12,n) forward of both halves |
+// [0,12) forward.  d_src may equal d_coeffs (in place).  CM_FFT_FUSED=0: the two transforms one after the other (A/B).
+bool fft_fused_serves(uint32_t W);
+void launch_fft_fused_rb(const FftPassArgs& inv, const FftPassArgs& fwd, uint32_t ntiles, uint32_t ncols, hipStream_t st);
+void interpolate_extend(const uint32_t* const* d_src, uint32_t* const* d_coeffs, uint32_t* const* d_lde, uint32_t ncols, uint32_t n,
+                        const Twiddles& tw, hipStream_t st) {
+  static const bool fused_on = !(getenv("CM_FFT_FUSED") && atoi(getenv("CM_FFT_FUSED")) == 0);
+  CM_CHECK(n >= 1 && n + 1 <= tw.R, "interpolate_extend: log size exceeds twiddle table");
+  if (ncols == 0) return;
+  const uint32_t W = n > FFT_CONTIG_LOG ? n - FFT_CONTIG_LOG : 0;
+  std::vector<std::pair<uint32_t, uint32_t>> passes;
+  plan_passes(n, passes);
+  const bool fused = fused_on && fft_fused_serves(W) && passes.size() == 2 && passes[0].second == FFT_CONTIG_LOG &&
+                     fft_pass_rb_tile_log(W, FFT_CONTIG_LOG) == 14;
+  if (!fused) {
+    interpolate_oop(d_src, d_coeffs, ncols, n, tw, st);
+    evaluate((const uint32_t* const*)d_coeffs, d_lde, ncols, n, n + 1, tw, st);
+    return;
+  }
+  launch_pass<true>(d_src, d_coeffs, ncols, n, 0, FFT_CONTIG_LOG, 1u << n, 1u, tw, st);
+  {
+    FftPassArgs inv_a, fwd_a;
+    inv_a.src = (const uint32_t* const*)d_coeffs; inv_a.dst = d_coeffs;
+    inv_a.xtw = tw.ixtw; inv_a.ytw = tw.iytw; inv_a.R = tw.R; inv_a.n = n; inv_a.lo = FFT_CONTIG_LOG; inv_a.hi = n;
+    inv_a.M = 14 - W; inv_a.in_len = 1u << n; inv_a.scale = inv(M31::from_u32(1u << n)).v;
+    fwd_a.src = (const uint32_t* const*)d_coeffs; fwd_a.dst = d_lde;   // (src is not read: the coefficients arrive in registers)
+    fwd_a.xtw = tw.xtw; fwd_a.ytw = tw.ytw; fwd_a.R = tw.R; fwd_a.n = n + 1; fwd_a.lo = FFT_CONTIG_LOG; fwd_a.hi = n;
+    fwd_a.M = 14 - W; fwd_a.in_len = 2u << n; fwd_a.scale = 1u;
+    const double N = (double)(1u << n);
+    KProfScope kp("k_fft_fused", 4.0 * ncols * 4.0 * N, st, /* butterflies */ (double)ncols * 1.5 * N * (double)W);
+    launch_fft_fused_rb(inv_a, fwd_a, 1u << (n - 14), ncols, st);
+  }
+  launch_pass<false>((const uint32_t* const*)d_lde, d_lde, ncols, n + 1, 0, FFT_CONTIG_LOG, 2u << n, 1u, tw, st);
+  CM_HIP(hipGetLastError());
+}
 void small_commit(const SmallCommitJob* d_jobs, uint32_t n_jobs, uint32_t max_log, uint32_t blowup, const Twiddles& tw, hipStream_t st) {
   if (!n_jobs) return;
   CM_CHECK(max_log >= 1 && max_log <= SMALL_COMMIT_MAX_LOG && max_log + blowup <= tw.R && max_log + blowup <= 14, "small_commit: bad sizes");

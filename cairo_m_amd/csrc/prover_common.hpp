@@ -229,6 +229,11 @@ struct Prover {
       }
       for (uint32_t c0 = 0; c0 < g.n; c0 += per) {
         const uint32_t nc = std::min(per, g.n - c0);
+        if (cfg.log_blowup_factor == 1 && (!from_coeffs || evals_in_place)) {
+          // interpolate + extend by two: the inverse transform's last pass and the forward one's first are one sweep (engine.hpp)
+          interpolate_extend(from_coeffs ? (const uint32_t* const*)dco + c0 : dsrc + c0, dco + c0, dld + c0, nc, g.log, *tw, ts);
+          continue;
+        }
         if (!from_coeffs) interpolate_oop(dsrc + c0, dco + c0, nc, g.log, *tw, ts);
         else if (evals_in_place) interpolate(dco + c0, nc, g.log, *tw, ts);
         evaluate((const uint32_t* const*)dco + c0, dld + c0, nc, g.log, g.log + cfg.log_blowup_factor, *tw, ts);

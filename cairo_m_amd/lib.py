@@ -96,6 +96,11 @@ class Backend:
         self._ck(self.L.cm_evaluate(self._harr(coeffs), C.c_uint32(len(coeffs)), C.c_uint32(log_n),
                                     C.c_uint32(log_out), C.c_uint64(tw), self._harr(out), C.c_uint64(0)))
 
+    def interpolate_extend(self, evals, coeffs, lde, log_n, tw):
+        """extend_evals at blowup 1: evals -> coeffs (2^log_n) and lde (2^(log_n + 1)); evals may be the coeffs handles"""
+        self._ck(self.L.cm_interpolate_extend(self._harr(evals), self._harr(coeffs), self._harr(lde), C.c_uint32(len(evals)),
+                                              C.c_uint32(log_n), C.c_uint64(tw), C.c_uint64(0)))
+
     def bit_reverse(self, cols, log_n):
         self._ck(self.L.cm_bit_reverse(self._harr(cols), C.c_uint32(len(cols)), C.c_uint32(log_n), C.c_uint64(0)))
 

@@ -100,6 +100,12 @@ int32_t cm_interpolate(const cm_handle* cols, uint32_t n_cols, uint32_t log_n, c
  * coefficients of 2^log_n -> bit-reversed evaluations on CanonicCoset(log_out).circle_domain(). */
 int32_t cm_evaluate(const cm_handle* coeffs, uint32_t n_cols, uint32_t log_n, uint32_t log_out, cm_handle tw,
                     const cm_handle* out, cm_stream_t s);
+/* tree_builder.extend_evals at log_blowup_factor 1 (prover.rs:71-73, 80-82, 100-102): interpolate_columns followed by
+ * evaluate on CanonicCoset(log_n + 1) in one call — evals (2^log_n each, bit-reversed) -> coeffs (2^log_n) and lde (2^(log_n+1)).
+ * Results equal cm_interpolate + cm_evaluate word for word; for 2^18..2^21 rows the last inverse pass and the first forward
+ * pass are one sweep over HBM.  evals[i] may equal coeffs[i] (in place). */
+int32_t cm_interpolate_extend(const cm_handle* evals, const cm_handle* coeffs, const cm_handle* lde, uint32_t n_cols, uint32_t log_n,
+                              cm_handle tw, cm_stream_t s);
 /* PolyOps::eval_at_point for n_cols polynomials at one QM31 circle point (x[4], y[4]);
  * out = n_cols * 4 u32 (host). */
 int32_t cm_eval_at_point(const cm_handle* coeffs, uint32_t n_cols, uint32_t log_n, const uint32_t pt_xy[8],

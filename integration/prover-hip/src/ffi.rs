@@ -187,6 +187,7 @@ unsafe extern "C" {
     pub fn cm_twiddles_free(tw: cm_handle) -> i32;
     pub fn cm_interpolate(cols: *const cm_handle, n_cols: u32, log_n: u32, tw: cm_handle, s: cm_stream_t) -> i32;
     pub fn cm_evaluate(coeffs: *const cm_handle, n_cols: u32, log_n: u32, log_out: u32, tw: cm_handle, out: *const cm_handle, s: cm_stream_t) -> i32;
+    pub fn cm_interpolate_extend(evals: *const cm_handle, coeffs: *const cm_handle, lde: *const cm_handle, n_cols: u32, log_n: u32, tw: cm_handle, s: cm_stream_t) -> i32;
     pub fn cm_eval_at_point(coeffs: *const cm_handle, n_cols: u32, log_n: u32, pt_xy: *const u32, out: *mut u32, s: cm_stream_t) -> i32;
     pub fn cm_merkle_commit_layer(log_size: u32, prev_layer: cm_handle, cols: *const cm_handle, n_cols: u32, out_hashes: cm_handle, s: cm_stream_t) -> i32;
     pub fn cm_merkle_commit(cols: *const cm_handle, col_logs: *const u32, n_cols: u32, root: *mut u8, s: cm_stream_t) -> i32;

@@ -55,6 +55,31 @@ def test_interpolate_evaluate_parity_full_size(backend, oracle, log_n):
     backend.twiddles_free(tw)
 
 
+@pytest.mark.parametrize("log_n", [4, 12, 17, 18, 19, 20, 21, 22])
+@pytest.mark.parametrize("in_place", [False, True])
+def test_interpolate_extend_parity(backend, oracle, log_n, in_place):
+    """extend_evals in one call (cm_interpolate_extend): 2^18..2^21 go through the fused sweep (last inverse pass + top layer +
+    first forward pass of both halves, k_fft_fused_rb), the other sizes through the two separate transforms; coefficients and
+    the extension equal the oracle's interpolate / evaluate word for word, out of place and in place."""
+    rng = np.random.default_rng(4000 + log_n)
+    ncols = 3 if log_n <= 20 else 1
+    tw = backend.twiddles(log_n + 1)
+    cols = rand_cols(rng, ncols, log_n)
+    ev = [backend.upload(c) for c in cols]
+    co = ev if in_place else [backend.col_alloc(1 << log_n) for _ in cols]
+    ld = [backend.col_alloc(2 << log_n) for _ in cols]
+    backend.interpolate_extend(ev, co, ld, log_n, tw)
+    for e, c_h, l_h, c in zip(ev, co, ld, cols):
+        want_c = oracle.interpolate(c)
+        assert np.array_equal(backend.download(c_h, 1 << log_n), want_c)
+        assert np.array_equal(backend.download(l_h, 2 << log_n), oracle.evaluate(want_c, log_n + 1))
+        if not in_place:
+            assert np.array_equal(backend.download(e, 1 << log_n), c)   # the evaluations are left alone
+    for h in set(ev + co + ld):
+        backend.col_free(h)
+    backend.twiddles_free(tw)
+
+
 def test_lde_roundtrip_large(backend):
     """Full-size property check (no oracle): 2^22 -> LDE 2^23 -> every even-half restriction
     interpolates back; here: interpolate(evaluate(c, n), n) == c and linearity."""
