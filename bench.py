@@ -48,16 +48,52 @@ def pmc_traffic(kernel_class):
     """HBM bytes per launch of one kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE need separate passes, so bench.py cannot collect them live; tools/pmc_traffic.py makes the
     file from `rocprofv3 --pmc` runs of this same command).  None when no file covers the class."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
+    f = latest_profile("pmc_traffic.json")
+    if not f:
         return None, None
     try:
-        d = json.load(open(files[-1]))
+        d = json.load(open(f))
         c = d["classes"].get(kernel_class)
-        return (c["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if c else (None, None)
+        return (c["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)) if c else (None, None)
     except (OSError, ValueError, KeyError):
         return None, None
+
+
+def latest_profile(suffix):
+    """profiles/<tag>_<suffix> of the measurement set of HEAD: the tag is the first word of profiles/LATEST (written when a set is
+    committed; file names do not sort by age — r03zz sorts behind r03h).  None when that set has no such file."""
+    try:
+        tag = open(os.path.join(ROOT, "profiles", "LATEST")).read().split()[0]
+    except (OSError, IndexError):
+        return None
+    f = os.path.join(ROOT, "profiles", f"{tag}_{suffix}")
+    return f if os.path.exists(f) else None
+
+
+# SURVEY §8d: algorithmic bytes per committed trace cell of every stage (each stage streams its input once and writes its output
+# once) and the kprof classes whose HIP-event intervals make up the stage.  The class sets are wider than the model's stages:
+# the transforms include the constraint accumulators' and the composition polynomial's, the Merkle classes every FRI tree and
+# the composition tree (the model prices those at ~0), so the fractions are lower bounds of what the model's stage reaches.
+STAGE_MODEL = [
+    ("trace / interaction generation", 4.0, ("k_trace_gen(region)", "k_logup(region)")),
+    ("IFFT + LDE", 8.0 + 12.0, ("k_fft_pass<ifft>", "k_fft_pass<fft>", "k_fft_fused", "k_small_commit")),
+    ("Merkle hashing", 8.0, ("k_merkle_layer", "k_merkle_layer_quad", "k_merkle_multi", "k_merkle_top", "k_merkle_tail")),
+    ("constraint quotients", 8.0, ("k_constraints(region)",)),
+    ("OODS eval_at_point", 4.0, ("k_eval_at_point",)),
+    ("DEEP quotients", 8.0, ("k_quotients",)),
+]
+
+
+def stage_roofline(kprof_all, n_prof, cells):
+    out = []
+    for name, bpc, classes in STAGE_MODEL:
+        ms = sum(kprof_all[c]["ms"] for c in classes if c in kprof_all) / n_prof
+        if ms <= 0:
+            continue
+        gbs = bpc * cells / (ms * 1e-3) / 1e9
+        out.append({"stage": name, "bytes_per_cell": bpc, "ms_per_step": ms, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS,
+                    "classes": [c for c in classes if c in kprof_all]})
+    return out
 
 
 def _oracle_child(fib_n, threads, reps, words_out=None, timeout=900):
@@ -448,6 +484,11 @@ def main():
                         "whole_path_model": {"bytes_per_cell": MODEL_BYTES_PER_CELL,
                                              "achieved_GBs": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9,
                                              "frac": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "stages": stage_roofline(kprof_all, n_prof, cells),
+                        "stages_note": "SURVEY §8d per-stage check: bytes per cell x committed cells / summed HIP-event intervals of the "
+                                       "stage's kernel classes in the instrumented pass.  With the commitment pipeline the transform and "
+                                       "Merkle intervals of a tree overlap in time (each includes the time it shared the GPU with the "
+                                       "other), so their sum exceeds the commit phases' wall time",
                         "kernels_note": "per-class HIP-event totals from the instrumented (untimed) pass after the warmup; '(region)' = "
                                         "one interval around a fork/join of per-component launches on side streams",
                         "kernels": {n: {"ms_per_step": v["ms"] / n_prof, "launches_per_step": v["calls"] / n_prof,
@@ -476,7 +517,9 @@ def main():
                "gpu_idle_ms": (ms_per_step - busy_ms) if busy_ms is not None else None,
                "gpu_idle_note": "ms_per_step minus the summed HIP-event intervals of every instrumented kernel class / fork-join region "
                                 "of the instrumented pass: host round trips, cross-stream hand-overs, copies and the few un-instrumented "
-                                "small kernels",
+                                "small kernels.  Since round 4 the transforms and the Merkle launches of a tree overlap on two streams, "
+                                "so the sum counts shared time twice and this figure UNDERSTATES the idle time (it can be negative); "
+                                "profiles/*_gaps.txt (traced timeline) is the reliable view",
                "alt_reading": alt,
                "phase_ms": phases, "roofline": roofline, "pipelined": pipelined, "sharded": sharded, "end_to_end": end_to_end,
                "proof_verified": verified}
@@ -485,6 +528,12 @@ def main():
             parity, out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, args.cpu_single_n, args.cpu_threads, hip_words if same else None)
             # bit-exactness AT the metric config: the oracle proves the very ProverInput the GPU was timed on
             out["parity_at_metric_config"] = parity
+            sc = latest_profile("cpu_scaling.json") or os.path.join(ROOT, "profiles", "r04_cpu_scaling.json")
+            if os.path.exists(sc):
+                try:
+                    out["cpu_baseline"]["thread_scaling"] = dict(json.load(open(sc)), source=os.path.relpath(sc, ROOT))
+                except (OSError, ValueError):
+                    pass
             if parity is False:
                 print(json.dumps(out))
                 sys.exit("bench.py: the HIP proof differs from the CPU oracle's proof of the same input")

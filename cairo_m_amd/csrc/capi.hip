@@ -19,6 +19,7 @@ namespace {
 std::mutex g_framing_mu;
 Framing g_framing;
 std::atomic<bool> g_framing_init{false};
+int g_framing_users = 0;   // provers / verifiers alive (guarded by g_framing_mu)
 }  // namespace
 const Framing& framing() {
   if (!g_framing_init) {
@@ -27,7 +28,8 @@ const Framing& framing() {
       Framing f;
       if (const char* e = getenv("CM_FRAMING")) {
         const std::string err = Framing::parse(e, f);
-        if (!err.empty()) { fprintf(stderr, "libcairom_hip: CM_FRAMING ignored: %s\n", err.c_str()); f = Framing(); }
+        // a proof made under a framing the caller did not ask for is a wrong proof: refuse to run (every entry point reports it)
+        if (!err.empty()) throw CmError(1, "CM_FRAMING: " + err);
       }
       g_framing = f;
       g_framing_init = true;
@@ -39,10 +41,21 @@ std::string set_framing(const char* spec) {
   Framing f;
   const std::string err = Framing::parse(spec, f);
   if (!err.empty()) return err;
-  (void)framing();   // settle the env initialisation first
+  try { (void)framing(); } catch (const CmError&) { /* a malformed CM_FRAMING is replaced by this explicit setting */ }
   std::lock_guard<std::mutex> lk(g_framing_mu);
+  if (g_framing_users > 0) return "framing: a proof or a verification is in flight; the setting can only change between them";
   g_framing = f;
+  g_framing_init = true;
   return "";
+}
+FramingUse::FramingUse() {
+  (void)framing();
+  std::lock_guard<std::mutex> lk(g_framing_mu);
+  g_framing_users++;
+}
+FramingUse::~FramingUse() {
+  std::lock_guard<std::mutex> lk(g_framing_mu);
+  g_framing_users--;
 }
 }  // namespace cm
 
@@ -161,7 +174,9 @@ int32_t cm_set_framing(const char* spec) {
   });
 }
 int32_t cm_get_framing(char* buf, size_t buf_len) {
-  const std::string d = framing().describe();
+  std::string d;
+  try { d = framing().describe(); }
+  catch (const std::exception& e) { g_last_error = e.what(); return -1; }   // a malformed CM_FRAMING: nothing is in force
   if (!buf || !buf_len) return (int32_t)d.size();
   const size_t n = d.size() < buf_len - 1 ? d.size() : buf_len - 1;
   memcpy(buf, d.data(), n);

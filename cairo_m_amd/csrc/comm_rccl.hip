@@ -119,13 +119,26 @@ int32_t rccl_all_to_all_v(void* ctx, const uint64_t* send_words, const uint64_t*
     if (send_words[me])
       CM_HIP(hipMemcpyAsync(c->view.recv_buf + my_r, c->view.send_buf + my_s, send_words[me] * 4, hipMemcpyDeviceToDevice, c->stream));
     cm::nccl_ck(r.GroupStart(), "ncclGroupStart");
-    for (uint32_t k = 0; k < n; k++) {
-      if (k != me && send_words[k]) cm::nccl_ck(r.Send(c->view.send_buf + so, (size_t)send_words[k], cm::kNcclUint32, (int)k, c->comm, c->stream), "ncclSend");
-      if (k != me && recv_words[k]) cm::nccl_ck(r.Recv(c->view.recv_buf + ro, (size_t)recv_words[k], cm::kNcclUint32, (int)k, c->comm, c->stream), "ncclRecv");
+    // The group is closed on EVERY path: a Send / Recv that fails in the middle must not leave this thread inside an open NCCL
+    // group (every later call on it — the ncclCommAbort of cm_comm::abort included — would be deferred).  The first error is
+    // remembered and reported once the group is closed.
+    cm::ncclResult_t first_err = (cm::ncclResult_t)0;
+    const char* first_what = nullptr;
+    for (uint32_t k = 0; k < n && !first_err; k++) {
+      if (k != me && send_words[k]) {
+        const cm::ncclResult_t e = r.Send(c->view.send_buf + so, (size_t)send_words[k], cm::kNcclUint32, (int)k, c->comm, c->stream);
+        if (e) { first_err = e; first_what = "ncclSend"; break; }
+      }
+      if (k != me && recv_words[k]) {
+        const cm::ncclResult_t e = r.Recv(c->view.recv_buf + ro, (size_t)recv_words[k], cm::kNcclUint32, (int)k, c->comm, c->stream);
+        if (e) { first_err = e; first_what = "ncclRecv"; break; }
+      }
       so += send_words[k];
       ro += recv_words[k];
     }
-    cm::nccl_ck(r.GroupEnd(), "ncclGroupEnd");
+    const cm::ncclResult_t end_err = r.GroupEnd();
+    if (first_err) cm::nccl_ck(first_err, first_what);
+    cm::nccl_ck(end_err, "ncclGroupEnd");
   });
 }
 // cm_comm::abort: this rank failed in the middle of a sharded proof — tear the communicator down so that the peers' pending and
@@ -155,6 +168,7 @@ int32_t cm_rccl_comm_create(const uint8_t id[128], uint32_t rank, uint32_t world
     c->send.alloc(staging_words * 4);
     c->recv.alloc(staging_words * 4);
     c->stream = cm::thread_main_stream();
+    c->view.struct_size = (uint32_t)sizeof(cm_comm);
     c->view.rank = rank; c->view.world = world; c->view.ctx = c.get();
     c->view.send_buf = c->send.u32(); c->view.recv_buf = c->recv.u32(); c->view.buf_words = staging_words;
     c->view.all_to_all_v = rccl_all_to_all_v;

@@ -72,7 +72,15 @@ struct Framing {
 };
 
 // process-wide setting (framing.cpp part of capi.hip); reads CM_FRAMING on first use
-const Framing& framing();
-std::string set_framing(const char* spec);   // "" on success
+const Framing& framing();                    // a malformed CM_FRAMING is a hard error (CmError) on first use, not a silent default
+std::string set_framing(const char* spec);   // "" on success; refused while a proof or a verification is running
+// Held by every prover / verifier for its lifetime: the kernels, the transcript and the quotient planning of ONE proof read the
+// process-wide setting at their own points, so it must not change underneath them (cm_set_framing then returns an error).
+struct FramingUse {
+  FramingUse();
+  ~FramingUse();
+  FramingUse(const FramingUse&) = delete;
+  FramingUse& operator=(const FramingUse&) = delete;
+};
 
 }  // namespace cm

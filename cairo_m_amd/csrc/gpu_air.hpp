@@ -143,6 +143,10 @@ struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
 #ifndef CM_LOGUP_INV_GROUP
 #define CM_LOGUP_INV_GROUP 6
 #endif
+  // INVARIANT (shared inversion): a zero norm in a group makes inv(all) = 0 and zeroes ALL fractions of the group, where the
+  // per-batch form lost one.  A denominator z - sum alpha^i v_i is zero with probability ~2^-124 per entry over the verifier's
+  // (z, alpha) — Stwo's own batch inverse panics on it, the reference would not produce a proof either — and a proof made
+  // from such a row fails the OODS composition check of this prover (check_composition_at_oods), so it cannot leave the library.
   static constexpr int G = CM_LOGUP_INV_GROUP;
   QM31 bn[G], bd[G];
   int cnt = 0;

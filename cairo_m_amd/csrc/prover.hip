@@ -1328,13 +1328,19 @@ int32_t cm_shard_plan(const cm_prover_input* input, uint32_t world, int32_t owne
 }
 int32_t cm_prove_sharded(const cm_device_input* input, const cm_pcs_config* config, const cm_comm* comm, cm_proof** out) {
   return pguard([&] {
-    CM_CHECK(comm && comm->all_gather && comm->all_to_all_v && comm->send_buf && comm->recv_buf, "cm_prove_sharded: incomplete cm_comm");
+    // the caller's struct may be older / shorter than this library's: copy what its struct_size covers, the rest stays zero
+    CM_CHECK(comm && comm->struct_size >= offsetof(cm_comm, flags) && comm->struct_size <= 4096,
+             "cm_prove_sharded: cm_comm.struct_size does not cover the required fields (set it to sizeof(cm_comm))");
+    cm_comm cc;
+    memset(&cc, 0, sizeof(cc));
+    memcpy(&cc, comm, std::min<size_t>(comm->struct_size, sizeof(cm_comm)));
+    CM_CHECK(cc.all_gather && cc.all_to_all_v && cc.send_buf && cc.recv_buf, "cm_prove_sharded: incomplete cm_comm");
     cm_pcs_config cfg = config ? *config : default_cfg();
     std::unique_ptr<cm_proof> p(new cm_proof());
     try {
-      p->d = cm::prove_sharded(*input->d, cfg, *comm);
+      p->d = cm::prove_sharded(*input->d, cfg, cc);
     } catch (...) {
-      if (comm->abort) comm->abort(comm->ctx);   // the peers are heading for a collective this rank will never join
+      if (cc.abort) cc.abort(cc.ctx);   // the peers are heading for a collective this rank will never join
       throw;
     }
     *out = p.release();

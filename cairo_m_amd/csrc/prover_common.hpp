@@ -74,6 +74,7 @@ constexpr uint32_t FFT_CHUNK_MB_DEFAULT = 0;   // Infinity-Cache blocking of the
 inline std::atomic<int> g_transcript_log{0};     // cm_set_transcript_log: proofs record every Fiat-Shamir step (ProofData::transcript)
 inline std::atomic<int> g_proofs_in_flight{0};   // proofs being made by cm_prove_many runners right now (0 outside of it)
 struct Prover {
+  FramingUse framing_use;   // the process-wide framing cannot change while this proof is being made (framing.hpp)
   hipStream_t st = 0;
   cm_pcs_config cfg;
   Twiddles* tw = nullptr;

@@ -286,6 +286,7 @@ bool rebuild_evals(const std::vector<uint32_t>& queries, const std::vector<QM31>
 // `expected` is the verifier's OWN PcsConfig (verify_cairo_m takes it from the caller, defaulting to REGULAR_96_BITS,
 // verifier.rs:17-31): the security level is never read from the proof.  A proof made under another config fails.
 std::string verify_proof(const ProofData& pf, const cm_pcs_config& expected) {
+  FramingUse framing_use;   // (see Prover: one framing for the whole verification)
   const cm_pcs_config& cfg = expected;
   if (pf.config.pow_bits != cfg.pow_bits || pf.config.log_blowup_factor != cfg.log_blowup_factor ||
       pf.config.n_queries != cfg.n_queries || pf.config.log_last_layer_degree_bound != cfg.log_last_layer_degree_bound)

@@ -28,10 +28,14 @@ _ABORT = C.CFUNCTYPE(None, C.c_void_p)
 
 
 class CmComm(C.Structure):
-    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("ctx", C.c_void_p), ("send_buf", C.c_void_p), ("recv_buf", C.c_void_p),
+    _fields_ = [("struct_size", C.c_uint32),                             # sizeof(cm_comm) of THIS binding: the library reads no further
+                ("rank", C.c_uint32), ("world", C.c_uint32), ("ctx", C.c_void_p), ("send_buf", C.c_void_p), ("recv_buf", C.c_void_p),
                 ("buf_words", C.c_uint64), ("all_to_all_v", _A2A), ("all_gather", _AG),
                 ("flags", C.c_uint32), ("set_stream", _SETSTREAM),       # 0 / NULL: the blocking form (this module's TorchComm)
                 ("abort", _ABORT)]                                       # NULL: the process group's own timeout releases the peers
+
+    def __init__(self, *fields, **kw):   # CmComm(rank, world, ctx, ...): struct_size is filled in here
+        super().__init__(C.sizeof(CmComm), *fields, **kw)
 
 
 def shard_plan(host_input, world, lib=None):

@@ -66,7 +66,9 @@ int32_t cm_get_cpu_affinity(void);
  *   pcs_mix       = bql (default: pow_bits, log_blowup, n_queries, log_last_layer)  |  blq   — PcsConfig::mix_into, prover.rs:36
  * A reference-produced transcript (integration/prover-hip/tests/golden_dump.rs -> tests/golden/ref_*.json, compared step by
  * step by tests/test_ref_golden.py) tells which value is right; prover and verifier must run under the same setting.
- * cm_get_framing writes the setting in force ("mix_u64=raw,hash_node=raw,...") and returns its length. */
+ * cm_get_framing writes the setting in force ("mix_u64=raw,hash_node=raw,...") and returns its length (-1: the environment
+ * variable CM_FRAMING is malformed — a hard error for every entry point until cm_set_framing replaces it).
+ * cm_set_framing is refused (status 1) while a proof or a verification is running: one proof = one framing. */
 int32_t cm_set_framing(const char* spec);
 int32_t cm_get_framing(char* buf, size_t buf_len);
 /* Transcript log: on = every proof records one entry per Fiat-Shamir call the reference prover makes (Stwo Channel::{mix_u32s,
@@ -275,6 +277,9 @@ int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words, const cm_
  * contiguous: all_to_all_v sends send_words[d] words to rank d from send_buf (blocks in rank order) and receives
  * recv_words[s] words from rank s into recv_buf; all_gather sends send_buf[0, words_per_rank) and receives world blocks. */
 typedef struct cm_comm {
+  uint32_t struct_size;              /* sizeof(cm_comm) as the CALLER compiled it: the fields behind all_gather are optional and are
+                                      * only read when this size covers them, so a caller built against an earlier header (or a
+                                      * binding that stops at all_gather) keeps working; smaller than that = status 1 */
   uint32_t rank, world;              /* world: a power of two, 1..8 */
   void* ctx;
   uint32_t* send_buf;

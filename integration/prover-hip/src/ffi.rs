@@ -141,6 +141,8 @@ pub struct cm_runner_segment {
 /// Collectives of the sharded prover (cm_prove_sharded): two blocking calls over two device staging buffers
 #[repr(C)]
 pub struct cm_comm {
+    /// `size_of::<cm_comm>()`: the library only reads the optional fields this size covers
+    pub struct_size: u32,
     pub rank: u32,
     pub world: u32,
     pub ctx: *mut c_void,

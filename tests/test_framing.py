@@ -57,3 +57,25 @@ def test_alternate_framing_is_consistent_across_oracle_and_product_verifier(orac
     # transcript: the first four entries are PcsConfig::mix_into — pow_bits, log_blowup, then (alt) last-layer bound, n_queries
     assert [e["op"] for e in tr_alt[:4]] == ["mix_u64"] * 4
     assert [e["words"][0] for e in tr_alt[:4]] == [16, 1, 0, 80]
+
+
+def test_malformed_env_framing_is_a_hard_error():
+    """CM_FRAMING is read once, on first use; a value that does not parse must not silently become the default framing (a proof
+    made under a framing the operator did not ask for is a wrong proof): cm_get_framing reports -1, cm_set_framing repairs it."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "from cairo_m_amd.lib import load_library\n"
+        "L = load_library()\n"
+        "buf = C.create_string_buffer(256)\n"
+        "rc = L.cm_get_framing(buf, C.c_size_t(256))\n"
+        "assert rc == -1, rc\n"
+        "assert L.cm_set_framing(b'hash_node=rfc') == 0\n"
+        "rc = L.cm_get_framing(buf, C.c_size_t(256))\n"
+        "assert rc > 0 and b'hash_node=rfc' in buf.value, (rc, buf.value)\n"
+        "print('ok')\n")
+    import os
+    env = dict(os.environ, CM_FRAMING="mix_u64=sometimes", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -87,3 +87,42 @@ def test_transcript_shape_follows_prove_cairo_m(backend, oracle):
     finally:
         set_transcript_log(False, backend.L)
         inp.free()
+
+
+def test_framing_cannot_change_under_a_running_proof(backend):
+    """One proof = one framing: the trees, the transcript and the quotient planning of a proof read the process-wide setting at
+    their own points, so cm_set_framing is refused (status 1, setting unchanged) while a prover is alive and accepted again
+    afterwards; the proofs made meanwhile verify under the setting they started with."""
+    import ctypes as C
+    import threading
+    inp = synth_fibonacci(100_000)
+    dev = backend.upload_input(inp)
+    proofs = []
+    t = threading.Thread(target=lambda: proofs.extend(backend.prove_many([dev] * 6, inflight=2)))
+    refused = accepted = 0
+    try:
+        backend.prove_device(dev).free()          # warm pools: the timed part below is steady-state proving (~6 ms per proof)
+        t.start()
+        while t.is_alive():
+            rc = backend.L.cm_set_framing(b"hash_node=rfc")
+            if rc != 0:
+                refused += 1
+            else:                                # slipped in between two proofs: put the default back at once
+                accepted += 1
+                while backend.L.cm_set_framing(b"") != 0 and t.is_alive():
+                    pass
+        t.join()
+        assert refused > 0, (refused, accepted)
+        assert backend.L.cm_set_framing(b"") == 0 and "hash_node=raw" in get_framing(backend.L)
+        assert len(proofs) == 6
+        if accepted == 0:                        # no proof can have been made under the alternate framing
+            for p in proofs:
+                assert p.verify()[0] == 0
+    finally:
+        if t.is_alive():
+            t.join()
+        for p in proofs:
+            p.free()
+        set_framing("", backend.L)
+        backend.free_input(dev)
+        inp.free()
