@@ -452,10 +452,33 @@ def main():
             be.free_input(d)
         h_min, h_avg = best(from_host)
         r_min, r_avg = best(from_runner)
+        # streaming ingest (cm_prove_many_host / cm_prove_many_segments): the same host inputs, uploads / device adapter of item
+        # i + 1 under the proofs of the items before it — compare with `pipelined.ms_per_proof` (inputs resident in HBM)
+        streamed = None
+        if args.pipelined > 1:
+            n_str = 4 * args.pipelined
+            def run_streamed(fn, item):
+                for p in fn([item] * args.pipelined, inflight=args.pipelined):
+                    p.free()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                ps = fn([item] * n_str, inflight=args.pipelined)
+                torch.cuda.synchronize()
+                d = (time.perf_counter() - t) * 1e3 / n_str
+                for p in ps:
+                    p.free()
+                return d
+            streamed = {"inflight": args.pipelined, "proofs": n_str,
+                        "pipelined_from_host_ms_per_proof": run_streamed(be.prove_many_host, inp),
+                        "pipelined_from_segments_ms_per_proof": run_streamed(be.prove_many_segments, seg),
+                        "api": "cm_prove_many_host / cm_prove_many_segments"}
         seg.free()
         end_to_end = {"host_prover_input_ms": {"min": h_min, "avg": h_avg, "api": "cm_prove_segment (pageable host ProverInput: upload + prove)"},
                       "runner_segment_ms": {"min": r_min, "avg": r_avg, "api": "cm_adapt_segment_device + cm_prove_device (runner trace + memory log in host memory -> device adapter -> proof)"},
                       "cells_per_s_from_host_input": cells / (h_min * 1e-3),
+                      **(streamed or {}),
+                      **({"streamed_vs_resident": streamed["pipelined_from_host_ms_per_proof"] / pipelined["ms_per_proof"]}
+                         if streamed and pipelined else {}),
                       "note": "PCIe-inclusive; never the headline `value` (inputs resident in HBM)"}
 
     if rank == 0:

@@ -69,13 +69,20 @@ static PublicData make_public_data(const cm_prover_input& in) {  // PublicData::
   return d;
 }
 
-DeviceInput* upload_input(const cm_prover_input& in) {
+// `st` = null: blocking copies on the NULL stream + a device-wide synchronisation (the one-shot form).  Otherwise every copy is
+// enqueued on `st` and only `st` is waited for — the streaming ingest (cm_prove_many_host) uploads segment k + 1 on the calling
+// thread's stream while the workers' proofs of segments <= k keep the GPU busy; a device-wide wait would stall the uploader
+// behind every proof in flight.
+DeviceInput* upload_input(const cm_prover_input& in, hipStream_t st = nullptr) {
   bind_thread_to_library_device();
-  DeviceInput* d = new DeviceInput();
+  std::unique_ptr<DeviceInput> dh(new DeviceInput());
+  DeviceInput* d = dh.get();
   d->meta = in;
-  auto up = [](DevBuf& b, const void* p, size_t bytes) {
+  auto up = [st](DevBuf& b, const void* p, size_t bytes) {
     b.alloc(bytes);
-    if (bytes) CM_HIP(hipMemcpy(b.p, p, bytes, hipMemcpyHostToDevice));
+    if (!bytes) return;
+    if (st) CM_HIP(hipMemcpyAsync(b.p, p, bytes, hipMemcpyHostToDevice, st));
+    else CM_HIP(hipMemcpy(b.p, p, bytes, hipMemcpyHostToDevice));
   };
   for (int i = 0; i < CM_N_OPCODE_COMPONENTS; i++) up(d->bundles[i], in.bundles[i], in.n_bundles[i] * sizeof(cm_bundle));
   up(d->data_accesses, in.data_accesses, in.n_data_accesses * sizeof(cm_data_access));
@@ -85,8 +92,9 @@ DeviceInput* upload_input(const cm_prover_input& in) {
   up(d->init_tree, in.initial_tree, in.n_initial_tree * sizeof(cm_merkle_node));
   up(d->fin_tree, in.final_tree, in.n_final_tree * sizeof(cm_merkle_node));
   d->public_data = make_public_data(in);
-  CM_HIP(hipDeviceSynchronize());   // the copies ran on the NULL stream; the prover's streams are non-blocking
-  return d;
+  if (st) CM_HIP(hipStreamSynchronize(st));
+  else CM_HIP(hipDeviceSynchronize());   // the copies ran on the NULL stream; the prover's streams are non-blocking
+  return dh.release();
 }
 
 // device adapter (adapter_device.hip): bulk arrays already live in HBM, the small boundary-memory / Merkle-tree
@@ -1385,6 +1393,113 @@ int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm
   lk.unlock();
   if (sh.rc) { cm_set_last_error(sh.err.c_str()); return sh.rc; }
   return 0;
+}
+// ---- streaming ingest (prover.rs:23-29 takes a HOST `&mut ProverInput`, the reference's bench clones one per
+// iteration, benches/prover_speed_benchmark.rs:65) ---------------------------------------------------------------------------
+// The calling thread is the PRODUCER: it turns item i into a device-resident input (upload of a host ProverInput, or the device
+// adapter on a runner segment) on its own stream and device pool while up to `inflight` worker threads prove the items before
+// it.  At most inflight + 1 device inputs are alive (the ones being proved and the one being produced); a spent input goes back
+// to the producer, which releases it into ITS pool — the next upload reuses the same blocks, so a steady stream of equal-sized
+// segments performs no hipMalloc / hipFree.  The PCIe copies run on the SDMA engines next to the proofs' kernels.
+extern "C++" {
+template <class Produce>
+static int32_t prove_streamed(uint32_t n, Produce&& produce, const cm_pcs_config* config, uint32_t inflight, cm_proof** outs) {
+  if (!n) return 0;
+  if (inflight < 1) inflight = 1;
+  if (inflight > 8) inflight = 8;
+  const cm_pcs_config cfg = config ? *config : default_cfg();
+  for (uint32_t i = 0; i < n; i++) outs[i] = nullptr;
+  cm::ProveWorkers& w = cm::prove_workers();
+  w.ensure(inflight);
+  struct Shared {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<uint32_t, cm::DeviceInput*>> ready;   // produced, not yet picked up
+    std::deque<cm::DeviceInput*> spent;                        // proved: the producer frees them (its pool)
+    uint32_t alive = 0, workers_done = 0;
+    bool no_more = false;
+    int32_t rc = 0;
+    std::string err;
+  } sh;
+  const uint32_t runners = inflight < n ? inflight : n;
+  for (uint32_t r = 0; r < runners; r++) {
+    w.submit([&sh, &cfg, outs] {
+      struct InFlight { InFlight() { cm::g_proofs_in_flight.fetch_add(1); } ~InFlight() { cm::g_proofs_in_flight.fetch_sub(1); } } in_flight;
+      for (;;) {
+        std::pair<uint32_t, cm::DeviceInput*> job;
+        {
+          std::unique_lock<std::mutex> lk(sh.mu);
+          sh.cv.wait(lk, [&] { return !sh.ready.empty() || sh.no_more; });
+          if (sh.ready.empty()) break;
+          job = sh.ready.front();
+          sh.ready.pop_front();
+        }
+        int32_t rc = 0;
+        std::string err;
+        try {
+          std::unique_ptr<cm_proof> p(new cm_proof());
+          p->d = cm::prove(*job.second, cfg);
+          outs[job.first] = p.release();
+        } catch (const cm::CmError& e) { rc = e.code ? e.code : 1; err = e.what(); }
+        catch (const std::exception& e) { rc = 1; err = e.what(); }
+        std::lock_guard<std::mutex> lk(sh.mu);
+        if (rc && !sh.rc) { sh.rc = rc; sh.err = err; }
+        sh.spent.push_back(job.second);
+        sh.cv.notify_all();
+      }
+      std::lock_guard<std::mutex> lk(sh.mu);
+      sh.workers_done++;
+      sh.cv.notify_all();
+    });
+  }
+  cm::bind_thread_to_library_device();
+  cm::AffinityScope cpu_scope;
+  auto release_spent = [&](std::unique_lock<std::mutex>& lk) {   // called with the lock held; frees outside of it
+    std::deque<cm::DeviceInput*> v;
+    v.swap(sh.spent);
+    sh.alive -= (uint32_t)v.size();
+    lk.unlock();
+    for (auto* d : v) delete d;
+    lk.lock();
+  };
+  int32_t prc = 0;
+  std::string perr;
+  for (uint32_t i = 0; i < n && !prc;) {
+    {
+      std::unique_lock<std::mutex> lk(sh.mu);
+      sh.cv.wait(lk, [&] { return sh.alive < inflight + 1 || !sh.spent.empty(); });
+      while (!sh.spent.empty()) release_spent(lk);
+      if (sh.alive >= inflight + 1) continue;
+    }
+    cm::DeviceInput* d = nullptr;
+    try { d = produce(i); }
+    catch (const cm::CmError& e) { prc = e.code ? e.code : 1; perr = e.what(); }
+    catch (const std::exception& e) { prc = 1; perr = e.what(); }
+    if (!d) break;
+    std::lock_guard<std::mutex> lk(sh.mu);
+    sh.ready.push_back({i, d});
+    sh.alive++;
+    sh.cv.notify_all();
+    i++;
+  }
+  {
+    std::unique_lock<std::mutex> lk(sh.mu);
+    sh.no_more = true;
+    sh.cv.notify_all();
+    sh.cv.wait(lk, [&] { return sh.workers_done == runners; });
+    while (!sh.spent.empty()) release_spent(lk);
+    if (prc && !sh.rc) { sh.rc = prc; sh.err = perr; }
+  }
+  if (sh.rc) { cm_set_last_error(sh.err.c_str()); return sh.rc; }
+  return 0;
+}
+}  // extern "C++"
+int32_t cm_prove_many_host(const cm_prover_input* const* inputs, uint32_t n, const cm_pcs_config* config, uint32_t inflight, cm_proof** outs) {
+  return prove_streamed(n, [&](uint32_t i) { return cm::upload_input(*inputs[i], cm::thread_main_stream()); }, config, inflight, outs);
+}
+int32_t cm_prove_many_segments(const cm_runner_segment* const* segments, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
+                               cm_proof** outs) {
+  return prove_streamed(n, [&](uint32_t i) { return cm::adapt_segment_device(*segments[i]); }, config, inflight, outs);
 }
 // ---- per-component AIR ops (include/cairom_hip.h): the kernels of the whole-segment prover, one component
 // at a time on caller-owned columns --------------------------------------------------------------------------------

@@ -523,6 +523,36 @@ def _backend_prove_many(self, dev_inputs, inflight=3, cfg=None):
 Backend.prove_many = _backend_prove_many
 
 
+def _prove_streamed(self, fn, views, inflight, cfg):
+    n = len(views)
+    ins = (C.c_void_p * n)(*[C.cast(v, C.c_void_p).value for v in views])
+    outs = (C.c_void_p * n)()
+    rc = fn(ins, C.c_uint32(n), _cfg(cfg), C.c_uint32(inflight), outs)
+    proofs = [Proof(self.L, C.c_void_p(outs[i])) if outs[i] else None for i in range(n)]
+    if rc != 0:
+        try:
+            self._ck(rc)
+        except CmError as e:
+            e.partial = proofs
+            raise
+    return proofs
+
+
+def _backend_prove_many_host(self, host_inputs, inflight=3, cfg=None):
+    """Streaming ingest (cm_prove_many_host): HOST ProverInputs; input i + 1 uploads while up to `inflight` proofs run."""
+    return _prove_streamed(self, self.L.cm_prove_many_host, [h.view for h in host_inputs], inflight, cfg)
+
+
+def _backend_prove_many_segments(self, host_segments, inflight=3, cfg=None):
+    """Streaming ingest from runner segments (cm_prove_many_segments): segment i + 1 goes through the device adapter while up to
+    `inflight` proofs run."""
+    return _prove_streamed(self, self.L.cm_prove_many_segments, [h.view for h in host_segments], inflight, cfg)
+
+
+Backend.prove_many_host = _backend_prove_many_host
+Backend.prove_many_segments = _backend_prove_many_segments
+
+
 def _backend_set_preprocessed_cache(self, on):
     """cm_set_preprocessed_cache: keep the committed preprocessed tree (tree 0) between proofs; off by default."""
     self._ck(self.L.cm_set_preprocessed_cache(C.c_int32(1 if on else 0)))

@@ -315,6 +315,14 @@ int32_t cm_rccl_comm_destroy(cm_rccl_comm* c);
  * inputs[i]; on error the first failure is returned and the proofs already built stay in outs (free them). */
 int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
                       cm_proof** outs);
+/* Streaming ingest: cm_prove_many from HOST inputs — the entry point of the reference takes a host
+ * `&mut ProverInput` (crates/prover/src/prover.rs:23-29).  The calling thread uploads input i + 1 (cm_prove_many_host) or runs
+ * the device adapter on runner segment i + 1 (cm_prove_many_segments = import_from_runner_output, adapter/mod.rs:97-193) on
+ * its own stream while up to `inflight` (1..8) library threads prove the inputs before it: the PCIe copies hide under the
+ * proofs.  At most inflight + 1 inputs are resident in HBM at any time.  outs[i] = proof of item i (bit-identical to
+ * cm_prove_segment / cm_adapt_segment_device + cm_prove_device of the same item); error contract of cm_prove_many. */
+int32_t cm_prove_many_host(const cm_prover_input* const* inputs, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
+                           cm_proof** outs);
 /* Preprocessed-tree cache: tree 0 commits constant tables (crates/prover/src/preprocessed/mod.rs:75-82;
  * verifier.rs:38 notes its root is a known constant).  Off by default (every proof recomputes it, as prover.rs:70-73
  * does); on = each host thread keeps the committed tree (coefficients, LDE, Merkle layers) between proofs of one
@@ -350,6 +358,9 @@ typedef struct {
   uint32_t program_range[2], input_range[2], output_range[2];
 } cm_runner_segment;
 int32_t cm_adapt_segment_device(const cm_runner_segment* seg, cm_device_input** out);
+/* streaming ingest from runner segments: see cm_prove_many_host */
+int32_t cm_prove_many_segments(const cm_runner_segment* const* segments, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
+                               cm_proof** outs);
 /* Copy a device-resident ProverInput back (tests: device adapter vs host adapter). */
 int32_t cm_device_input_download(const cm_device_input* in, cm_host_input** out);
 /* The synthetic VM's raw output for one segment (what cm_vm_run feeds to the host adapter). */

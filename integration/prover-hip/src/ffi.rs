@@ -221,6 +221,8 @@ unsafe extern "C" {
     pub fn cm_rccl_comm_view(c: *const cm_rccl_comm) -> *const cm_comm;
     pub fn cm_rccl_comm_destroy(c: *mut cm_rccl_comm) -> i32;
     pub fn cm_prove_many(inputs: *const *const cm_device_input, n: u32, config: *const cm_pcs_config, inflight: u32, outs: *mut *mut cm_proof) -> i32;
+    pub fn cm_prove_many_host(inputs: *const *const cm_prover_input, n: u32, config: *const cm_pcs_config, inflight: u32, outs: *mut *mut cm_proof) -> i32;
+    pub fn cm_prove_many_segments(segments: *const *const cm_runner_segment, n: u32, config: *const cm_pcs_config, inflight: u32, outs: *mut *mut cm_proof) -> i32;
     pub fn cm_set_preprocessed_cache(on: i32) -> i32;
     pub fn cm_set_twiddle_cache(on: i32) -> i32;
     pub fn cm_proof_from_words(words: *const u32, n_words: u64, out: *mut *mut cm_proof) -> i32;

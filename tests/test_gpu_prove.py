@@ -211,6 +211,72 @@ def test_prove_many_pipeline(backend, oracle):
         i.free()
 
 
+def test_streaming_ingest_equals_solo_proofs(backend, oracle):
+    """cm_prove_many_host / cm_prove_many_segments (streaming ingest): the calling thread uploads host ProverInput i + 1 — or runs the
+    device adapter on runner segment i + 1 — while the workers prove the items before it; at most inflight + 1 inputs are resident.
+    Every proof equals the proof of the same item made alone (cm_prove_segment / cm_adapt_segment_device + cm_prove_device), in
+    the order given, with more items than slots so that device inputs are recycled through the producer's pool."""
+    from cairo_m_amd.lib import synth_fibonacci_segment
+    sizes = (3, 50, 100, 1000)
+    inps = [synth_fibonacci(n) for n in sizes]
+    segs = [synth_fibonacci_segment(n) for n in sizes]
+    alone = []
+    for i in inps:
+        p = backend.prove(i)
+        alone.append(p.words().copy())
+        p.free()
+    assert oracle.verify(alone[3])[0] == 0
+    order = [0, 3, 1, 2, 3, 3, 0, 2, 1, 3, 2]
+    for inflight in (1, 3):
+        proofs = backend.prove_many_host([inps[k] for k in order], inflight=inflight)
+        for k, p in zip(order, proofs):
+            assert np.array_equal(p.words(), alone[k]), (inflight, k)
+            p.free()
+    seg_alone = []
+    for sg in segs:
+        d = backend.adapt_segment(sg)
+        p = backend.prove_device(d)
+        seg_alone.append(p.words().copy())
+        p.free()
+        backend.free_input(d)
+    proofs = backend.prove_many_segments([segs[k] for k in order], inflight=2)
+    for k, p in zip(order, proofs):
+        assert np.array_equal(p.words(), seg_alone[k]), k
+        p.free()
+    for x in inps + segs:
+        x.free()
+
+
+def test_streaming_ingest_reports_a_bad_item_and_keeps_the_rest(backend):
+    """Error contract of the streaming form = cm_prove_many's: the first failure is returned, the other proofs are built."""
+    import ctypes as C
+    from cairo_m_amd.lib import CmError, ProverInputView
+    inps = [synth_fibonacci(n) for n in (9, 30, 12, 40)]
+    solo = []
+    for i in inps:
+        p = backend.prove(i)
+        solo.append(p.words().copy())
+        p.free()
+    v = C.cast(inps[1].view, C.POINTER(ProverInputView)).contents
+    acc = np.ctypeslib.as_array(C.cast(v.data_accesses, C.POINTER(C.c_uint32)), shape=(int(v.n_data_accesses), 4))
+    acc[20:40, 3] ^= 1
+    with pytest.raises(CmError) as e:
+        backend.prove_many_host(inps, inflight=2)
+    assert "status 10" in str(e.value)
+    part = e.value.partial
+    assert part[1] is None
+    for k in (0, 2, 3):
+        assert part[k] is not None and np.array_equal(part[k].words(), solo[k])
+        part[k].free()
+    acc[20:40, 3] ^= 1
+    good = backend.prove_many_host(inps, inflight=2)
+    for k, p in enumerate(good):
+        assert np.array_equal(p.words(), solo[k])
+        p.free()
+    for i in inps:
+        i.free()
+
+
 def test_invalid_witness_is_rejected_with_status_10(backend, oracle):
     """Error behaviour of the boundary: the reference surfaces exactly one Stwo error, ProvingError::Stwo(
     ConstraintsNotSatisfied) (crates/prover/src/errors.rs:14-18) — the composition polynomial does not match the
