@@ -456,7 +456,8 @@ def main():
         # i + 1 under the proofs of the items before it — compare with `pipelined.ms_per_proof` (inputs resident in HBM)
         streamed = None
         if args.pipelined > 1:
-            n_str = 4 * args.pipelined
+            n_str = 8 * args.pipelined   # a STREAM of segments: the first proof cannot start before the first upload has landed
+                                         # (~6 ms of pipeline fill, once), so the run is long enough to amortise it below 2 %
             def run_streamed(fn, item):
                 for p in fn([item] * args.pipelined, inflight=args.pipelined):
                     p.free()
