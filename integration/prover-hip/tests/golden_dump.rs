@@ -268,3 +268,123 @@ fn dump_reference_goldens() {
         dump(&case.name, input);
     }
 }
+
+// ---- per-op vectors: ref_ops.json -----------------------------------------------------------------------------------------------
+// The whole-proof goldens above localise a disagreement to a transcript step; these localise it to ONE Stwo backend operation on a
+// seeded input the HIP repository regenerates itself (tests/test_ref_ops.py: `lcg` below, same constants): interpolate, evaluate on
+// the double domain, eval_at_point, the Merkle root of a mixed-degree tree, fold_line, fold_circle_into_line, grind, and the order
+// in which ColumnSampleBatch::new_vec groups sample points (framing switch `sample_batch`).  Stwo signatures as of `ab57a1c`, from
+// memory — this file has never been compiled (see the header); adjust the calls, keep the JSON keys.
+use stwo_prover::core::backend::Column;
+use stwo_prover::core::circle::{CirclePoint, Coset, SECURE_FIELD_CIRCLE_GEN};
+use stwo_prover::core::fields::secure_column::SecureColumnByCoords;
+use stwo_prover::core::fri::FriOps;
+use stwo_prover::core::pcs::quotients::{ColumnSampleBatch, PointSample};
+use stwo_prover::core::poly::circle::{CanonicCoset, CircleEvaluation, PolyOps, SecureEvaluation};
+use stwo_prover::core::poly::line::{LineDomain, LineEvaluation};
+use stwo_prover::core::poly::BitReversedOrder;
+use stwo_prover::core::vcs::prover::MerkleProver;
+
+const P31: u64 = (1 << 31) - 1;
+/// x <- x * 6364136223846793005 + 1442695040888963407 (mod 2^64); value = (x >> 33) mod (2^31 - 1)
+fn lcg(seed: u64, n: usize) -> Vec<M31> {
+    let mut s = seed;
+    (0..n)
+        .map(|_| {
+            s = s.wrapping_mul(6364136223846793005).wrapping_add(1442695040888963407);
+            M31::from_u32_unchecked(((s >> 33) % P31) as u32)
+        })
+        .collect()
+}
+fn words(v: &[M31]) -> String {
+    v.iter().map(|x| x.0.to_string()).collect::<Vec<_>>().join(",")
+}
+fn qwords(q: SecureField) -> String {
+    let a = q.to_m31_array();
+    format!("[{},{},{},{}]", a[0].0, a[1].0, a[2].0, a[3].0)
+}
+fn secure_col(seed: u64, n: usize) -> SecureColumnByCoords<SimdBackend> {
+    let mut c = SecureColumnByCoords::<SimdBackend>::zeros(n);
+    let v = lcg(seed, 4 * n);
+    for i in 0..n {
+        c.set(i, SecureField::from_m31_array([v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]]));
+    }
+    c
+}
+fn secure_words(c: &SecureColumnByCoords<SimdBackend>) -> String {
+    // coordinate-major: 4 columns of n words, like cm_fri_fold_line's four handles
+    (0..4).map(|k| format!("[{}]", words(&c.columns[k].to_cpu()))).collect::<Vec<_>>().join(",")
+}
+
+#[test]
+fn dump_reference_ops() {
+    const LOG: u32 = 6;
+    let n = 1usize << LOG;
+    let domain = CanonicCoset::new(LOG).circle_domain();
+    let big = CanonicCoset::new(LOG + 1).circle_domain();
+    let twiddles = SimdBackend::precompute_twiddles(big.half_coset);
+    // interpolate / evaluate / eval_at_point: seed 1
+    let eval = CircleEvaluation::<SimdBackend, M31, BitReversedOrder>::new(domain, lcg(1, n).into_iter().collect());
+    let poly = eval.interpolate_with_twiddles(&twiddles);
+    let coeffs = poly.coeffs.to_cpu();
+    let lde = poly.evaluate_with_twiddles(big, &twiddles).values.to_cpu();
+    let pt = SECURE_FIELD_CIRCLE_GEN.mul(7);
+    let at = poly.eval_at_point(pt);
+    // Merkle: columns of 2^5, 2^5 and 2^3 rows (seeds 2, 3, 4): the mixed-degree root
+    let (ca, cb, cc) = (lcg(2, 32), lcg(3, 32), lcg(4, 8));
+    let cols: Vec<<SimdBackend as stwo_prover::core::backend::ColumnOps<M31>>::Column> =
+        vec![ca.iter().copied().collect(), cb.iter().copied().collect(), cc.iter().copied().collect()];
+    let tree = MerkleProver::<SimdBackend, Blake2sMerkleHasher>::commit(cols.iter().collect());
+    // FRI folds: a line evaluation of 2^LOG points (seed 5) folded once; a circle evaluation of 2^LOG points (seed 6) folded into
+    // a zero line of 2^(LOG-1); alpha = the four words of seed 7
+    let a = lcg(7, 4);
+    let alpha = SecureField::from_m31_array([a[0], a[1], a[2], a[3]]);
+    let line = LineEvaluation::<SimdBackend>::new(LineDomain::new(Coset::half_odds(LOG)), secure_col(5, n));
+    let folded = SimdBackend::fold_line(&line, alpha, &twiddles);
+    let src = SecureEvaluation::<SimdBackend, BitReversedOrder>::new(domain, secure_col(6, n));
+    let mut dst = LineEvaluation::<SimdBackend>::new_zero(LineDomain::new(domain.half_coset));
+    SimdBackend::fold_circle_into_line(&mut dst, &src, alpha, &twiddles);
+    // grind: a fresh channel after mix_u64(0x0123456789abcdef), 10 bits
+    let mut ch = Blake2sChannel::default();
+    ch.mix_u64(0x0123456789abcdef);
+    let digest_before = ch.digest();
+    let nonce = <SimdBackend as GrindOps<Blake2sChannel>>::grind(&ch, 10);
+    // ColumnSampleBatch::new_vec: column 0 sampled at p1, column 1 at [p2, p1], column 2 at p1 — batches in Stwo's order
+    let (p1, p2) = (SECURE_FIELD_CIRCLE_GEN.mul(5), SECURE_FIELD_CIRCLE_GEN.mul(3));
+    let v = SecureField::from_m31_array([a[0], a[0], a[0], a[0]]);
+    let s0 = vec![PointSample { point: p1, value: v }];
+    let s1 = vec![PointSample { point: p2, value: v }, PointSample { point: p1, value: v }];
+    let s2 = vec![PointSample { point: p1, value: v }];
+    let batches = ColumnSampleBatch::new_vec(&[&s0, &s1, &s2]);
+    let batch_json: Vec<String> = batches
+        .iter()
+        .map(|b| {
+            format!(
+                "{{\"point_x\":{},\"point_y\":{},\"columns\":[{}]}}",
+                qwords(b.point.x),
+                qwords(b.point.y),
+                b.columns_and_values.iter().map(|(c, _)| c.to_string()).collect::<Vec<_>>().join(",")
+            )
+        })
+        .collect();
+    let out = format!(
+        "{{\"source\":\"reference\",\"stwo_rev\":\"ab57a1c\",\"log\":{LOG},\n\"interpolate\":[{}],\n\"evaluate\":[{}],\n\"eval_at_point\":{{\"x\":{},\"y\":{},\"value\":{}}},\n\"merkle_root\":\"{}\",\n\"alpha\":{},\n\"fold_line\":[{}],\n\"fold_circle_into_line\":[{}],\n\"grind\":{{\"digest\":\"{}\",\"bits\":10,\"nonce\":{}}},\n\"sample_batches\":{{\"p1_x\":{},\"p2_x\":{},\"batches\":[{}]}}}}\n",
+        words(&coeffs),
+        words(&lde),
+        qwords(pt.x),
+        qwords(pt.y),
+        qwords(at),
+        hex(&tree.root().0),
+        qwords(alpha),
+        secure_words(&folded.values),
+        secure_words(&dst.values),
+        hex(&digest_before.0),
+        nonce,
+        qwords(p1.x),
+        qwords(p2.x),
+        batch_json.join(",")
+    );
+    let path = golden_dir().join("ref_ops.json");
+    std::fs::write(&path, out).expect("write ref_ops.json");
+    println!("wrote {}", path.display());
+}

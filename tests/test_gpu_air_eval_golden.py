@@ -159,6 +159,17 @@ def test_hip_domain_eval_matches_reference_derived_vectors(backend, oracle, name
             want, j = expected_row(rows[k], rels_z, rels_apow, coeffs, n_cons - n_batches, dinv[r >> LOG])
             assert j == n_batches and n_inter == 4 * n_batches
             assert tuple(int(x) for x in acc[:, r]) == want, (name, "evaluation-domain row", r, "golden row", k)
+            # the comparison is sensitive: the same row with ONE constraint value or ONE tuple element changed does not match
+            bad = json.loads(json.dumps(rows[k]))
+            if bad["constraints"]:
+                bad["constraints"][-1] = (bad["constraints"][-1] + 1) % P
+            else:
+                bad["relations"][0][2][0] = (bad["relations"][0][2][0] + 1) % P
+            assert expected_row(bad, rels_z, rels_apow, coeffs, n_cons - n_batches, dinv[r >> LOG])[0] != want
+            bad = json.loads(json.dumps(rows[k]))
+            bad["relations"][-1][2][-1] = (bad["relations"][-1][2][-1] + 1) % P
+            assert expected_row(bad, rels_z, rels_apow, coeffs, n_cons - n_batches, dinv[r >> LOG])[0] != want
+        assert acc.any()
     finally:
         for h in h_tr + h_it + h_pp + h_acc:
             backend.col_free(h)
