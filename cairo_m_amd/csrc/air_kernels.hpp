@@ -18,6 +18,11 @@ struct ConstraintArgs {
   int n_base;                   // number of add_constraint constraints
   uint32_t cumsum_shift[4];
   uint32_t denom_inv[2];        // 1 / coset_vanishing on the two cosets of the evaluation domain
+  // Row range of the evaluation domain to cover (n_rows = 0: all 2^(log_size + 1) rows).  The sharded prover evaluates a
+  // component that is split over the ranks on ITS rows only: tr / it then point `row0` words in front of the rank's slices (the
+  // kernels index columns by the global row), the last four interaction columns (the cumulative sum, read at the previous
+  // row as well) and pp are full columns.
+  uint32_t row0 = 0, n_rows = 0;
 };
 
 void launch_opcode_trace(int cid, const void* bundles, uint32_t n, const void* acc, uint32_t log_size, uint32_t* const* d_cols,

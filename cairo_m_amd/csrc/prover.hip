@@ -1328,10 +1328,23 @@ int32_t cm_shard_plan(const cm_prover_input* input, uint32_t world, int32_t owne
     CM_CHECK(world >= 1 && world <= 8 && (world & (world - 1)) == 0, "cm_shard_plan: world must be 1, 2, 4 or 8");
     uint32_t clog[air::N_COMPONENTS];
     cm::component_logs(*input, clog);
-    int owner[air::N_COMPONENTS];
-    cm::shard_plan(clog, world, owner);
-    for (int c = 0; c < air::N_COMPONENTS; c++) if (owner_out) owner_out[c] = owner[c];
-    if (staging_words) *staging_words = cm::shard_staging_words(clog, owner, world);
+    const cm::ShardPlan p = cm::make_shard_plan(clog, world);
+    for (int c = 0; c < air::N_COMPONENTS; c++) if (owner_out) owner_out[c] = p.owner[c];
+    if (staging_words) *staging_words = cm::shard_staging_words(clog, p, world);
+  });
+}
+int32_t cm_shard_plan_columns(const cm_prover_input* input, uint32_t world, int32_t* trace_col_owner, uint32_t* n_trace_cols,
+                              int32_t* interaction_col_owner, uint32_t* n_interaction_cols, uint64_t load_cells[8]) {
+  return pguard([&] {
+    CM_CHECK(world >= 1 && world <= 8 && (world & (world - 1)) == 0, "cm_shard_plan_columns: world must be 1, 2, 4 or 8");
+    uint32_t clog[air::N_COMPONENTS];
+    cm::component_logs(*input, clog);
+    const cm::ShardPlan p = cm::make_shard_plan(clog, world);
+    if (trace_col_owner) for (size_t j = 0; j < p.tr_owner.size(); j++) trace_col_owner[j] = p.tr_owner[j];
+    if (interaction_col_owner) for (size_t j = 0; j < p.it_owner.size(); j++) interaction_col_owner[j] = p.it_owner[j];
+    if (n_trace_cols) *n_trace_cols = (uint32_t)p.tr_owner.size();
+    if (n_interaction_cols) *n_interaction_cols = (uint32_t)p.it_owner.size();
+    if (load_cells) for (int k = 0; k < 8; k++) load_cells[k] = p.load[k];
   });
 }
 int32_t cm_prove_sharded(const cm_device_input* input, const cm_pcs_config* config, const cm_comm* comm, cm_proof** out) {

@@ -49,6 +49,18 @@ def shard_plan(host_input, world, lib=None):
     return list(owner), words.value
 
 
+def shard_plan_columns(host_input, world, lib=None):
+    """column-level plan (cm_shard_plan_columns): (owner of every trace column, owner of every interaction column, cells per rank)"""
+    L = lib or load_library()
+    tr, it = (C.c_int32 * 2048)(), (C.c_int32 * 2048)()
+    ntr, nit = C.c_uint32(0), C.c_uint32(0)
+    load = (C.c_uint64 * 8)()
+    rc = L.cm_shard_plan_columns(host_input.view, C.c_uint32(world), tr, C.byref(ntr), it, C.byref(nit), load)
+    if rc:
+        raise CmError(f"cm_shard_plan_columns failed with status {rc}")
+    return list(tr[:ntr.value]), list(it[:nit.value]), list(load[:world])
+
+
 class TorchComm:
     """cm_comm over torch.distributed.  `staging` = (send, recv) int32 tensors: CUDA tensors for a real run, CPU tensors when
     the collectives are exercised without a GPU (tests/test_multirank_cpu.py)."""

@@ -300,6 +300,13 @@ typedef struct cm_comm {
 #define CM_COMM_STREAM_ORDERED 1u
 /* host code (no GPU): which rank owns which component, and the staging capacity (words) a sharded proof of `input` needs */
 int32_t cm_shard_plan(const cm_prover_input* input, uint32_t world, int32_t owner[CM_N_COMPONENTS], uint64_t* staging_words);
+/* owner[c] = -1: component c is SPLIT over all ranks — a large opcode component (more than an eighth of a rank's fair share of
+ * the cells, at least 2^12 rows) is generated, looked up and constrained by ROW RANGE on every rank, and its columns are
+ * transformed by the ranks the plan gives them to one by one (the four cumulative-sum columns of its LogUp stay together).
+ * cm_shard_plan_columns reports that column-level plan: the owner of every column of trees 1 / 2 in commitment order (arrays of
+ * at least 2048 entries; the counts come back in n_*_cols) and the cells every rank transforms (load_cells[r], r < world). */
+int32_t cm_shard_plan_columns(const cm_prover_input* input, uint32_t world, int32_t* trace_col_owner, uint32_t* n_trace_cols,
+                              int32_t* interaction_col_owner, uint32_t* n_interaction_cols, uint64_t load_cells[8]);
 int32_t cm_prove_sharded(const cm_device_input* input, const cm_pcs_config* config, const cm_comm* comm, cm_proof** out);
 /* In-library cm_comm on RCCL (xGMI inside a node), stream-ordered: no host synchronisation around an exchange, nothing but
  * the library in the data path.  Rank 0 makes the 128-byte id (cm_rccl_unique_id) and the launcher hands it to every rank;

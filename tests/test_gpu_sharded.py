@@ -71,6 +71,28 @@ def test_sharded_fri_layers_by_row_range(backend, oracle, tmp_path, world, fib_n
     inp.free()
 
 
+@pytest.mark.parametrize("world,fib_n,min_log", [(2, 200, 5), (4, 3_000, 6), (8, 30_000, 7), (4, 100_000, 12), (2, 30_000, 99)])
+def test_split_components_by_rows_and_columns(backend, oracle, tmp_path, world, fib_n, min_log):
+    """Large opcode components are SPLIT over the ranks (ShardPlan): trace rows, lookup histograms, LogUp rows and constraint
+    quotients by row range, IFFT / LDE / OODS by column, with the rows -> columns transposes in between and the cumulative-sum
+    LDE columns gathered for the previous-row mask.  CM_SHARD_SPLIT_MIN_LOG lowers the size threshold so that small proofs split
+    most of their opcode components (down to 4-row slices); 99 = never split (the whole-component plan of rounds 2-3).  The proof
+    never changes."""
+    inp = synth_fibonacci(fib_n)
+    p = backend.prove(inp)
+    want = p.words().copy()
+    p.free()
+    out = str(tmp_path / "proof")
+    log = _run_sharded(world, fib_n, out, extra_env={"CM_SHARD_SPLIT_MIN_LOG": str(min_log)})
+    for r in range(world):
+        got = np.load(f"{out}.{r}.npy")
+        assert got.size == want.size, (r, got.size, want.size, log[-500:])
+        diff = np.nonzero(got != want)[0]
+        assert diff.size == 0, f"rank {r}: first differing words {diff[:8]} of {got.size}"
+    assert oracle.verify(want)[0] == 0
+    inp.free()
+
+
 @pytest.mark.parametrize("world,iters", [(2, 300), (4, 24_000), (8, 100_000)])
 def test_sharded_all_opcode_proof_equals_single_gpu_proof(backend, oracle, tmp_path, world, iters):
     """BASELINE configs[4] shape: every opcode component live (24 of them with ~iters rows each), so the ownership plan spreads

@@ -23,9 +23,9 @@ inp = synth_fibonacci(3000)
 owner, words = shard_plan(inp, world)
 t = torch.tensor(owner, dtype=torch.int32)
 ref = t.clone(); dist.broadcast(ref, 0)
-assert torch.equal(t, ref) and set(owner) == set(range(world)) and words > 0
+assert torch.equal(t, ref) and set(o for o in owner if o >= 0) == set(range(world)) and words > 0   # (-1: split over all ranks)
 big, _ = shard_plan(synth_fibonacci(100_000), world)
-assert big[7] != big[6]              # store_fp_imm and store_fp_fp, the two heaviest components of a large fibonacci_loop
+assert big[7] == -1 and big[6] == -1  # store_fp_imm and store_fp_fp, the two heaviest components of a large fibonacci_loop: split over the ranks
 # ---- collectives on CPU staging buffers (the GPU path differs only in where the buffers live)
 comm = TorchComm(1 << 12)
 send = np.frombuffer((C.c_uint32 * (1 << 12)).from_address(comm.send.data_ptr()), dtype=np.uint32)

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Host-side AddressSanitizer build of the library next to the shipped one (SURVEY §5 "race detection / sanitizers"):
+#   tools/asan_build.sh            -> cairo_m_amd/libcairom_hip_asan.so  (objects in cairo_m_amd/csrc/build_asan)
+# Device code is NOT instrumented (-fno-gpu-sanitize: the image has no xnack+ ASAN device runtime); what this build checks is the
+# host side of the prover — the decommitment sections and gather plans, the upload ring, the pinned landing buffers, proof
+# assembly, the C ABI marshalling — under the real GPU workload.  Run on the GPU box with tools/asan_run.sh.
+set -e
+cd "$(dirname "$0")/../cairo_m_amd/csrc"
+make -j8 BUILD=build_asan TARGET=../libcairom_hip_asan.so \
+  EXTRA="-fsanitize=address -fno-gpu-sanitize -shared-libasan -g -fno-omit-frame-pointer" \
+  LDEXTRA="-fsanitize=address -fno-gpu-sanitize -shared-libasan"

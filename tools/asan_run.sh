@@ -1,0 +1,13 @@
+#!/bin/bash
+# On the GPU box: the GPU test suite (or "$@") against the host-ASAN build of the library.  Output -> gpurun_out/<tag>_asan.txt
+#   tools/asan_run.sh r04 [pytest args...]
+tag=${1:-rXX}; shift
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+export CAIROM_HIP_LIB=$PWD/cairo_m_amd/libcairom_hip_asan.so
+# detect_leaks=0: CPython and the HIP runtime keep process-lifetime allocations; protect_shadow_gap=0: the ROCm runtime maps
+# fixed addresses inside ASAN's shadow gap
+export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:log_path=gpurun_out/${tag}_asan_report
+ARGS=("$@"); [ ${#ARGS[@]} -eq 0 ] && ARGS=(tests -m gpu -q -x --deselect tests/test_gpu_workloads.py::test_configs4_all_opcodes_at_2pow26_rows_verifies)
+LD_PRELOAD=$RT python -m pytest "${ARGS[@]}" > gpurun_out/${tag}_asan.txt 2>&1
+tail -5 gpurun_out/${tag}_asan.txt
+ls gpurun_out/${tag}_asan_report* 2>/dev/null | head
