@@ -196,6 +196,7 @@ def main():
                          "RCCL communicator (cm_rccl_comm_create) — needs one GPU per rank")
     ap.add_argument("--force-device", type=int, default=-1, help="every rank uses this GPU (tests: ranks sharing one GPU over gloo)")
     ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--cfg", default="", help="PcsConfig as pow_bits,log_blowup_factor,log_last_layer_degree_bound,n_queries (default REGULAR_96_BITS)")
     ap.add_argument("--out", default="", help="rank r writes its proof words to <out>.<r>.npy")
     ap.add_argument("--check-single", action="store_true", help="every rank also makes the single-GPU proof and compares all words")
     ap.add_argument("--json", action="store_true", help="rank 0 prints one JSON line (bench.py's `sharded` object) instead of a dict")
@@ -216,16 +217,19 @@ def main():
         inp = vm_run(all_opcodes_program(a.mixed_iters)[0], entry_pc=0, args=(), n_returns=0)
     else:
         inp = synth_fibonacci(a.fib_n)
+    cfg = tuple(int(x) for x in a.cfg.split(",")) if a.cfg else None
     owner, words = shard_plan(inp, dist.get_world_size(), be.L)
+    if cfg and cfg[1] > 1:
+        words <<= cfg[1] - 1              # cm_shard_plan sizes the staging buffers for log_blowup_factor 1: the LDE grows by 2^(B - 1)
     comm = RcclComm(be, words) if a.comm == "rccl" else TorchComm(words, device=local)
     dev = be.upload_input(inp)
-    p = prove_sharded(be, dev, comm)          # warm-up + the proof that is written out
+    p = prove_sharded(be, dev, comm, cfg)     # warm-up + the proof that is written out
     w = p.words().copy()
     cells = p.stats()["cells"]
     p.free()
     same = None
     if a.check_single:
-        q = be.prove_device(dev)
+        q = be.prove_device(dev, cfg)
         same = bool(q.words().size == w.size and (q.words() == w).all())
         q.free()
     ms, phases = [], {}
@@ -233,7 +237,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter()
-        q = prove_sharded(be, dev, comm)
+        q = prove_sharded(be, dev, comm, cfg)
         torch.cuda.synchronize()
         ms.append((time.perf_counter() - t) * 1e3)
         phases = {k: round(v, 3) for k, v in q.stats()["phase_ms"].items()}
@@ -253,7 +257,8 @@ def main():
                 "unit": "M31 trace cells/s", "bit_identical_to_single_gpu_proof": (tt[1].item() == 0.0) if a.check_single else None,
                 "component_owner": owner, "collectives_per_proof": comm.calls // (a.steps + 1),
                 "MB_sent_per_rank_per_proof": comm.bytes_moved / (a.steps + 1) / 1e6, "phase_ms": phases,
-                "note": "whole components are the sharding unit; Merkle hashing of all four trees, the DEEP quotients and the FRI "
+                "note": "components are the sharding unit, large opcode components split by rows (generation, lookups, constraints) and "
+                        "columns (transforms); Merkle hashing of all four trees, the DEEP quotients and the FRI "
                         "layers above 2^16 rows are row-sharded; the (cheap) transforms of trees 0 / 3 and the small FRI layers are "
                         "replicated; time = max over ranks of the wall time of `steps` proofs"}))
     elif dist.get_rank() == 0:

@@ -22,10 +22,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_sharded(world, fib_n, out, mixed_iters=0, comm="torch", extra_env=None):
+def _run_sharded(world, fib_n, out, mixed_iters=0, comm="torch", extra_env=None, cfg=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "-m", "cairo_m_amd.sharded", "--fib-n", str(fib_n), "--dist-backend", "gloo",
            "--force-device", "0", "--steps", "0", "--out", out, "--mixed-iters", str(mixed_iters), "--comm", comm]
+    if cfg:
+        cmd += ["--cfg", ",".join(str(x) for x in cfg)]
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(extra_env or {})
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
@@ -90,6 +92,26 @@ def test_split_components_by_rows_and_columns(backend, oracle, tmp_path, world, 
         diff = np.nonzero(got != want)[0]
         assert diff.size == 0, f"rank {r}: first differing words {diff[:8]} of {got.size}"
     assert oracle.verify(want)[0] == 0
+    inp.free()
+
+
+@pytest.mark.parametrize("world,fib_n,cfg", [(2, 300, (10, 2, 0, 30)), (4, 30_000, (8, 3, 1, 20)), (8, 3_000, (8, 2, 2, 16))])
+def test_sharded_log_blowup_factor_above_one(backend, oracle, tmp_path, world, fib_n, cfg):
+    """log_blowup_factor > 1 in the sharded prover: commitment domains of log + B, constraints on the (log + 1) domain of every
+    owner's own polynomials (whole components: no split), FRI with the larger blowup — equal to the single-GPU proof under the same
+    PcsConfig, which the oracle's verifier accepts under that config."""
+    inp = synth_fibonacci(fib_n)
+    p = backend.prove(inp, cfg=cfg)
+    want = p.words().copy()
+    p.free()
+    out = str(tmp_path / "proof")
+    log = _run_sharded(world, fib_n, out, cfg=cfg)
+    for r in range(world):
+        got = np.load(f"{out}.{r}.npy")
+        assert got.size == want.size, (r, got.size, want.size, log[-500:])
+        diff = np.nonzero(got != want)[0]
+        assert diff.size == 0, f"rank {r}: first differing words {diff[:8]} of {got.size}"
+    assert oracle.verify(want, cfg=cfg)[0] == 0
     inp.free()
 
 
