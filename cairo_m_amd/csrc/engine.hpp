@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <sched.h>
 #include <vector>
+#include <functional>
 #include <string.h>
 #include <utility>
 #include "field.hpp"
@@ -123,6 +124,11 @@ void gather_words(const uint32_t* const* d_addrs, uint32_t n, uint32_t width, ui
 struct RowRun { const uint32_t* const* d_cols; uint32_t n_cols, row, out_off, pad; };
 void gather_runs(const RowRun* d_runs, uint32_t n_runs, uint32_t* d_out, hipStream_t st);
 
+// Per-thread resources (streams, events, pinned buffers, the upload ring) are created on first use by whichever host thread enters
+// the library; `at_thread_exit` registers their release for the moment that thread ends (reverse order).  Without it a service
+// that proves from short-lived threads leaked ~35 MB of pinned host memory, nine streams and a few dozen events per thread — the
+// round-4 soak (tools/stress_pipeline.py: three new threads per round for ten minutes) took the test box down twice that way.
+void at_thread_exit(std::function<void()> f);
 // pool.cpp-style services implemented in pool.hip
 void* pool_get(size_t bytes);
 void pool_put(void* p);
@@ -155,6 +161,7 @@ hipStream_t thread_main_stream();
 // side stream i of the calling host thread (the streams Fork hands out), with NO ordering against anything: the caller orders it
 // with events (Prover::commit_enqueue runs the transforms of a commitment there, next to the Merkle launches on the main stream)
 hipStream_t thread_side_stream(int i);
+hipStream_t thread_priority_stream(int rel);   // rel < 0: highest priority class, > 0: lowest (own hardware queues; pool.hip)
 
 // Fork/join over a small set of side streams (thread-local, created once): independent per-component
 // launches of one phase run concurrently instead of serialising 34 tiny kernels on one stream.

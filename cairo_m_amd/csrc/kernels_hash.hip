@@ -251,6 +251,8 @@ static uint32_t* next_ticket(hipStream_t st) {
     // (Recycled device memory is not zero: with the plain hipMemset a second prover thread drew garbage tickets.)
     CM_HIP(hipMemsetAsync(ring, 0, N * 4, st));
     CM_HIP(hipStreamSynchronize(st));
+    uint32_t* own = ring;
+    at_thread_exit([own] { (void)hipFree(own); });
   }
   return ring + (pos++ % N);
 }

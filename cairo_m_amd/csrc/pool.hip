@@ -86,9 +86,36 @@ struct Stage {
     if (!base) CM_HIP(hipHostMalloc((void**)&base, size, hipHostMallocDefault));
   }
 };
-Stage& stage() { static thread_local Stage* s = new Stage(); return *s; }  // ring wrap syncs only the owner's stream
+Stage& stage() {   // ring wrap syncs only the owner's stream
+  static thread_local Stage* s = nullptr;
+  if (!s) {
+    s = new Stage();
+    Stage* own = s;
+    at_thread_exit([own] {
+      for (const Stage::User& u : own->users) { (void)hipEventSynchronize(u.ev); (void)hipEventDestroy(u.ev); }
+      for (hipEvent_t e : own->spare) (void)hipEventDestroy(e);
+      if (own->base) (void)hipHostFree(own->base);
+      delete own;
+    });
+  }
+  return *s;
+}
 }  // namespace
 
+namespace {
+struct ThreadExit {
+  std::vector<std::function<void()>> fns;
+  ~ThreadExit() {
+    for (auto it = fns.rbegin(); it != fns.rend(); ++it) {
+      try { (*it)(); } catch (...) {}   // never throw out of a thread's teardown
+    }
+  }
+};
+}  // namespace
+void at_thread_exit(std::function<void()> f) {
+  static thread_local ThreadExit te;
+  te.fns.push_back(std::move(f));
+}
 void* pool_get(size_t bytes) { return pool().get(bytes); }
 void pool_put(void* p) { pool().put(p); }
 void pool_trim() { pool().trim(); }
@@ -148,7 +175,15 @@ struct Landing {
   uint8_t* base = nullptr;
   size_t cap = 0;
 };
-Landing& landing() { static thread_local Landing* l = new Landing(); return *l; }
+Landing& landing() {
+  static thread_local Landing* l = nullptr;
+  if (!l) {
+    l = new Landing();
+    Landing* own = l;
+    at_thread_exit([own] { if (own->base) (void)hipHostFree(own->base); delete own; });
+  }
+  return *l;
+}
 }  // namespace
 const void* stage_download_async(const void* src, size_t bytes, hipStream_t st) {
   Landing& l = landing();
@@ -165,7 +200,11 @@ const void* stage_download_async(const void* src, size_t bytes, hipStream_t st) 
 // FRI challenges): copies into pageable memory block the caller and cost 15-25 us each
 uint32_t* pinned_words() {
   static thread_local uint32_t* p = nullptr;
-  if (!p) CM_HIP(hipHostMalloc((void**)&p, 4096, hipHostMallocDefault));
+  if (!p) {
+    CM_HIP(hipHostMalloc((void**)&p, 4096, hipHostMallocDefault));
+    uint32_t* own = p;
+    at_thread_exit([own] { (void)hipHostFree(own); });
+  }
   return p;
 }
 
@@ -182,10 +221,38 @@ struct SideStreams {
     CM_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
   }
 };
-SideStreams& side() { static thread_local SideStreams* s = new SideStreams(); return *s; }
+SideStreams& side() {
+  static thread_local SideStreams* s = nullptr;
+  if (!s) {
+    s = new SideStreams();
+    SideStreams* own = s;
+    at_thread_exit([own] {
+      for (int i = 0; i < Fork::N; i++) { (void)hipStreamSynchronize(own->s[i]); (void)hipStreamDestroy(own->s[i]); (void)hipEventDestroy(own->done[i]); }
+      (void)hipEventDestroy(own->fork_ev);
+      delete own;
+    });
+  }
+  return *s;
+}
 }  // namespace
 
 hipStream_t thread_side_stream(int i) { return side().s[((i % Fork::N) + Fork::N) % Fork::N]; }
+// A stream of its own PRIORITY class: the runtime keeps separate hardware queues per priority, so this stream never shares a
+// hardware queue with the main / side streams (eight normal-priority streams land on four queues, and two streams on one queue
+// run strictly one after the other: the transforms of tree 1 once sat in front of the whole preprocessed tree that way).
+// rel: -1 = the highest priority the device offers, +1 = the lowest.
+hipStream_t thread_priority_stream(int rel) {
+  static thread_local hipStream_t hi = nullptr, lo = nullptr;
+  hipStream_t& s = rel < 0 ? hi : lo;
+  if (!s) {
+    int least = 0, greatest = 0;
+    CM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));   // numerically: greatest <= 0 <= least
+    CM_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, rel < 0 ? greatest : least));
+    hipStream_t own = s;
+    at_thread_exit([own] { (void)hipStreamSynchronize(own); (void)hipStreamDestroy(own); });
+  }
+  return s;
+}
 Fork::Fork(hipStream_t main_stream) : main(main_stream) { CM_HIP(hipEventRecord(side().fork_ev, main)); }
 int Fork::main_or(int side_index) {
   static const bool on = !(getenv("CM_FORK_MAIN") && atoi(getenv("CM_FORK_MAIN")) == 0);
@@ -290,6 +357,8 @@ hipStream_t thread_main_stream() {
   if (!s) {
     bind_thread_to_library_device();
     CM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipStream_t own = s;
+    at_thread_exit([own] { (void)hipStreamSynchronize(own); (void)hipStreamDestroy(own); });
   }
   return s;
 }

@@ -564,7 +564,7 @@ struct SegmentProver {
     // to all of the above; its root is copied on THAT stream and waited for here, while the GPU is still busy with tree 1.
     if (pp_fork) {
       static thread_local hipEvent_t ev_root0 = nullptr;
-      if (!ev_root0) CM_HIP(hipEventCreateWithFlags(&ev_root0, hipEventDisableTiming));
+      if (!ev_root0) { CM_HIP(hipEventCreateWithFlags(&ev_root0, hipEventDisableTiming)); thread_event_owned(ev_root0); }
       hipStream_t ps = pp_fork->stream(Fork::N - 1);
       CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT0, P.trees[0].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, ps));
       CM_HIP(hipEventRecord(ev_root0, ps));
@@ -643,7 +643,7 @@ struct SegmentProver {
       // the host only waits for THIS copy (an event), after the tree-2 transforms and hashes have been enqueued behind it:
       // no GPU idle time while the host reads and mixes the 34 sums
       static thread_local hipEvent_t ev_sums = nullptr;
-      if (!ev_sums) CM_HIP(hipEventCreateWithFlags(&ev_sums, hipEventDisableTiming));
+      if (!ev_sums) { CM_HIP(hipEventCreateWithFlags(&ev_sums, hipEventDisableTiming)); thread_event_owned(ev_sums); }
       CM_HIP(hipEventRecord(ev_sums, st));
       sums_ready = ev_sums;
     }
@@ -968,7 +968,7 @@ struct SegmentProver {
       chan_mix_root_draw(d_chan, P.trees[3].merkle.layers[0].u32(), d_step3.u32(), d_step3.u32() + 4, st);
       // root 3 and the felt come back HERE in stream order — in front of the evaluation kernels enqueued next
       CM_HIP(hipMemcpyAsync(pinned_words() + PIN_STEP3, d_step3.p, 48, hipMemcpyDeviceToHost, st));   // {felt[4], root 3 [8]}: one copy
-      if (!ev_root3) CM_HIP(hipEventCreateWithFlags(&ev_root3, hipEventDisableTiming));
+      if (!ev_root3) { CM_HIP(hipEventCreateWithFlags(&ev_root3, hipEventDisableTiming)); thread_event_owned(ev_root3); }
       CM_HIP(hipEventRecord(ev_root3, st));
       std::vector<EapJob> ej;
       for (auto& j : ojobs) {

@@ -70,9 +70,11 @@ struct CommittedTree {
   DevBuf tables;  // one upload: pointer tables of coeffs / lde / the FFT groups / the Merkle column order
 };
 
+constexpr int PIPE_PRIO_DEFAULT = 0;          // commitment pipeline: priority class of the transform stream (A/B: CM_PIPE_PRIO)
 constexpr uint32_t FFT_CHUNK_MB_DEFAULT = 0;   // Infinity-Cache blocking of the transform sweeps (commit_enqueue); A/B: CM_FFT_CHUNK_MB
 inline std::atomic<int> g_transcript_log{0};     // cm_set_transcript_log: proofs record every Fiat-Shamir step (ProofData::transcript)
 inline std::atomic<int> g_proofs_in_flight{0};   // proofs being made by cm_prove_many runners right now (0 outside of it)
+inline void thread_event_owned(hipEvent_t e) { at_thread_exit([e] { (void)hipEventDestroy(e); }); }   // destroyed when the creating thread ends
 struct Prover {
   FramingUse framing_use;   // the process-wide framing cannot change while this proof is being made (framing.hpp)
   hipStream_t st = 0;
@@ -87,7 +89,15 @@ struct Prover {
   // hipStreamSynchronize per phase drained the GPU at boundaries that need no host round trip (constraints ->
   // composition commit, quotients -> FRI).  CM_HOST_TRACE=1 restores the synchronising form and prints host / wait times.
   std::vector<hipEvent_t> evs;
-  static std::vector<hipEvent_t>& event_cache() { static thread_local std::vector<hipEvent_t> c; return c; }
+  static std::vector<hipEvent_t>& event_cache() {
+    static thread_local std::vector<hipEvent_t>* c = nullptr;
+    if (!c) {
+      c = new std::vector<hipEvent_t>();
+      std::vector<hipEvent_t>* own = c;
+      at_thread_exit([own] { for (hipEvent_t e : *own) (void)hipEventDestroy(e); delete own; });
+    }
+    return *c;
+  }
   hipEvent_t next_event() {
     auto& c = event_cache();
     if (evs.size() == c.size()) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); c.push_back(e); }
@@ -252,8 +262,11 @@ struct Prover {
   }
   // the stream the transforms of a pipelined commitment run on (a side stream of the calling thread; A/B: CM_PIPE_STREAM = index)
   static hipStream_t pipe_stream() {
+    // CM_PIPE_PRIO: -1 = a stream of the highest priority class (its own hardware queue; the transforms feed the Merkle launches,
+    // so they go first), 1 = lowest class, 0 = side stream CM_PIPE_STREAM of the normal class
+    static const int prio = getenv("CM_PIPE_PRIO") ? atoi(getenv("CM_PIPE_PRIO")) : PIPE_PRIO_DEFAULT;
     static const int idx = getenv("CM_PIPE_STREAM") ? atoi(getenv("CM_PIPE_STREAM")) : 0;
-    return thread_side_stream(idx);
+    return prio ? thread_priority_stream(prio) : thread_side_stream(idx);
   }
   // events of the commitment pipeline: a ring per host thread (a wait captures the record that precedes it, so a slot may be
   // re-recorded while an earlier wait on it is still pending)
@@ -263,6 +276,8 @@ struct Prover {
     if (ring.empty()) {
       ring.resize(64);
       for (auto& e : ring) CM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      const std::vector<hipEvent_t> own = ring;
+      at_thread_exit([own] { for (hipEvent_t e : own) (void)hipEventDestroy(e); });
     }
     return ring[pos++ % ring.size()];
   }
@@ -287,7 +302,7 @@ struct Prover {
   // one event per tree slot, created once per host thread
   static hipEvent_t pace_event(int slot) {
     static thread_local hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (!ev[slot]) CM_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+    if (!ev[slot]) { CM_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming)); thread_event_owned(ev[slot]); }
     return ev[slot];
   }
 };

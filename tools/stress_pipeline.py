@@ -55,6 +55,22 @@ def main():
              "framing_slipped": 0, "streamed": 0, "churn_threads": 0}
     t_end = time.time() + 60 * a.minutes
 
+    def mem_available_gb():
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1048576.0
+        return 0.0
+
+    def rss_gb():
+        for line in open("/proc/self/status"):
+            if line.startswith("VmRSS:"):
+                return int(line.split()[1]) / 1048576.0
+        return 0.0
+    vram0 = be.mem_info()[0] / 2**30
+    stats["vram_free_gb_start"] = round(vram0, 1)
+    mem0, rss0 = mem_available_gb(), rss_gb()
+    stats["mem_available_gb_start"] = round(mem0, 1)
+
     def check(k, p):
         stats["proofs"] += 1
         if not np.array_equal(p.words(), alone[k]):
@@ -128,8 +144,18 @@ def main():
             check(k, p)
         stats["churn_threads"] += len(ts)
         stats["rounds"] += 1
+        # a leak must end the soak, not the box: the thread-churn part once lost ~35 MB of pinned memory per thread (fixed:
+        # engine.hpp at_thread_exit) and took the test box down after four minutes
+        if mem_available_gb() < mem0 - 16 or rss_gb() > rss0 + 16 or be.mem_info()[0] / 2**30 < vram0 - 64:
+            print(f"MEMORY GROWTH: MemAvailable {mem0:.1f} -> {mem_available_gb():.1f} GB, RSS {rss0:.1f} -> {rss_gb():.1f} GB, free VRAM "
+                  f"{vram0:.1f} -> {be.mem_info()[0] / 2**30:.1f} GiB: stopping", flush=True)
+            stats["mismatches"] += 1
+            break
         print(f"round {rnd}: {time.perf_counter() - t0:.2f} s, proofs so far {stats['proofs']}, mismatches {stats['mismatches']}", flush=True)
     stats["minutes"] = a.minutes
+    stats["mem_available_gb_end"] = round(mem_available_gb(), 1)
+    stats["rss_growth_gb"] = round(rss_gb() - rss0, 2)
+    stats["vram_free_gb_end"] = round(be.mem_info()[0] / 2**30, 1)
     stats["ok"] = stats["mismatches"] == 0 and stats["failures_reported"] == stats["injected_failures"]
     print(json.dumps(stats))
     if not stats["ok"]:
