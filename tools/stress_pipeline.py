@@ -128,13 +128,13 @@ def main():
         for k, p in zip(order, be.prove_many_host([inps[k] for k in order], inflight=4)):
             check(k, p)
             stats["streamed"] += 1
-        # 4. thread churn
+        # 4. thread churn (every fourth round: ~900 short-lived threads in ten minutes)
         res = {}
 
         def work(i, k):
             p = be.prove_device(devs[k])
             res[i] = (k, p)
-        ks = [int(x) for x in rng.integers(0, len(devs), size=3)]
+        ks = [int(x) for x in rng.integers(0, len(devs), size=3)] if rnd % 4 == 0 else []
         ts = [threading.Thread(target=work, args=(i, k)) for i, k in enumerate(ks)]
         for t in ts:
             t.start()
@@ -146,12 +146,14 @@ def main():
         stats["rounds"] += 1
         # a leak must end the soak, not the box: the thread-churn part once lost ~35 MB of pinned memory per thread (fixed:
         # engine.hpp at_thread_exit) and took the test box down after four minutes
-        if mem_available_gb() < mem0 - 16 or rss_gb() > rss0 + 16 or be.mem_info()[0] / 2**30 < vram0 - 64:
+        # (MemAvailable is reported, not acted on: the host is shared and it moves by tens of GB on its own)
+        if rss_gb() > rss0 + 24 or be.mem_info()[0] / 2**30 < vram0 - 160:
             print(f"MEMORY GROWTH: MemAvailable {mem0:.1f} -> {mem_available_gb():.1f} GB, RSS {rss0:.1f} -> {rss_gb():.1f} GB, free VRAM "
                   f"{vram0:.1f} -> {be.mem_info()[0] / 2**30:.1f} GiB: stopping", flush=True)
             stats["mismatches"] += 1
             break
-        print(f"round {rnd}: {time.perf_counter() - t0:.2f} s, proofs so far {stats['proofs']}, mismatches {stats['mismatches']}", flush=True)
+        print(f"round {rnd}: {time.perf_counter() - t0:.2f} s, proofs so far {stats['proofs']}, mismatches {stats['mismatches']}, free VRAM "
+              f"{be.mem_info()[0] / 2**30:.1f} GiB, RSS {rss_gb():.1f} GB", flush=True)
     stats["minutes"] = a.minutes
     stats["mem_available_gb_end"] = round(mem_available_gb(), 1)
     stats["rss_growth_gb"] = round(rss_gb() - rss0, 2)
