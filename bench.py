@@ -222,8 +222,9 @@ def main():
                     help="fibonacci_loop size the CPU oracle proves for cpu_baseline (default: the bench workload itself, ~14 s on 16 threads)")
     ap.add_argument("--cpu-single-n", type=int, default=1000,
                     help="fibonacci_loop size of the single-thread oracle run (default 1000 = BASELINE configs[0]; 0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=min(16, os.cpu_count() or 1),
-                    help="OpenMP threads of the all-thread oracle run (its loops are short: beyond a few tens of threads fork/join dominates)")
+    ap.add_argument("--cpu-threads", type=int, default=min(32, os.cpu_count() or 1),
+                    help="OpenMP threads of the multi-thread oracle run: 32 is where its thread-scaling curve peaks on the 256-CPU hosts "
+                         "of the pool (profiles/r04a_cpu_scaling.json: 16 -> 2.13e7, 32 -> 2.17e7, 64 -> 1.89e7, 256 -> 2.5e6 cells/s)")
     ap.add_argument("--alt-fib-n", type=int, default=838_000,
                     help="the alternative reading of the metric config (largest column = 2^22 rows), reported as `alt_reading`; 0 = skip")
     ap.add_argument("--alt-steps", type=int, default=3)

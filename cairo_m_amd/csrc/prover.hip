@@ -1455,6 +1455,7 @@ static int32_t prove_streamed(uint32_t n, Produce&& produce, const cm_pcs_config
           outs[job.first] = p.release();
         } catch (const cm::CmError& e) { rc = e.code ? e.code : 1; err = e.what(); }
         catch (const std::exception& e) { rc = 1; err = e.what(); }
+        catch (...) { rc = 1; err = "unknown error"; }
         std::lock_guard<std::mutex> lk(sh.mu);
         if (rc && !sh.rc) { sh.rc = rc; sh.err = err; }
         sh.spent.push_back(job.second);
@@ -1488,6 +1489,7 @@ static int32_t prove_streamed(uint32_t n, Produce&& produce, const cm_pcs_config
     try { d = produce(i); }
     catch (const cm::CmError& e) { prc = e.code ? e.code : 1; perr = e.what(); }
     catch (const std::exception& e) { prc = 1; perr = e.what(); }
+    catch (...) { prc = 1; perr = "unknown error"; }
     if (!d) break;
     std::lock_guard<std::mutex> lk(sh.mu);
     sh.ready.push_back({i, d});
@@ -1508,11 +1510,17 @@ static int32_t prove_streamed(uint32_t n, Produce&& produce, const cm_pcs_config
 }
 }  // extern "C++"
 int32_t cm_prove_many_host(const cm_prover_input* const* inputs, uint32_t n, const cm_pcs_config* config, uint32_t inflight, cm_proof** outs) {
-  return prove_streamed(n, [&](uint32_t i) { return cm::upload_input(*inputs[i], cm::thread_main_stream()); }, config, inflight, outs);
+  return prove_streamed(n, [&](uint32_t i) {
+    CM_CHECK(inputs && inputs[i], "cm_prove_many_host: null input");
+    return cm::upload_input(*inputs[i], cm::thread_main_stream());
+  }, config, inflight, outs);
 }
 int32_t cm_prove_many_segments(const cm_runner_segment* const* segments, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
                                cm_proof** outs) {
-  return prove_streamed(n, [&](uint32_t i) { return cm::adapt_segment_device(*segments[i]); }, config, inflight, outs);
+  return prove_streamed(n, [&](uint32_t i) {
+    CM_CHECK(segments && segments[i], "cm_prove_many_segments: null segment");
+    return cm::adapt_segment_device(*segments[i]);
+  }, config, inflight, outs);
 }
 // ---- per-component AIR ops (include/cairom_hip.h): the kernels of the whole-segment prover, one component
 // at a time on caller-owned columns --------------------------------------------------------------------------------
