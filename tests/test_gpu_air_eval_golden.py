@@ -3,10 +3,11 @@
 `DomainEval` / `k_constraints<C>` kernels (cm_constraints_accumulate) on a 2^4-row component, i.e. a 2^5-row evaluation domain.
 
 What is checked against WHAT: the rows of arbitrary field elements are placed on the evaluation domain as the component's
-trace columns, the interaction columns and the claimed sum are zero, relation challenges and constraint coefficients are random.
-Then every LogUp constraint (c_j - c_{j-1}) * D_j - N_j collapses to -N_j, and the kernel's accumulator must equal
+trace columns, the interaction columns are zero, relation challenges, constraint coefficients and the claimed sum are random.
+Then every LogUp constraint (c_j - c_{j-1}) * D_j - N_j collapses to -N_j — the last one, which carries the cumulative-sum shift,
+to shift * D_last - N_last — and the kernel's accumulator must equal
 
-    ( sum_k coeff_k * C_k  -  sum_j coeff_{n_base + j} * N_j ) / vanishing(row)
+    ( sum_k coeff_k * C_k  -  sum_j coeff_{n_base + j} * N_j  +  coeff_last * shift * D_last ) / vanishing(row)
 
 where C_k are the golden constraint values and N_j the numerators of the paired fractions built from the golden relation entries
 (multiplicity, tuple) — computed HERE in plain Python integers (M31 / QM31 arithmetic below), from the vectors alone.  Nothing of
@@ -90,7 +91,7 @@ def denom_inverses(log):
     return out
 
 
-def expected_row(g_row, rels_z, rels_apow, coeffs, n_base, dinv):
+def expected_row(g_row, rels_z, rels_apow, coeffs, n_base, dinv, shift=(0, 0, 0, 0)):
     total = (0, 0, 0, 0)
     cons = g_row["constraints"]
     assert len(cons) == n_base
@@ -104,13 +105,18 @@ def expected_row(g_row, rels_z, rels_apow, coeffs, n_base, dinv):
             den = qadd(den, qscale(rels_apow[r][i], v))
         ents.append((mult % P, qsub(den, rels_z[r])))
     j = 0
+    n_batches = (len(ents) + 1) // 2
     for i in range(0, len(ents), 2):
         if i + 1 < len(ents):
             (n0, d0), (n1, d1) = ents[i], ents[i + 1]
-            num = qadd(qscale(d1, n0), qscale(d0, n1))
+            num, den = qadd(qscale(d1, n0), qscale(d0, n1)), qmul(d0, d1)
         else:
-            num = qfrom(ents[i][0])
-        total = qsub(total, qmul(coeffs[n_base + j], num))
+            num, den = qfrom(ents[i][0]), ents[i][1]
+        # zero interaction columns: (c_j - c_{j-1}) * D - N = -N; the LAST batch carries the cumulative-sum shift:
+        # (cur - prev_row - prev_col + shift) * D - N = shift * D - N  — which also puts the denominator of a lone last entry
+        # (an odd number of relation entries) under test
+        term = qsub(qmul(shift, den), num) if j == n_batches - 1 else qsub((0, 0, 0, 0), num)
+        total = qadd(total, qmul(coeffs[n_base + j], term))
         j += 1
     return qscale(total, dinv), j
 
@@ -147,16 +153,18 @@ def test_hip_domain_eval_matches_reference_derived_vectors(backend, oracle, name
     coeff = rng.integers(0, P, size=4 * n_cons, dtype=np.uint32)
     coeffs = [tuple(int(x) for x in coeff[4 * k:4 * k + 4]) for k in range(n_cons)]
     dinv = denom_inverses(LOG)
+    claimed = rng.integers(1, P, size=4, dtype=np.uint32)                     # InteractionClaim: cumsum shift = claimed / 2^LOG
+    shift = qscale(tuple(int(x) for x in claimed), pow(1 << LOG, P - 2, P))
     h_tr = [backend.upload(tr[c]) for c in range(n_trace)]
     h_it = [backend.upload(np.zeros(n_eval, dtype=np.uint32)) for _ in range(n_inter)]
     h_pp = [backend.upload(np.zeros(n_eval, dtype=np.uint32)) for _ in PREPROC_LOG]    # not read by these 30 components
     h_acc = [backend.upload(np.zeros(n_eval, dtype=np.uint32)) for _ in range(4)]
     try:
-        backend.constraints_accumulate(cid, h_tr, h_it, h_pp, LOG, rel, coeff, np.zeros(4, dtype=np.uint32), h_acc)
+        backend.constraints_accumulate(cid, h_tr, h_it, h_pp, LOG, rel, coeff, claimed, h_acc)
         acc = np.stack([backend.download(h, n_eval) for h in h_acc])
         for r, k in sorted(place.items()):
             n_batches = (len(rows[k]["relations"]) + 1) // 2
-            want, j = expected_row(rows[k], rels_z, rels_apow, coeffs, n_cons - n_batches, dinv[r >> LOG])
+            want, j = expected_row(rows[k], rels_z, rels_apow, coeffs, n_cons - n_batches, dinv[r >> LOG], shift)
             assert j == n_batches and n_inter == 4 * n_batches
             assert tuple(int(x) for x in acc[:, r]) == want, (name, "evaluation-domain row", r, "golden row", k)
             # the comparison is sensitive: the same row with ONE constraint value or ONE tuple element changed does not match
@@ -165,10 +173,10 @@ def test_hip_domain_eval_matches_reference_derived_vectors(backend, oracle, name
                 bad["constraints"][-1] = (bad["constraints"][-1] + 1) % P
             else:
                 bad["relations"][0][2][0] = (bad["relations"][0][2][0] + 1) % P
-            assert expected_row(bad, rels_z, rels_apow, coeffs, n_cons - n_batches, dinv[r >> LOG])[0] != want
+            assert expected_row(bad, rels_z, rels_apow, coeffs, n_cons - n_batches, dinv[r >> LOG], shift)[0] != want
             bad = json.loads(json.dumps(rows[k]))
             bad["relations"][-1][2][-1] = (bad["relations"][-1][2][-1] + 1) % P
-            assert expected_row(bad, rels_z, rels_apow, coeffs, n_cons - n_batches, dinv[r >> LOG])[0] != want
+            assert expected_row(bad, rels_z, rels_apow, coeffs, n_cons - n_batches, dinv[r >> LOG], shift)[0] != want
         assert acc.any()
     finally:
         for h in h_tr + h_it + h_pp + h_acc:

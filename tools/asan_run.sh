@@ -2,7 +2,7 @@
 # On the GPU box: the GPU test suite (or "$@") against the host-ASAN build of the library.  Output -> gpurun_out/<tag>_asan.txt
 #   tools/asan_run.sh r04 [pytest args...]
 tag=${1:-rXX}; shift
-RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+RT=$(ls /usr/lib/x86_64-linux-gnu/libasan.so.* | head -1)   # the system runtime, NOT ROCm's libclang_rt.asan (tools/asan_build.sh)
 export CAIROM_HIP_LIB=$PWD/cairo_m_amd/libcairom_hip_asan.so
 # detect_leaks=0: CPython and the HIP runtime keep process-lifetime allocations; protect_shadow_gap=0: the ROCm runtime maps
 # fixed addresses inside ASAN's shadow gap
