@@ -1415,31 +1415,43 @@ int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm
 // to the producer, which releases it into ITS pool — the next upload reuses the same blocks, so a steady stream of equal-sized
 // segments performs no hipMalloc / hipFree.  The PCIe copies run on the SDMA engines next to the proofs' kernels.
 extern "C++" {
+// n_producers: threads that turn items into device inputs (the calling thread + n_producers - 1 library threads).  One is enough
+// for plain uploads (6 ms of PCIe per 10 ms proof); the device adapter is ~13 ms of uploads, kernels and five host round trips per
+// segment while the GPU is busy proving, so runner segments get two.  An input is released by the producer that made it (its
+// device pool owns the blocks).
 template <class Produce>
-static int32_t prove_streamed(uint32_t n, Produce&& produce, const cm_pcs_config* config, uint32_t inflight, cm_proof** outs) {
+static int32_t prove_streamed(uint32_t n, Produce&& produce, const cm_pcs_config* config, uint32_t inflight, cm_proof** outs,
+                              uint32_t n_producers = 1) {
   if (!n) return 0;
   if (inflight < 1) inflight = 1;
   if (inflight > 8) inflight = 8;
+  if (n_producers < 1) n_producers = 1;
+  if (n_producers > 3) n_producers = 3;
+  if (n_producers > n) n_producers = n;
   const cm_pcs_config cfg = config ? *config : default_cfg();
   for (uint32_t i = 0; i < n; i++) outs[i] = nullptr;
   cm::ProveWorkers& w = cm::prove_workers();
-  w.ensure(inflight);
+  w.ensure(inflight + n_producers - 1);
+  struct Job { uint32_t i; cm::DeviceInput* d; uint32_t pid; };
   struct Shared {
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::pair<uint32_t, cm::DeviceInput*>> ready;   // produced, not yet picked up
-    std::deque<cm::DeviceInput*> spent;                        // proved: the producer frees them (its pool)
-    uint32_t alive = 0, workers_done = 0;
-    bool no_more = false;
+    std::deque<Job> ready;                         // produced, not yet picked up
+    std::deque<cm::DeviceInput*> spent[3];         // proved: back to the producer that made them
+    uint32_t outstanding[3] = {0, 0, 0};           // inputs of producer p that exist (being produced, ready, being proved, spent)
+    uint32_t alive = 0, next_i = 0, workers_done = 0, producers_done = 0, n_producers = 1;
+    bool no_more = false, stop = false;
     int32_t rc = 0;
     std::string err;
   } sh;
+  sh.n_producers = n_producers;
+  const uint32_t cap = inflight + n_producers;     // device inputs alive at once
   const uint32_t runners = inflight < n ? inflight : n;
   for (uint32_t r = 0; r < runners; r++) {
     w.submit([&sh, &cfg, outs] {
       struct InFlight { InFlight() { cm::g_proofs_in_flight.fetch_add(1); } ~InFlight() { cm::g_proofs_in_flight.fetch_sub(1); } } in_flight;
       for (;;) {
-        std::pair<uint32_t, cm::DeviceInput*> job;
+        Job job;
         {
           std::unique_lock<std::mutex> lk(sh.mu);
           sh.cv.wait(lk, [&] { return !sh.ready.empty() || sh.no_more; });
@@ -1451,14 +1463,14 @@ static int32_t prove_streamed(uint32_t n, Produce&& produce, const cm_pcs_config
         std::string err;
         try {
           std::unique_ptr<cm_proof> p(new cm_proof());
-          p->d = cm::prove(*job.second, cfg);
-          outs[job.first] = p.release();
+          p->d = cm::prove(*job.d, cfg);
+          outs[job.i] = p.release();
         } catch (const cm::CmError& e) { rc = e.code ? e.code : 1; err = e.what(); }
         catch (const std::exception& e) { rc = 1; err = e.what(); }
         catch (...) { rc = 1; err = "unknown error"; }
         std::lock_guard<std::mutex> lk(sh.mu);
         if (rc && !sh.rc) { sh.rc = rc; sh.err = err; }
-        sh.spent.push_back(job.second);
+        sh.spent[job.pid].push_back(job.d);
         sh.cv.notify_all();
       }
       std::lock_guard<std::mutex> lk(sh.mu);
@@ -1466,44 +1478,66 @@ static int32_t prove_streamed(uint32_t n, Produce&& produce, const cm_pcs_config
       sh.cv.notify_all();
     });
   }
-  cm::bind_thread_to_library_device();
-  cm::AffinityScope cpu_scope;
-  auto release_spent = [&](std::unique_lock<std::mutex>& lk) {   // called with the lock held; frees outside of it
-    std::deque<cm::DeviceInput*> v;
-    v.swap(sh.spent);
-    sh.alive -= (uint32_t)v.size();
-    lk.unlock();
-    for (auto* d : v) delete d;
-    lk.lock();
-  };
-  int32_t prc = 0;
-  std::string perr;
-  for (uint32_t i = 0; i < n && !prc;) {
-    {
-      std::unique_lock<std::mutex> lk(sh.mu);
-      sh.cv.wait(lk, [&] { return sh.alive < inflight + 1 || !sh.spent.empty(); });
-      while (!sh.spent.empty()) release_spent(lk);
-      if (sh.alive >= inflight + 1) continue;
+  // one producer: takes the next index while a slot is free, makes the device input, hands it to the workers; frees what comes back
+  auto producer = [&sh, &produce, n, cap](uint32_t pid) {
+    cm::bind_thread_to_library_device();
+    auto release_spent = [&](std::unique_lock<std::mutex>& lk) {   // lock held on entry and exit; the frees run outside of it
+      std::deque<cm::DeviceInput*> v;
+      v.swap(sh.spent[pid]);
+      sh.alive -= (uint32_t)v.size();
+      sh.outstanding[pid] -= (uint32_t)v.size();
+      lk.unlock();
+      for (auto* d : v) delete d;
+      lk.lock();
+      sh.cv.notify_all();
+    };
+    for (;;) {
+      uint32_t i;
+      {
+        std::unique_lock<std::mutex> lk(sh.mu);
+        sh.cv.wait(lk, [&] { return !sh.spent[pid].empty() || sh.stop || sh.next_i >= n || sh.alive < cap; });
+        if (!sh.spent[pid].empty()) { release_spent(lk); continue; }
+        if (sh.stop || sh.next_i >= n) break;
+        if (sh.alive >= cap) continue;
+        i = sh.next_i++;
+        sh.alive++;
+        sh.outstanding[pid]++;
+      }
+      cm::DeviceInput* d = nullptr;
+      int32_t rc = 0;
+      std::string err;
+      try { d = produce(i); }
+      catch (const cm::CmError& e) { rc = e.code ? e.code : 1; err = e.what(); }
+      catch (const std::exception& e) { rc = 1; err = e.what(); }
+      catch (...) { rc = 1; err = "unknown error"; }
+      std::lock_guard<std::mutex> lk(sh.mu);
+      if (!d) {   // this item cannot be made: report it, stop producing (the items already handed over are still proved)
+        if (!sh.rc) { sh.rc = rc ? rc : 1; sh.err = err; }
+        sh.stop = true;
+        sh.alive--;
+        sh.outstanding[pid]--;
+      } else sh.ready.push_back(Job{i, d, pid});
+      sh.cv.notify_all();
     }
-    cm::DeviceInput* d = nullptr;
-    try { d = produce(i); }
-    catch (const cm::CmError& e) { prc = e.code ? e.code : 1; perr = e.what(); }
-    catch (const std::exception& e) { prc = 1; perr = e.what(); }
-    catch (...) { prc = 1; perr = "unknown error"; }
-    if (!d) break;
-    std::lock_guard<std::mutex> lk(sh.mu);
-    sh.ready.push_back({i, d});
-    sh.alive++;
+    std::unique_lock<std::mutex> lk(sh.mu);
+    if (++sh.producers_done == sh.n_producers) sh.no_more = true;
     sh.cv.notify_all();
-    i++;
+    // its inputs come back as the workers finish: release them here, on the thread whose pool owns them
+    while (sh.outstanding[pid] > 0) {
+      sh.cv.wait(lk, [&] { return !sh.spent[pid].empty(); });
+      release_spent(lk);
+    }
+  };
+  std::atomic<uint32_t> extra_done{0};
+  for (uint32_t pid = 1; pid < n_producers; pid++)
+    w.submit([&producer, &extra_done, &sh, pid] { producer(pid); extra_done.fetch_add(1); std::lock_guard<std::mutex> lk(sh.mu); sh.cv.notify_all(); });
+  {
+    cm::AffinityScope cpu_scope;
+    producer(0);
   }
   {
     std::unique_lock<std::mutex> lk(sh.mu);
-    sh.no_more = true;
-    sh.cv.notify_all();
-    sh.cv.wait(lk, [&] { return sh.workers_done == runners; });
-    while (!sh.spent.empty()) release_spent(lk);
-    if (prc && !sh.rc) { sh.rc = prc; sh.err = perr; }
+    sh.cv.wait(lk, [&] { return sh.workers_done == runners && extra_done.load() == n_producers - 1; });
   }
   if (sh.rc) { cm_set_last_error(sh.err.c_str()); return sh.rc; }
   return 0;
@@ -1520,7 +1554,7 @@ int32_t cm_prove_many_segments(const cm_runner_segment* const* segments, uint32_
   return prove_streamed(n, [&](uint32_t i) {
     CM_CHECK(segments && segments[i], "cm_prove_many_segments: null segment");
     return cm::adapt_segment_device(*segments[i]);
-  }, config, inflight, outs);
+  }, config, inflight, outs, /*n_producers=*/2);
 }
 // ---- per-component AIR ops (include/cairom_hip.h): the kernels of the whole-segment prover, one component
 // at a time on caller-owned columns --------------------------------------------------------------------------------

@@ -326,7 +326,8 @@ int32_t cm_prove_many(const cm_device_input* const* inputs, uint32_t n, const cm
  * `&mut ProverInput` (crates/prover/src/prover.rs:23-29).  The calling thread uploads input i + 1 (cm_prove_many_host) or runs
  * the device adapter on runner segment i + 1 (cm_prove_many_segments = import_from_runner_output, adapter/mod.rs:97-193) on
  * its own stream while up to `inflight` (1..8) library threads prove the inputs before it: the PCIe copies hide under the
- * proofs.  At most inflight + 1 inputs are resident in HBM at any time.  outs[i] = proof of item i (bit-identical to
+ * proofs.  At most inflight + 1 inputs are resident in HBM at any time (inflight + 2 for cm_prove_many_segments, whose adapter —
+ * uploads, sorts and five host round trips per segment — runs on a second library thread as well).  outs[i] = proof of item i (bit-identical to
  * cm_prove_segment / cm_adapt_segment_device + cm_prove_device of the same item); error contract of cm_prove_many. */
 int32_t cm_prove_many_host(const cm_prover_input* const* inputs, uint32_t n, const cm_pcs_config* config, uint32_t inflight,
                            cm_proof** outs);

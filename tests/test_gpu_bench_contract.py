@@ -36,6 +36,15 @@ def test_single_gpu_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
     assert d["parity_at_metric_config"] is True and d["proof_verified"] is True       # sample == bench workload here
     assert d["end_to_end"]["host_prover_input_ms"]["min"] > d["ms_per_step"] * 0.5
+    # round 4: per-stage roofline against SURVEY 8d's bytes-per-cell table, the measurement set the traffic figure comes from, and
+    # the streaming-ingest legs next to the resident pipeline
+    st = {x["stage"]: x for x in r["stages"]}
+    assert {"IFFT + LDE", "Merkle hashing", "constraint quotients", "DEEP quotients"} <= set(st)
+    assert abs(sum(x["bytes_per_cell"] for x in r["stages"]) - 52.0) < 1e-9 and all(0 < x["frac"] < 1 for x in r["stages"])
+    latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().split()[0]
+    assert r["traffic_source"] is None or os.path.basename(r["traffic_source"]).startswith(latest + "_")
+    e = d["end_to_end"]
+    assert e["pipelined_from_host_ms_per_proof"] > 0 and e["pipelined_from_segments_ms_per_proof"] > 0 and e["streamed_vs_resident"] > 0.5
 
 
 def test_gpus_2_self_spawns_and_reports_both_modes():
