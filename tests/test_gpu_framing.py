@@ -92,32 +92,38 @@ def test_transcript_shape_follows_prove_cairo_m(backend, oracle):
 def test_framing_cannot_change_under_a_running_proof(backend):
     """One proof = one framing: the trees, the transcript and the quotient planning of a proof read the process-wide setting at
     their own points, so cm_set_framing is refused (status 1, setting unchanged) while a prover is alive and accepted again
-    afterwards; the proofs made meanwhile verify under the setting they started with."""
-    import ctypes as C
+    afterwards.  While six proofs run on the library's threads this thread keeps asking for the ALTERNATE node hashing: every
+    request that arrives while a prover is alive must be refused; one that slips in between two proofs is undone at once (and the
+    refusals of the undo count as well); afterwards the default is in force and a change is accepted."""
     import threading
     inp = synth_fibonacci(100_000)
     dev = backend.upload_input(inp)
-    proofs = []
-    t = threading.Thread(target=lambda: proofs.extend(backend.prove_many([dev] * 6, inflight=2)))
+    proofs, errors = [], []
+
+    def work():
+        try:
+            proofs.extend(backend.prove_many([dev] * 6, inflight=2))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    t = threading.Thread(target=work)
     refused = accepted = 0
     try:
-        backend.prove_device(dev).free()          # warm pools: the timed part below is steady-state proving (~6 ms per proof)
+        backend.prove_device(dev).free()          # warm pools: the part below is steady-state proving (~6 ms per proof)
         t.start()
         while t.is_alive():
-            rc = backend.L.cm_set_framing(b"hash_node=rfc")
-            if rc != 0:
+            if backend.L.cm_set_framing(b"hash_node=rfc") != 0:
                 refused += 1
-            else:                                # slipped in between two proofs: put the default back at once
-                accepted += 1
-                while backend.L.cm_set_framing(b"") != 0 and t.is_alive():
-                    pass
+                assert "hash_node=raw" in get_framing(backend.L)      # a refused request changes nothing
+                continue
+            accepted += 1                           # slipped in while no prover was alive: put the default back
+            while backend.L.cm_set_framing(b"") != 0:
+                refused += 1                        # (a proof started under the alternate framing and holds it until it is done)
         t.join()
+        assert not errors, errors
         assert refused > 0, (refused, accepted)
         assert backend.L.cm_set_framing(b"") == 0 and "hash_node=raw" in get_framing(backend.L)
+        assert backend.L.cm_set_framing(b"hash_node=rfc") == 0 and "hash_node=rfc" in get_framing(backend.L)   # idle: accepted
         assert len(proofs) == 6
-        if accepted == 0:                        # no proof can have been made under the alternate framing
-            for p in proofs:
-                assert p.verify()[0] == 0
     finally:
         if t.is_alive():
             t.join()
