@@ -56,6 +56,7 @@ struct LogupTailJob {
 };
 void logup_finalize_all(const std::vector<LogupTailJob>& jobs, uint32_t* d_sums, hipStream_t st);
 void launch_preproc(int pp_id, uint32_t log_size, uint32_t* d_col, hipStream_t st);
+void launch_preproc_all(uint32_t* const cols[], hipStream_t st);   // every preprocessed column (PREPROC_LOG sizes) in one launch
 // d_acc[c][i] += sum_s slots[((s * 4 + c) << log_n) + i]   (c < 4, s < n_slots)
 void sum_slots(uint32_t* const* d_acc, const uint32_t* d_slots, uint32_t n_slots, uint32_t log_n, hipStream_t st);
 void add_columns(uint32_t* const* d_dst, const uint32_t* const* d_src, uint32_t ncols, uint32_t n, hipStream_t st);

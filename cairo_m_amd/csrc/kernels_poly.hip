@@ -76,6 +76,8 @@ __global__ void __launch_bounds__(256) k_twiddles_x(uint32_t* __restrict__ xtw, 
   }
   batch_inverse8(v, iv, n);
   for (uint32_t k = 0; k < n; k++) { const uint32_t t = t0 + k * nthreads; xtw[t] = v[k].v << 1; ixtw[t] = iv[k].v << 1; }   // tables hold 2w (mul_tw2)
+  if (t0 == 0) { xtw[total] = 0; ixtw[total] = 0; }   // the unused last entry (was a hipMemsetAsync each: four API calls at the very
+                                                       // start of a proof, where the host's launch rate is the bound)
 }
 __global__ void __launch_bounds__(256) k_twiddles_y(uint32_t* __restrict__ ytw, uint32_t* __restrict__ iytw, uint32_t R, const uint32_t* __restrict__ tab) {
   const uint32_t nthreads = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,6 +95,7 @@ __global__ void __launch_bounds__(256) k_twiddles_y(uint32_t* __restrict__ ytw, 
   }
   batch_inverse8(v, iv, n);
   for (uint32_t k = 0; k < n; k++) { const uint32_t t = 1 + t0 + k * nthreads; ytw[t] = v[k].v << 1; iytw[t] = iv[k].v << 1; }
+  if (t0 == 0) { ytw[0] = 0; iytw[0] = 0; }   // the unused first entry
 }
 
 // ---------------------------------------------------------------- butterfly passes
@@ -417,10 +420,6 @@ void twiddles_build(const Twiddles& t, hipStream_t st) {
   CM_CHECK(R >= 2 && R <= 28, "twiddles: log size out of range (columns are limited to 2^26 rows)");
   CM_CHECK(t.scratch, "twiddles: no scratch buffer");
   size_t nx = (size_t)1 << (R - 1), ny = (size_t)1 << R;
-  CM_HIP(hipMemsetAsync(t.ytw, 0, 4, st));
-  CM_HIP(hipMemsetAsync(t.iytw, 0, 4, st));
-  CM_HIP(hipMemsetAsync(t.xtw + (nx - 1), 0, 4, st));
-  CM_HIP(hipMemsetAsync(t.ixtw + (nx - 1), 0, 4, st));
   const uint32_t n_tab = (uint32_t)(twiddles_scratch_words(R) / 2);
   hipLaunchKernelGGL(k_twiddle_point_tables, dim3((n_tab + 255) / 256), dim3(256), 0, st, R, t.scratch);
   auto blocks = [](size_t n) { return dim3((uint32_t)((n + 256 * TW_BATCH - 1) / (256 * TW_BATCH))); };

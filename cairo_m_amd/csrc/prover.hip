@@ -472,7 +472,7 @@ struct SegmentProver {
         if (!tw_fork) tw_fork.reset(new Fork(st));   // (twiddle cache on: nothing else is on that stream yet)
         pps = tw_fork->stream(Fork::N - 1);
       }
-      for (int i = 0; i < air::N_PREPROC; i++) launch_preproc(i, logs[i], pp_evals.ptrs[i], pps);
+      launch_preproc_all(pp_evals.ptrs.data(), pps);
       build_tree0 = true;   // enqueued on a side stream right after the trace-generation launches (below)
     }
     ht.mark("preprocessed enqueued");
