@@ -128,6 +128,41 @@ pub fn prove_cairo_m_hip(input: &mut ProverInput, pcs_config: Option<PcsConfig>)
 /// `verify_cairo_m::<Blake2sMerkleChannel>` stays the reference's own function: the value returned above is an ordinary
 /// `Proof<Blake2sMerkleHasher>`.  This helper is the library-side verifier (host code, no GPU) for callers that want the
 /// check without Stwo: same acceptance conditions, error mapped onto the reference's enum.
+/// Streaming form for a service that proves the continuation segments of a run (crates/runner/src/vm/mod.rs:184-240 cuts them,
+/// crates/prover/tests/prover.rs:203-243 proves them one by one): `cm_prove_many_host` uploads segment k + 1 on the calling
+/// thread while up to `inflight` library threads prove the segments before it, so the 6 ms PCIe copy of a 2^22-step segment hides
+/// under the 10 ms proof of its predecessor.  Proofs come back in input order; the first failing segment is reported
+/// (`ConstraintsNotSatisfied` for status 10) after the others have been proved.
+pub fn prove_segments_hip(
+    inputs: &mut [ProverInput],
+    pcs_config: Option<PcsConfig>,
+    inflight: u32,
+) -> Result<Vec<Proof<Blake2sMerkleHasher>>, ProvingError> {
+    ensure_init();
+    let cfg = pcs(&pcs_config.unwrap_or(REGULAR_96_BITS));
+    let flats: Vec<Flat> = inputs.iter_mut().map(|i| Flat::new(i, MemoryOrder::AscendingAddress)).collect();
+    let views: Vec<_> = flats.iter().map(|f| f.view()).collect();
+    let ptrs: Vec<*const cm_prover_input> = views.iter().map(|v| v as *const cm_prover_input).collect();
+    let mut outs: Vec<*mut cm_proof> = vec![std::ptr::null_mut(); inputs.len()];
+    let rc = unsafe { cm_prove_many_host(ptrs.as_ptr(), ptrs.len() as u32, &cfg, inflight, outs.as_mut_ptr()) };
+    let handles: Vec<ProofHandle> = outs.into_iter().filter(|p| !p.is_null()).map(ProofHandle).collect();   // freed on drop
+    match rc {
+        0 => {}
+        10 => return Err(ProvingError::Stwo(StwoProvingError::ConstraintsNotSatisfied)),
+        _ => panic!("libcairom_hip: status {rc}: {}", last_error()),
+    }
+    handles
+        .iter()
+        .map(|h| {
+            let (mut ptr, mut len) = (std::ptr::null(), 0usize);
+            let rc = unsafe { cm_proof_json(h.0, &mut ptr, &mut len) };
+            assert!(rc == 0, "cm_proof_json: {}", last_error());
+            let json = unsafe { std::slice::from_raw_parts(ptr as *const u8, len) };
+            Ok(sonic_rs::from_slice(json).expect("libcairom_hip returned a malformed Proof JSON"))
+        })
+        .collect()
+}
+
 pub fn verify_words_hip(proof: &ProofHandleRef, pcs_config: Option<PcsConfig>) -> Result<(), VerificationError> {
     let cfg = pcs(&pcs_config.unwrap_or(REGULAR_96_BITS));
     let rc = unsafe { cm_verify_proof(proof.0, &cfg) };
