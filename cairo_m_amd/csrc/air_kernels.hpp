@@ -54,7 +54,7 @@ struct LogupTailJob {
   uint32_t tmp_off, btot_off;  // filled by logup_finalize_all
   uint32_t id, pad;            // index of the job in the caller's list (claimed sums / shifts)
 };
-void logup_finalize_all(const std::vector<LogupTailJob>& jobs, uint32_t* d_sums, hipStream_t st);
+void logup_finalize_all(const std::vector<LogupTailJob>& jobs, uint32_t* d_sums, hipStream_t st, std::vector<DevBuf>* keep = nullptr);
 void launch_preproc(int pp_id, uint32_t log_size, uint32_t* d_col, hipStream_t st);
 void launch_preproc_all(uint32_t* const cols[], hipStream_t st);   // every preprocessed column (PREPROC_LOG sizes) in one launch
 // d_acc[c][i] += sum_s slots[((s * 4 + c) << log_n) + i]   (c < 4, s < n_slots)

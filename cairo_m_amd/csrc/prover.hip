@@ -599,6 +599,12 @@ struct SegmentProver {
     // ---- tree 2: interaction trace (prover.rs:96-102) ----
     hipEvent_t sums_ready = nullptr;
     ColumnSet it_evals;
+    // The LogUp tail (claimed sums, the running-sum columns' prefix scans: ~0.15 ms of short memory-bound kernels) runs on a side
+    // stream while the tree-2 transforms of every OTHER column start; the running-sum columns go last in their size group.
+    // CM_LOGUP_DEFER=0: the tail on the main stream in front of the tree (the round-3 order).
+    static const bool defer_tail = !(getenv("CM_LOGUP_DEFER") && atoi(getenv("CM_LOGUP_DEFER")) == 0);
+    std::vector<DevBuf> tail_scratch;   // alive until the host has seen the sums
+    Prover::DeferredCols late;
     {
       std::vector<uint32_t> logs;
       for (int c = 0; c < air::N_COMPONENTS; c++) {
@@ -608,7 +614,8 @@ struct SegmentProver {
       it_evals.alloc(logs, st);
     }
     {
-      DevBuf d_sums(air::N_COMPONENTS * 16);
+      tail_scratch.emplace_back(air::N_COMPONENTS * 16);
+      uint32_t* const d_sums = tail_scratch.back().u32();
       std::vector<LogupTailJob> jobs(air::N_COMPONENTS);
       // small components (idle opcode components = 16 padding rows, the tiny builtins): ONE launch for all of them
       std::vector<SmallLogupJob> small_jobs;
@@ -636,16 +643,27 @@ struct SegmentProver {
       }
       fk.join();
       kreg.close();
-      logup_finalize_all(jobs, d_sums.u32(), st);
+      hipStream_t sf = st;
+      if (defer_tail) {
+        sf = thread_side_stream(1);   // (side stream 0 is the pipeline's transform stream)
+        hipEvent_t e = Prover::pipe_event();
+        CM_HIP(hipEventRecord(e, st));
+        CM_HIP(hipStreamWaitEvent(sf, e, 0));
+        late.late.assign(it_evals.ptrs.size(), 0);
+        for (int c = 0; c < air::N_COMPONENTS; c++)
+          for (int k = 0; k < 4; k++) late.late[it0[c] + air::component_info(c).n_interaction - 4 + k] = 1;
+      }
+      logup_finalize_all(jobs, d_sums, sf, defer_tail ? &tail_scratch : nullptr);
       static_assert(PIN_SUMS + air::N_COMPONENTS * 4 <= PIN_COEFF, "pinned slot layout");
       const uint32_t* sums = pinned_words() + PIN_SUMS;
-      CM_HIP(hipMemcpyAsync((void*)sums, d_sums.p, air::N_COMPONENTS * 16, hipMemcpyDeviceToHost, st));
+      CM_HIP(hipMemcpyAsync((void*)sums, d_sums, air::N_COMPONENTS * 16, hipMemcpyDeviceToHost, sf));
       // the host only waits for THIS copy (an event), after the tree-2 transforms and hashes have been enqueued behind it:
       // no GPU idle time while the host reads and mixes the 34 sums
       static thread_local hipEvent_t ev_sums = nullptr;
       if (!ev_sums) { CM_HIP(hipEventCreateWithFlags(&ev_sums, hipEventDisableTiming)); thread_event_owned(ev_sums); }
-      CM_HIP(hipEventRecord(ev_sums, st));
+      CM_HIP(hipEventRecord(ev_sums, sf));
       sums_ready = ev_sums;
+      late.ready = ev_sums;
     }
     P.tick("interaction_gen");
     // interpolate in place: coeffs alias the evaluation buffer (every size group right in front of its extension)
@@ -653,10 +671,11 @@ struct SegmentProver {
       CommittedTree& t = P.trees[2];
       t.coeffs = std::move(it_evals);
       t.merkle.pace_ev = Prover::pace_event(2);
-      P.commit_enqueue(t, nullptr, true, st, true, /*evals_in_place=*/true, P.pipe_stream());
+      P.commit_enqueue(t, nullptr, true, st, true, /*evals_in_place=*/true, P.pipe_stream(), defer_tail ? &late : nullptr);
     }
     {
       CM_HIP(hipEventSynchronize(sums_ready));
+      tail_scratch.clear();
       // host replay of the device-side step behind tree 1 (its results were copied back in front of the sums)
       {
         const uint32_t* s1 = pinned_words() + PIN_STEP1;

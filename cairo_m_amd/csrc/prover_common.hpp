@@ -149,8 +149,11 @@ struct Prover {
   // issue, the transform passes wait on HBM / LDS for ~40 % of their cycles (profiles/r03h_pmc_sq.json) — back to back on one queue
   // they never met.  `s_tr` must already be ordered behind everything the transforms read (a Fork side stream of `s`); when this
   // returns `s` is ordered behind all of `s_tr`'s work.  null = everything on `s` (CM_COMMIT_PIPE=0 forces that form: A/B).
+  // Columns whose evaluations are still being finished on another stream when the tree is enqueued (tree 2: the four running-sum
+  // columns of every component while the LogUp tail runs): transformed last within their size group, behind `ready`.
+  struct DeferredCols { std::vector<char> late; hipEvent_t ready = nullptr; };
   void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true,
-                      bool evals_in_place = false, hipStream_t s_tr = nullptr) {
+                      bool evals_in_place = false, hipStream_t s_tr = nullptr, const DeferredCols* defer = nullptr) {
     static const bool pipe_on = !(getenv("CM_COMMIT_PIPE") && atoi(getenv("CM_COMMIT_PIPE")) == 0);
     if (!pipe_on || !with_merkle || s_tr == s) s_tr = nullptr;
     const std::vector<uint32_t> logs = from_coeffs ? t.coeffs.logs : evals->logs;
@@ -167,11 +170,14 @@ struct Prover {
     t.lde.alloc(lde_logs, s, false);
     ub.add(t.lde.ptrs, &t.lde.d_view);
     // pointer table of all size groups of the tree: [src | coeffs | lde] per group
-    struct Grp { uint32_t log, n; size_t off; };
+    struct Grp { uint32_t log, n; size_t off; uint32_t n_early; };
     std::vector<Grp> grps;
     std::vector<const uint32_t*> table;
     for (auto& kv : by_log(logs)) {
-      Grp g{kv.first, (uint32_t)kv.second.size(), table.size()};
+      Grp g{kv.first, (uint32_t)kv.second.size(), table.size(), (uint32_t)kv.second.size()};
+      if (defer)
+        g.n_early = (uint32_t)(std::stable_partition(kv.second.begin(), kv.second.end(), [&](size_t i) { return !defer->late[i]; }) -
+                               kv.second.begin());
       for (auto i : kv.second) table.push_back(from_coeffs ? nullptr : evals->ptrs[i]);
       for (auto i : kv.second) table.push_back(t.coeffs.ptrs[i]);
       for (auto i : kv.second) table.push_back(t.lde.ptrs[i]);
@@ -220,7 +226,18 @@ struct Prover {
         t.merkle.run_launch(plan[next_launch++], s);
       }
     };
-    small_commit(d_sjobs, (uint32_t)sjobs.size(), small_max, cfg.log_blowup_factor, *tw, ts);
+    // the small columns (and the late ones of every group) need `defer->ready`: not in front of the first large group's early
+    // columns, which is the work that hides the wait
+    bool small_done = false;
+    uint64_t total_cells = 0, early_cells = 0;
+    for (auto l : logs) total_cells += (uint64_t)1 << l;
+    auto late_ready = [&]() {
+      if (small_done) return;
+      small_done = true;
+      if (defer) CM_HIP(hipStreamWaitEvent(ts, defer->ready, 0));
+      small_commit(d_sjobs, (uint32_t)sjobs.size(), small_max, cfg.log_blowup_factor, *tw, ts);
+    };
+    if (!defer) late_ready();
     for (size_t gi = 0; gi < grps.size(); gi++) {
       const Grp& g = grps[gi];
       if (small_commit_serves(g.log, cfg.log_blowup_factor)) continue;
@@ -238,8 +255,14 @@ struct Prover {
         per = (uint32_t)std::max<uint64_t>(1, ((uint64_t)chunk_mb << 20) / col_bytes);
         if (per >= g.n || (g.log < 16)) per = g.n;
       }
-      for (uint32_t c0 = 0; c0 < g.n; c0 += per) {
-        const uint32_t nc = std::min(per, g.n - c0);
+      // (groups are split only until a fifth of the tree's cells is in the stream in front of the wait — about the length of
+      // the LogUp tail; later groups go through whole: a launch of four columns fills the chip badly)
+      if (defer && !small_done && early_cells * 5 >= total_cells) late_ready();
+      const uint32_t n_early = small_done ? g.n : g.n_early;
+      early_cells += (uint64_t)n_early << g.log;
+      for (uint32_t c0 = 0, nc = 0; c0 < g.n; c0 += nc) {
+        if (c0 >= n_early) late_ready();
+        nc = std::min(per, (c0 < n_early ? n_early : g.n) - c0);
         if (cfg.log_blowup_factor == 1 && (!from_coeffs || evals_in_place)) {
           // interpolate + extend by two: the inverse transform's last pass and the forward one's first are one sweep (engine.hpp)
           interpolate_extend(from_coeffs ? (const uint32_t* const*)dco + c0 : dsrc + c0, dco + c0, dld + c0, nc, g.log, *tw, ts);
@@ -249,12 +272,14 @@ struct Prover {
         else if (evals_in_place) interpolate(dco + c0, nc, g.log, *tw, ts);
         evaluate((const uint32_t* const*)dco + c0, dld + c0, nc, g.log, g.log + cfg.log_blowup_factor, *tw, ts);
       }
+      late_ready();
       // what can be hashed now: every layer above the next (smaller) group that is still to be transformed
       int next_log = -1;
       for (size_t gj = gi + 1; gj < grps.size(); gj++)
         if (!small_commit_serves(grps[gj].log, cfg.log_blowup_factor)) { next_log = (int)(grps[gj].log + cfg.log_blowup_factor); break; }
       hash_ready(next_log + 1);
     }
+    late_ready();
     if (with_merkle) {
       if (s_tr) hash_ready(0);   // (a tree of small columns only: nothing was hashed inside the loop)
       else t.merkle.commit_prepared(s);
