@@ -30,87 +30,98 @@ namespace {
 
 struct OpTable { uint8_t size[64], acc[64], comp[64], valid[64]; };
 
+// per step: info = component << 14 | opcode << 8 | entries << 4 | operand accesses (bits 8..18 are the step sort's key: inside a
+// component the reference concatenates the bundles of its opcode variants in the order of `define_opcodes!`
+// (components/opcodes/mod.rs:51-58, 223-268), which is ascending opcode id for every group); cnt = entries | accesses << 32,
+// scanned in place into the step's offsets in the memory log and in the data-access array
+constexpr uint32_t INFO_KEY_LO = 8, INFO_KEY_HI = 19;
+__device__ __forceinline__ uint32_t info_comp(uint32_t info) { return info >> 14; }
+__device__ __forceinline__ uint32_t info_ne(uint32_t info) { return (info >> 4) & 15u; }
+__device__ __forceinline__ uint32_t info_na(uint32_t info) { return info & 15u; }
 __global__ void k_step_counts(const uint32_t* __restrict__ trace, uint32_t n_steps, const uint32_t* __restrict__ init_mem,
-                              uint32_t n_init, OpTable tab, uint32_t* __restrict__ n_entries, uint32_t* __restrict__ n_acc,
-                              uint32_t* __restrict__ comp, uint32_t* __restrict__ err) {
+                              uint32_t n_init, OpTable tab, uint32_t* __restrict__ info, unsigned long long* __restrict__ cnt,
+                              uint32_t* __restrict__ err) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_steps) return;
   uint32_t pc = trace[2 * t];
   uint32_t op = pc < n_init ? init_mem[4 * (size_t)pc] : 64u;
-  if (op >= 64u || !tab.valid[op]) { atomicOr(err, 1u); n_entries[t] = 0; n_acc[t] = 0; comp[t] = 0; return; }
-  n_entries[t] = 1u + (tab.size[op] > 4 ? 1u : 0u) + tab.acc[op];
-  n_acc[t] = tab.acc[op];
-  // sort key: component, then opcode — inside a component the reference concatenates the bundles of its opcode variants in
-  // the order of `define_opcodes!` (components/opcodes/mod.rs:51-58, 223-268), which is ascending opcode id for every group
-  comp[t] = ((uint32_t)tab.comp[op] << 6) | op;
+  if (op >= 64u || !tab.valid[op]) { atomicOr(err, 1u); info[t] = 0; cnt[t] = 0; return; }
+  const uint32_t na = tab.acc[op], ne = 1u + (tab.size[op] > 4 ? 1u : 0u) + na;
+  info[t] = ((uint32_t)tab.comp[op] << 14) | (op << 8) | (ne << 4) | na;
+  cnt[t] = (unsigned long long)ne | ((unsigned long long)na << 32);
 }
-// keys[e] = (address << 32) | e ; clock of entry e = step + 1
-__global__ void k_entry_keys(const uint32_t* __restrict__ trace, uint32_t n_steps, const uint32_t* __restrict__ entry_off,
-                             const uint32_t* __restrict__ n_entries, const uint32_t* __restrict__ mem /*5 words each*/,
-                             uint32_t n_mem, unsigned long long* __restrict__ keys, uint32_t* __restrict__ entry_clock,
-                             uint32_t* __restrict__ err) {
+// per log entry e: its address (the sort key), its own index (the sort payload) and its clock = step + 1; the largest address
+// bounds the sort's bit range
+__global__ void k_entry_keys(const uint32_t* __restrict__ trace, uint32_t n_steps, const unsigned long long* __restrict__ off,
+                             const uint32_t* __restrict__ info, const uint32_t* __restrict__ mem /*5 words each*/, uint32_t n_mem,
+                             uint32_t* __restrict__ addr_key, uint32_t* __restrict__ entry_id, uint32_t* __restrict__ entry_clock,
+                             uint32_t* __restrict__ err /*[0] flags, [1] largest address*/) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_steps) return;
-  uint32_t e0 = entry_off[t], n = n_entries[t];
-  if (e0 + n > n_mem) { atomicOr(err, 2u); return; }
-  if (n && mem[5 * (size_t)e0] != trace[2 * t]) atomicOr(err, 4u);  // first entry of a step is the fetch at pc
-  for (uint32_t k = 0; k < n; k++) {
-    uint32_t e = e0 + k;
-    keys[e] = ((unsigned long long)mem[5 * (size_t)e] << 32) | e;
-    entry_clock[e] = t + 1;
+  uint32_t amax = 0;
+  if (t < n_steps) {
+    uint32_t e0 = (uint32_t)off[t], n = info_ne(info[t]);
+    if (e0 + n > n_mem) { atomicOr(err, 2u); n = 0; }
+    if (n && mem[5 * (size_t)e0] != trace[2 * t]) atomicOr(err, 4u);  // first entry of a step is the fetch at pc
+    for (uint32_t k = 0; k < n; k++) {
+      uint32_t e = e0 + k, a = mem[5 * (size_t)e];
+      addr_key[e] = a;
+      entry_id[e] = e;
+      entry_clock[e] = t + 1;
+      amax = a > amax ? a : amax;
+    }
   }
+  for (int d = 32; d; d >>= 1) { uint32_t o = __shfl_xor(amax, d); amax = o > amax ? o : amax; }
+  // (one address: only waves that would raise it go to the atomic unit — 65 K same-address atomics took 0.6 ms)
+  if ((threadIdx.x & 63u) == 0 && amax > __atomic_load_n(err + 1, __ATOMIC_RELAXED)) atomicMax(err + 1, amax);
 }
-// sorted position i -> previous access of the same cell
-__global__ void k_prev_links(const unsigned long long* __restrict__ sorted, uint32_t n_mem, const uint32_t* __restrict__ mem,
-                             const uint32_t* __restrict__ entry_clock, const uint32_t* __restrict__ init_mem, uint32_t n_init,
-                             uint32_t* __restrict__ prev_clock /*adjusted*/, uint32_t* __restrict__ prev_val0,
-                             uint32_t* __restrict__ cu_count, uint32_t* __restrict__ cu_prev /*unadjusted prev clock*/,
-                             uint32_t* __restrict__ head_flag) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_mem) return;
-  unsigned long long k = sorted[i];
-  uint32_t addr = (uint32_t)(k >> 32), e = (uint32_t)k;
-  bool head = i == 0 || (uint32_t)(sorted[i - 1] >> 32) != addr;
+// sorted position i (by address; entries of one cell stay in log order: the sort is stable) -> previous access of the same cell.
+// link[e] = (previous clock, adjusted by the clock-update rows in between; word 0 of the previous value).  Entries further than
+// RC20_LIMIT clocks from their predecessor are rare: only they write cu_count[e] (zeroed by the caller) and their position.
+__global__ void k_prev_links(const uint32_t* __restrict__ sorted_addr, const uint32_t* __restrict__ sorted_e, uint32_t n_mem,
+                             const uint32_t* __restrict__ mem, const uint32_t* __restrict__ entry_clock,
+                             const uint32_t* __restrict__ init_mem, uint32_t n_init, uint2* __restrict__ link,
+                             uint32_t* __restrict__ cu_count, uint32_t* __restrict__ cu_pos, uint32_t* __restrict__ head_flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+  const bool live = i < n_mem;
+  const uint32_t addr = live ? sorted_addr[i] : 0u, e = live ? sorted_e[i] : 0u;
+  // this entry's own clock and value word (two reads at a log-ordered index); the next position takes them from here
+  const uint32_t clk = live ? entry_clock[e] : 0u, v0 = live ? mem[5 * (size_t)e + 1] : 0u;
+  uint32_t paddr = __shfl_up(addr, 1), pclk = __shfl_up(clk, 1), pv0 = __shfl_up(v0, 1);
+  if (lane == 0 && live && i > 0) {
+    const uint32_t pe = sorted_e[i - 1];
+    paddr = sorted_addr[i - 1]; pclk = entry_clock[pe]; pv0 = mem[5 * (size_t)pe + 1];
+  }
+  if (!live) return;
+  const bool head = i == 0 || paddr != addr;
   head_flag[i] = head ? 1u : 0u;
-  uint32_t pclk, pv0;
   if (head) {
     pclk = 0;
-    pv0 = addr < n_init ? init_mem[4 * (size_t)addr] : mem[5 * (size_t)e + 1];
-  } else {
-    uint32_t pe = (uint32_t)sorted[i - 1];
-    pclk = entry_clock[pe];
-    pv0 = mem[5 * (size_t)pe + 1];
+    pv0 = addr < n_init ? init_mem[4 * (size_t)addr] : v0;
   }
-  uint32_t clk = entry_clock[e];
-  uint32_t delta = clk - pclk;
-  uint32_t steps = delta > air::RC20_LIMIT ? delta / air::RC20_LIMIT : 0u;
-  cu_count[e] = steps;
-  cu_prev[e] = pclk;
-  prev_clock[e] = pclk + steps * air::RC20_LIMIT;
-  prev_val0[e] = pv0;
+  const uint32_t delta = clk - pclk;
+  const uint32_t steps = delta > air::RC20_LIMIT ? delta / air::RC20_LIMIT : 0u;
+  if (steps) { cu_count[e] = steps; cu_pos[e] = i; }
+  link[e] = make_uint2(pclk + steps * air::RC20_LIMIT, pv0);
 }
-// run heads broadcast their sorted position (inclusive max-scan of head ? i : 0 done by hipCUB): the "initial value"
-// of a cell outside the initial memory is the value of its first access
-__global__ void k_head_pos(const uint32_t* __restrict__ head_flag, uint32_t n, uint32_t* __restrict__ pos) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) pos[i] = head_flag[i] ? i : 0u;
-}
-__global__ void k_entry_head(const unsigned long long* __restrict__ sorted, const uint32_t* __restrict__ head_pos, uint32_t n,
-                             uint32_t* __restrict__ head_entry) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) head_entry[(uint32_t)sorted[i]] = (uint32_t)sorted[head_pos[i]];
-}
+// clock-update rows in log order (cu_off = exclusive scan of cu_count).  The value of a cell outside the initial memory is the
+// value of its FIRST access: the head of its run in the sorted order, found by bisection from the entry's own position.
 __global__ void k_clock_updates(const uint32_t* __restrict__ mem, uint32_t n_mem, const uint32_t* __restrict__ cu_count,
-                                const uint32_t* __restrict__ cu_off, const uint32_t* __restrict__ cu_prev,
-                                const uint32_t* __restrict__ head_entry, const uint32_t* __restrict__ init_mem, uint32_t n_init,
-                                cm_clock_update* __restrict__ out) {
+                                const uint32_t* __restrict__ cu_off, const uint32_t* __restrict__ cu_pos, const uint2* __restrict__ link,
+                                const uint32_t* __restrict__ sorted_addr, const uint32_t* __restrict__ sorted_e,
+                                const uint32_t* __restrict__ init_mem, uint32_t n_init, cm_clock_update* __restrict__ out) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_mem) return;
   uint32_t n = cu_count[e];
   if (!n) return;
   uint32_t addr = mem[5 * (size_t)e];
-  const uint32_t* iv = addr < n_init ? init_mem + 4 * (size_t)addr : mem + 5 * (size_t)head_entry[e] + 1;
-  uint32_t pclk = cu_prev[e];
+  const uint32_t* iv;
+  if (addr < n_init) iv = init_mem + 4 * (size_t)addr;
+  else {
+    uint32_t lo = 0, hi = cu_pos[e];          // first position whose address is `addr`
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (sorted_addr[mid] < addr) lo = mid + 1; else hi = mid; }
+    iv = mem + 5 * (size_t)sorted_e[lo] + 1;
+  }
+  uint32_t pclk = link[e].x - n * air::RC20_LIMIT;
   for (uint32_t k = 0; k < n; k++) {
     cm_clock_update u;
     u.address = addr; u.prev_clock = pclk;
@@ -123,54 +134,63 @@ __global__ void k_iota(uint32_t* p, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
 }
-// sorted[] is non-decreasing (component << 6 | opcode): ends[c] = index after the last step of component c
+// sorted[] is non-decreasing in the key bits (component, opcode): ends[c] = index after the last step of component c
 __global__ void k_run_ends(const uint32_t* __restrict__ sorted, uint32_t n, uint32_t* __restrict__ ends) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (i + 1 == n || (sorted[i + 1] >> 6) != (sorted[i] >> 6)) ends[sorted[i] >> 6] = i + 1;
+  if (i + 1 == n || info_comp(sorted[i + 1]) != info_comp(sorted[i])) ends[info_comp(sorted[i])] = i + 1;
 }
 struct BundleDst { cm_bundle* p[CM_N_OPCODE_COMPONENTS]; uint32_t start[CM_N_OPCODE_COMPONENTS + 1]; };
-// i = position in the component-sorted (stable) order of the steps
-__global__ void k_bundles(const uint32_t* __restrict__ sorted_step, uint32_t n_steps, const uint32_t* __restrict__ trace,
-                          const uint32_t* __restrict__ comp, const uint32_t* __restrict__ entry_off,
-                          const uint32_t* __restrict__ n_entries, const uint32_t* __restrict__ n_acc,
-                          const uint32_t* __restrict__ acc_off, const uint32_t* __restrict__ mem,
-                          const uint32_t* __restrict__ prev_clock, const uint32_t* __restrict__ prev_val0, BundleDst dst,
-                          cm_data_access* __restrict__ accesses, OpTable tab) {
+// position of every step in the component-sorted (stable) order
+__global__ void k_step_pos(const uint32_t* __restrict__ sorted_step, uint32_t n_steps, uint32_t* __restrict__ pos) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_steps) return;
-  uint32_t t = sorted_step[i], c = comp[t] >> 6;
-  uint32_t e0 = entry_off[t], ne = n_entries[t], na = n_acc[t];
+  if (i < n_steps) pos[sorted_step[i]] = i;
+}
+// One thread per step, in LOG order: every read (trace, offsets, log entries, links) and the data-access rows are sequential;
+// only the 48-byte bundle goes to its component's array (the other way round — threads in bundle order — gathers one useful
+// element per cache line from all of those: 0.47 ms against 0.3 at 4.2 M steps).
+__global__ void k_bundles(const uint32_t* __restrict__ step_pos, uint32_t n_steps, const uint32_t* __restrict__ trace,
+                          const uint32_t* __restrict__ info, const unsigned long long* __restrict__ off,
+                          const uint32_t* __restrict__ mem, const uint2* __restrict__ link, BundleDst dst,
+                          cm_data_access* __restrict__ accesses, OpTable tab) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_steps) return;
+  const uint32_t i = step_pos[t], inf = info[t], c = info_comp(inf);
+  const unsigned long long o = off[t];
+  const uint32_t e0 = (uint32_t)o, a0 = (uint32_t)(o >> 32), ne = info_ne(inf), na = info_na(inf);
   uint32_t ninst = ne - na;  // 1 or 2 instruction-word entries
   cm_bundle b;
-  b.pc = trace[2 * t]; b.fp = trace[2 * t + 1]; b.clock = t + 1; b.inst_prev_clock = prev_clock[e0];
+  b.pc = trace[2 * t]; b.fp = trace[2 * t + 1]; b.clock = t + 1; b.inst_prev_clock = link[e0].x;
   const uint32_t* w = mem + 5 * (size_t)e0 + 1;
   const uint32_t sz = tab.size[w[0] & 63u];  // only the instruction's own words are kept (adapter/mod.rs:132-150)
 #pragma unroll
   for (int k = 0; k < 4; k++) b.inst[k] = (uint32_t)k < sz ? w[k] : 0u;
   b.inst[4] = sz > 4 ? w[5] : 0u;
   b.inst[5] = sz > 5 ? w[6] : 0u;
-  b.span_start = acc_off[t]; b.span_len = na;
-  dst.p[c][i - dst.start[c]] = b;
+  b.span_start = a0; b.span_len = na;
+  static_assert(sizeof(cm_bundle) == 48 && sizeof(cm_data_access) == 16, "rows are written as 16-byte words");
+  uint4* bo = reinterpret_cast<uint4*>(dst.p[c] + (i - dst.start[c]));   // (pool blocks are 256-byte aligned)
+  bo[0] = make_uint4(b.pc, b.fp, b.clock, b.inst_prev_clock);
+  bo[1] = make_uint4(b.inst[0], b.inst[1], b.inst[2], b.inst[3]);
+  bo[2] = make_uint4(b.inst[4], b.inst[5], b.span_start, b.span_len);
   for (uint32_t k = 0; k < na; k++) {
     uint32_t e = e0 + ninst + k;
-    cm_data_access a;
-    a.address = mem[5 * (size_t)e]; a.prev_clock = prev_clock[e]; a.prev_value = prev_val0[e]; a.value = mem[5 * (size_t)e + 1];
-    accesses[acc_off[t] + k] = a;
+    const uint2 l = link[e];
+    reinterpret_cast<uint4*>(accesses)[a0 + k] = make_uint4(mem[5 * (size_t)e], l.x, l.y, mem[5 * (size_t)e + 1]);
   }
 }
 // one record per touched cell: (address, first entry, last entry), compacted by the head flags' exclusive scan
 struct CellRec { uint32_t addr, first_entry, last_entry, last_clock; };
-__global__ void k_cells(const unsigned long long* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ head_flag,
-                        const uint32_t* __restrict__ head_rank /*exclusive scan of head_flag*/,
+__global__ void k_cells(const uint32_t* __restrict__ sorted_addr, const uint32_t* __restrict__ sorted_e, uint32_t n,
+                        const uint32_t* __restrict__ head_flag, const uint32_t* __restrict__ head_rank /*exclusive scan of head_flag*/,
                         const uint32_t* __restrict__ entry_clock, CellRec* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t addr = (uint32_t)(sorted[i] >> 32);
-  bool tail = i + 1 == n || (uint32_t)(sorted[i + 1] >> 32) != addr;
+  uint32_t addr = sorted_addr[i];
+  bool tail = i + 1 == n || sorted_addr[i + 1] != addr;
   const uint32_t run = head_rank[i] - (head_flag[i] ? 0u : 1u);  // exclusive scan counts this run's head for i > head
-  if (head_flag[i]) { out[run].addr = addr; out[run].first_entry = (uint32_t)sorted[i]; }
-  if (tail) { out[run].last_entry = (uint32_t)sorted[i]; out[run].last_clock = entry_clock[(uint32_t)sorted[i]]; }
+  if (head_flag[i]) { out[run].addr = addr; out[run].first_entry = sorted_e[i]; }
+  if (tail) { out[run].last_entry = sorted_e[i]; out[run].last_clock = entry_clock[sorted_e[i]]; }
 }
 
 template <class F>
@@ -272,11 +292,10 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
   CM_CHECK(seg.n_memory_trace < (1ull << 32) && seg.n_trace < (1ull << 32), "adapter: segment too large");
   CM_CHECK(seg.n_memory_trace >= 1, "adapter: empty memory trace");
   // ---- upload the runner output ----
-  DevBuf d_trace(seg.n_trace * 8), d_mem((size_t)n_mem * 20 + 4), d_init((size_t)n_init * 16 + 4), d_err(4);
+  DevBuf d_trace(seg.n_trace * 8), d_mem((size_t)n_mem * 20 + 4), d_init((size_t)n_init * 16 + 4), d_err(8);
   CM_HIP(hipMemcpyAsync(d_trace.p, seg.trace, seg.n_trace * 8, hipMemcpyHostToDevice, st));
   if (n_mem) CM_HIP(hipMemcpyAsync(d_mem.p, seg.memory_trace, (size_t)n_mem * 20, hipMemcpyHostToDevice, st));
   if (n_init) CM_HIP(hipMemcpyAsync(d_init.p, seg.initial_memory, (size_t)n_init * 16, hipMemcpyHostToDevice, st));
-  CM_HIP(hipMemsetAsync(d_err.p, 0, 4, st));
   OpTable tab;
   memset(&tab, 0, sizeof(tab));
   for (uint32_t op = 0; op < 64; op++) {
@@ -286,73 +305,75 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
       tab.comp[op] = (uint8_t)air::component_of_opcode(op);
     }
   }
-  // ---- 1. per-step counts and offsets ----
-  DevBuf d_ne((size_t)n_steps * 4 + 4), d_na((size_t)n_steps * 4 + 4), d_comp((size_t)n_steps * 4 + 4), d_eoff((size_t)n_steps * 4 + 4),
-      d_aoff((size_t)n_steps * 4 + 4);
-  hipLaunchKernelGGL(k_step_counts, grid1(n_steps), dim3(256), 0, st, d_trace.u32(), n_steps, d_init.u32(), n_init, tab, d_ne.u32(),
-                     d_na.u32(), d_comp.u32(), d_err.u32());
-  with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_ne.u32(), d_eoff.u32(), (int)n_steps, st)); });
-  with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_na.u32(), d_aoff.u32(), (int)n_steps, st)); });
-  // ---- 2. sort the log by (address, entry index) ----
-  uint32_t n_acc = 0;
-  DevBuf d_keys((size_t)n_mem * 8 + 8), d_sorted((size_t)n_mem * 8 + 8), d_eclk((size_t)n_mem * 4 + 4);
-  hipLaunchKernelGGL(k_entry_keys, grid1(n_steps), dim3(256), 0, st, d_trace.u32(), n_steps, d_eoff.u32(), d_ne.u32(), d_mem.u32(), n_mem,
-                     d_keys.as<unsigned long long>(), d_eclk.u32(), d_err.u32());
+  // ---- 1. per-step counts and offsets (one 64-bit scan: log entries | operand accesses) ----
+  CM_HIP(hipMemsetAsync(d_err.p, 0, 8, st));
+  DevBuf d_info((size_t)n_steps * 4 + 4), d_off((size_t)n_steps * 8 + 8);
+  hipLaunchKernelGGL(k_step_counts, grid1(n_steps), dim3(256), 0, st, d_trace.u32(), n_steps, d_init.u32(), n_init, tab, d_info.u32(),
+                     d_off.as<unsigned long long>(), d_err.u32());
+  // (the last step's own counts are needed for the totals: keep them before the in-place scan)
+  uint32_t* const pin = pinned_words() + PIN_LAST_LAYER;   // no proof runs on this thread while it adapts a segment
+  CM_HIP(hipMemcpyAsync(pin + 0, d_off.as<unsigned long long>() + (n_steps - 1), 8, hipMemcpyDeviceToHost, st));
+  with_temp([&](void* t, size_t& b) {
+    CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_off.as<unsigned long long>(), d_off.as<unsigned long long>(), (int)n_steps, st));
+  });
+  // ---- 2. sort the log by address; entries of one cell keep their log order (stable radix sort, 32-bit key + entry index) ----
+  uint32_t n_acc = 0, addr_bits = 1;
+  DevBuf d_addr((size_t)n_mem * 4 + 4), d_eid((size_t)n_mem * 4 + 4), d_saddr((size_t)n_mem * 4 + 4), d_se((size_t)n_mem * 4 + 4),
+      d_eclk((size_t)n_mem * 4 + 4);
+  hipLaunchKernelGGL(k_entry_keys, grid1(n_steps), dim3(256), 0, st, d_trace.u32(), n_steps, d_off.as<unsigned long long>(), d_info.u32(),
+                     d_mem.u32(), n_mem, d_addr.u32(), d_eid.u32(), d_eclk.u32(), d_err.u32());
   {
-    // totals + error flag are needed on the host before the sort sizes are trusted
-    uint32_t last[4] = {0, 0, 0, 0}, err = 0;
-    CM_HIP(hipMemcpyAsync(&last[0], d_eoff.u32() + (n_steps - 1), 4, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync(&last[1], d_ne.u32() + (n_steps - 1), 4, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync(&last[2], d_aoff.u32() + (n_steps - 1), 4, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync(&last[3], d_na.u32() + (n_steps - 1), 4, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, st));
+    // totals, error flags and the largest address are needed on the host before the sort sizes are trusted
+    CM_HIP(hipMemcpyAsync(pin + 2, d_off.as<unsigned long long>() + (n_steps - 1), 8, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(pin + 4, d_err.p, 8, hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
+    const uint32_t err = pin[4], amax = pin[5];
     CM_CHECK(!(err & 1u), "adapter: invalid opcode (or an opcode without a prover component)");
-    CM_CHECK(!(err & 2u) && last[0] + last[1] == n_mem, "adapter: memory trace length does not match the instructions executed");
+    CM_CHECK(!(err & 2u) && pin[0] + pin[2] == n_mem, "adapter: memory trace length does not match the instructions executed");
     CM_CHECK(!(err & 4u), "adapter: a step's first memory entry is not the instruction fetch at pc");
-    n_acc = last[2] + last[3];
+    n_acc = pin[1] + pin[3];
+    while (addr_bits < 32 && (amax >> addr_bits)) addr_bits++;
   }
   with_temp([&](void* t, size_t& b) {
-    CM_HIP(hipcub::DeviceRadixSort::SortKeys(t, b, d_keys.as<unsigned long long>(), d_sorted.as<unsigned long long>(), (int)n_mem, 0, 62, st));
+    CM_HIP(hipcub::DeviceRadixSort::SortPairs(t, b, d_addr.u32(), d_saddr.u32(), d_eid.u32(), d_se.u32(), (int)n_mem, 0, (int)addr_bits, st));
   });
   // ---- 3. previous accesses, clock updates ----
-  DevBuf d_pclk((size_t)n_mem * 4 + 4), d_pv0((size_t)n_mem * 4 + 4), d_cuc((size_t)n_mem * 4 + 4), d_cup((size_t)n_mem * 4 + 4),
-      d_head((size_t)n_mem * 4 + 4), d_hpos((size_t)n_mem * 4 + 4), d_hent((size_t)n_mem * 4 + 4), d_cuoff((size_t)n_mem * 4 + 4),
-      d_hrank((size_t)n_mem * 4 + 4);
-  hipLaunchKernelGGL(k_prev_links, grid1(n_mem), dim3(256), 0, st, d_sorted.as<unsigned long long>(), n_mem, d_mem.u32(), d_eclk.u32(),
-                     d_init.u32(), n_init, d_pclk.u32(), d_pv0.u32(), d_cuc.u32(), d_cup.u32(), d_head.u32());
-  hipLaunchKernelGGL(k_head_pos, grid1(n_mem), dim3(256), 0, st, d_head.u32(), n_mem, d_hpos.u32());
-  with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::InclusiveScan(t, b, d_hpos.u32(), d_hpos.u32(), hipcub::Max(), (int)n_mem, st)); });
-  hipLaunchKernelGGL(k_entry_head, grid1(n_mem), dim3(256), 0, st, d_sorted.as<unsigned long long>(), d_hpos.u32(), n_mem, d_hent.u32());
+  DevBuf d_link((size_t)n_mem * 8 + 8), d_cuc((size_t)n_mem * 4 + 4), d_cupos((size_t)n_mem * 4 + 4), d_head((size_t)n_mem * 4 + 4),
+      d_cuoff((size_t)n_mem * 4 + 4), d_hrank((size_t)n_mem * 4 + 4);
+  CM_HIP(hipMemsetAsync(d_cuc.p, 0, (size_t)n_mem * 4, st));
+  hipLaunchKernelGGL(k_prev_links, grid1(n_mem), dim3(256), 0, st, d_saddr.u32(), d_se.u32(), n_mem, d_mem.u32(), d_eclk.u32(), d_init.u32(),
+                     n_init, d_link.as<uint2>(), d_cuc.u32(), d_cupos.u32(), d_head.u32());
   with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_cuc.u32(), d_cuoff.u32(), (int)n_mem, st)); });
   with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_head.u32(), d_hrank.u32(), (int)n_mem, st)); });
-  uint32_t n_cu = 0, n_cells = 0;
-  {
-    uint32_t a[2] = {0, 0}, c[2] = {0, 0};
-    CM_HIP(hipMemcpyAsync(&a[0], d_cuoff.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync(&a[1], d_cuc.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync(&c[0], d_hrank.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync(&c[1], d_head.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipStreamSynchronize(st));
-    n_cu = a[0] + a[1];
-    n_cells = c[0] + c[1];
-  }
-  DevBuf d_cu((size_t)n_cu * sizeof(cm_clock_update) + 4);
-  hipLaunchKernelGGL(k_clock_updates, grid1(n_mem), dim3(256), 0, st, d_mem.u32(), n_mem, d_cuc.u32(), d_cuoff.u32(), d_cup.u32(),
-                     d_hent.u32(), d_init.u32(), n_init, d_cu.as<cm_clock_update>());
-  // ---- 4. bundles per opcode component, opcode variants grouped inside (stable 11-bit sort of the steps), data accesses ----
-  DevBuf d_steps((size_t)n_steps * 4 + 4), d_steps_sorted((size_t)n_steps * 4 + 4), d_comp_sorted((size_t)n_steps * 4 + 4);
+  // ---- 4. steps bucketed per opcode component, opcode variants grouped inside (stable 11-bit sort) ----
+  DevBuf d_steps((size_t)n_steps * 4 + 4), d_steps_sorted((size_t)n_steps * 4 + 4), d_info_sorted((size_t)n_steps * 4 + 4);
   hipLaunchKernelGGL(k_iota, grid1(n_steps), dim3(256), 0, st, d_steps.u32(), n_steps);
   with_temp([&](void* t, size_t& b) {
-    CM_HIP(hipcub::DeviceRadixSort::SortPairs(t, b, d_comp.u32(), d_comp_sorted.u32(), d_steps.u32(), d_steps_sorted.u32(), (int)n_steps, 0, 11, st));
+    CM_HIP(hipcub::DeviceRadixSort::SortPairs(t, b, d_info.u32(), d_info_sorted.u32(), d_steps.u32(), d_steps_sorted.u32(), (int)n_steps,
+                                              (int)INFO_KEY_LO, (int)INFO_KEY_HI, st));
   });
   // component counts: the sorted component array is non-decreasing -> count = upper bound difference
   DevBuf d_counts(32 * 4);
   CM_HIP(hipMemsetAsync(d_counts.p, 0, 32 * 4, st));
-  hipLaunchKernelGGL(k_run_ends, grid1(n_steps), dim3(256), 0, st, d_comp_sorted.u32(), n_steps, d_counts.u32());
+  hipLaunchKernelGGL(k_run_ends, grid1(n_steps), dim3(256), 0, st, d_info_sorted.u32(), n_steps, d_counts.u32());
+  // ONE host round trip for everything the allocations below need
+  uint32_t n_cu = 0, n_cells = 0;
   uint32_t ends[32];
-  CM_HIP(hipMemcpyAsync(ends, d_counts.p, sizeof(ends), hipMemcpyDeviceToHost, st));
-  CM_HIP(hipStreamSynchronize(st));
+  {
+    CM_HIP(hipMemcpyAsync(pin + 8, d_cuoff.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(pin + 9, d_cuc.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(pin + 10, d_hrank.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(pin + 11, d_head.u32() + (n_mem - 1), 4, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(pin + 16, d_counts.p, sizeof(ends), hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    n_cu = pin[8] + pin[9];
+    n_cells = pin[10] + pin[11];
+    memcpy(ends, pin + 16, sizeof(ends));
+  }
+  DevBuf d_cu((size_t)n_cu * sizeof(cm_clock_update) + 4);
+  if (n_cu)
+    hipLaunchKernelGGL(k_clock_updates, grid1(n_mem), dim3(256), 0, st, d_mem.u32(), n_mem, d_cuc.u32(), d_cuoff.u32(), d_cupos.u32(),
+                       d_link.as<uint2>(), d_saddr.u32(), d_se.u32(), d_init.u32(), n_init, d_cu.as<cm_clock_update>());
   uint64_t counts[CM_N_OPCODE_COMPONENTS] = {0};
   {
     uint32_t prev_end = 0;  // ends[c] = one past the last step of component c in sorted order (0 if absent)
@@ -370,12 +391,13 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
   }
   dst.start[CM_N_OPCODE_COMPONENTS] = run;
   DevBuf d_acc((size_t)n_acc * sizeof(cm_data_access) + 4);
-  hipLaunchKernelGGL(k_bundles, grid1(n_steps), dim3(256), 0, st, d_steps_sorted.u32(), n_steps, d_trace.u32(), d_comp.u32(), d_eoff.u32(),
-                     d_ne.u32(), d_na.u32(), d_aoff.u32(), d_mem.u32(), d_pclk.u32(), d_pv0.u32(), dst, d_acc.as<cm_data_access>(), tab);
+  hipLaunchKernelGGL(k_step_pos, grid1(n_steps), dim3(256), 0, st, d_steps_sorted.u32(), n_steps, d_steps.u32());   // (the iota is spent)
+  hipLaunchKernelGGL(k_bundles, grid1(n_steps), dim3(256), 0, st, d_steps.u32(), n_steps, d_trace.u32(), d_info.u32(),
+                     d_off.as<unsigned long long>(), d_mem.u32(), d_link.as<uint2>(), dst, d_acc.as<cm_data_access>(), tab);
   // ---- 5. touched cells -> host: boundary memory, multiplicities, Merkle trees ----
   DevBuf d_cells((size_t)n_cells * sizeof(CellRec) + 16);
-  hipLaunchKernelGGL(k_cells, grid1(n_mem), dim3(256), 0, st, d_sorted.as<unsigned long long>(), n_mem, d_head.u32(), d_hrank.u32(),
-                     d_eclk.u32(), d_cells.as<CellRec>());
+  hipLaunchKernelGGL(k_cells, grid1(n_mem), dim3(256), 0, st, d_saddr.u32(), d_se.u32(), n_mem, d_head.u32(), d_hrank.u32(), d_eclk.u32(),
+                     d_cells.as<CellRec>());
   std::vector<CellRec> cells(n_cells);
   CM_HIP(hipMemcpyAsync(cells.data(), d_cells.p, (size_t)n_cells * sizeof(CellRec), hipMemcpyDeviceToHost, st));
   CM_HIP(hipGetLastError());

@@ -15,7 +15,7 @@ import sys
 
 
 def short(name):
-    n = name.split("(")[0]
+    n = name.replace("(anonymous namespace)::", "").split("(")[0]
     return n.replace("void ", "").replace("cm::", "")
 
 
