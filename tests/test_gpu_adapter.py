@@ -83,7 +83,7 @@ def test_partial_merkle_trees_on_device(backend, monkeypatch):
         hi.free(); hs.free()
 
 
-def scatter_store_program(n):
+def scatter_store_program(n, base=100):
     """A loop that writes n distinct memory cells through a double dereference ([[fp+8] + [fp+11]] = [fp+12]):
     the boundary memory grows to n cells, which takes the device adapter's GPU Merkle-tree path (>= 2048 cells)."""
     P = 2**31 - 1
@@ -92,8 +92,8 @@ def scatter_store_program(n):
         [43, 0, 8],            # pc 1: [fp+8] = fp
         [9, 7, 12],            # pc 2: value = 7
         [9, n, 30],            # pc 3: counter = n
-        [4, 20, 100, 11],      # pc 4: off = i + 100                      <- loop head
-        [45, 8, 11, 12],       # pc 5: [[fp+8] + off] = value  (cell fp + 100 + i)
+        [4, 20, base, 11],     # pc 4: off = i + base                     <- loop head
+        [45, 8, 11, 12],       # pc 5: [[fp+8] + off] = value  (cell fp + base + i)
         [4, 20, 1, 21],        # pc 6: i' = i + 1
         [4, 21, 0, 20],        # pc 7: i = i'
         [4, 30, P - 1, 31],    # pc 8: c' = c - 1
@@ -109,6 +109,18 @@ def test_large_boundary_memory_uses_device_trees(backend):
     hs = vm_segment(prog, entry_pc=0, args=(), n_returns=0)
     a = prover_input_arrays(hi.view)
     assert a["initial_memory"].shape[0] >= 3000 and a["initial_tree"].shape[0] > 10_000
+    _check(backend, hi, hs)
+    hi.free(); hs.free()
+
+
+def test_wide_addresses(backend):
+    """The address sort only runs over the bits the largest address of the log uses: cells near the top of the 28-bit address space
+    (adapter/merkle.rs tree height 30 = address bits + 2) next to the program's own small addresses."""
+    prog = scatter_store_program(300, base=(1 << 27) + 12345)
+    hi = vm_run(prog, entry_pc=0, args=(), n_returns=0)
+    hs = vm_segment(prog, entry_pc=0, args=(), n_returns=0)
+    a = prover_input_arrays(hi.view)
+    assert int(a["data_accesses"][:, 0].max()) >= 1 << 27
     _check(backend, hi, hs)
     hi.free(); hs.free()
 
