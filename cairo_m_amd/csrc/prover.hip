@@ -628,8 +628,13 @@ struct SegmentProver {
       DevBuf d_small = upload(small_jobs, st);
       KProfRegion kreg("k_logup(region)", st);
       Fork fk(st);
+      // Side streams of this region: every stream the join waits on is one barrier packet at the head of the main queue, ~5.5 us
+      // each even when its event has long fired (tools/join_lab.hip: 15 us for three, 42-49 us for seven).  The ~15 LogUp kernels
+      // lose nothing on five streams (interaction_gen + interaction_commit 2.66 -> 2.61 ms, profiles/r04n_ab_logup_width.txt); the
+      // constraint and quotient regions do (1.0 -> 1.3 ms with four) and keep all eight.  CM_LOGUP_WIDTH: side streams used here.
+      static const int lw = getenv("CM_LOGUP_WIDTH") ? std::max(1, std::min(atoi(getenv("CM_LOGUP_WIDTH")), Fork::N - 1)) : 4;
       launch_logup_small(d_small.as<SmallLogupJob>(), (uint32_t)small_jobs.size(), small_max_log, (const uint32_t* const*)pp_evals.dev(),
-                         drel.as<DevRelations>(), fk.stream(Fork::N - 1));   // first: latency-bound, hidden under the large kernels
+                         drel.as<DevRelations>(), fk.stream(lw));   // first: latency-bound, hidden under the large kernels
       int spos = 0;
       for (int pos = 0; pos < air::N_COMPONENTS; pos++) {   // large components first (see trace generation)
         const int c = by_size_all[pos];
@@ -638,7 +643,7 @@ struct SegmentProver {
         jobs[c].log_size = clog[c];
         if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
         launch_logup(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), (const uint32_t* const*)pp_evals.dev(), clog[c],
-                     drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos == 0 ? Fork::main_or(0) : spos % fork_width(Fork::N - 1)));
+                     drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos == 0 ? Fork::main_or(0) : spos % lw));
         spos++;
       }
       fk.join();
