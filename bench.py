@@ -77,7 +77,7 @@ def latest_profile(suffix):
 STAGE_MODEL = [
     ("trace / interaction generation", 4.0, ("k_trace_gen(region)", "k_logup(region)")),
     ("IFFT + LDE", 8.0 + 12.0, ("k_fft_pass<ifft>", "k_fft_pass<fft>", "k_fft_fused", "k_small_commit")),
-    ("Merkle hashing", 8.0, ("k_merkle_layer", "k_merkle_layer_quad", "k_merkle_multi", "k_merkle_top", "k_merkle_tail")),
+    ("Merkle hashing", 8.0, ("k_merkle_layer", "k_merkle_layer_quad", "k_merkle_multi", "k_merkle_top", "k_merkle_tail", "k_fold_leaf")),
     ("constraint quotients", 8.0, ("k_constraints(region)",)),
     ("OODS eval_at_point", 4.0, ("k_eval_at_point",)),
     ("DEEP quotients", 8.0, ("k_quotients",)),

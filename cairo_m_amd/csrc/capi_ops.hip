@@ -154,6 +154,35 @@ int32_t cm_fri_fold_line(const cm_handle in[4], const uint32_t alpha[4], uint32_
     CM_HIP(hipStreamSynchronize(S(s)));
   });
 }
+int32_t cm_fri_fold_line_leaves(const cm_handle* in, const cm_handle* circle, const uint32_t* alpha, const uint32_t* alpha_circle,
+                                uint32_t log_n, cm_handle tw, const cm_handle out[4], cm_handle leaf_hashes, cm_stream_t s) {
+  return guard([&] {
+    CM_CHECK(tw, "cm_fri_fold_line_leaves: null twiddles");
+    CM_CHECK(log_n >= 2, "cm_fri_fold_line_leaves: log_n < 2");
+    CM_CHECK(in || circle, "cm_fri_fold_line_leaves: neither a line nor a circle source");
+    CM_CHECK((in == nullptr) == (alpha == nullptr) && (circle == nullptr) == (alpha_circle == nullptr),
+             "cm_fri_fold_line_leaves: every source comes with its challenge");
+    const Twiddles& T = *(Twiddles*)(uintptr_t)tw;
+    uint32_t* d[4]; const uint32_t* c[4] = {nullptr, nullptr, nullptr, nullptr}; const uint32_t* q[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0; k < 4; k++) { d[k] = P32(out[k]); if (in) c[k] = P32(in[k]); if (circle) q[k] = P32(circle[k]); }
+    std::vector<uint32_t> a8(8, 0);
+    if (alpha) memcpy(a8.data(), alpha, 16);
+    if (alpha_circle) memcpy(a8.data() + 4, alpha_circle, 16);
+    DevBuf d_a = upload(a8, S(s));
+    const bool fused = in ? fold_line_leaf(d, c, circle ? q : nullptr, log_n, T, S(s), d_a.u32(), circle ? d_a.u32() + 4 : nullptr, P32(leaf_hashes))
+                          : fold_circle_leaf(d, q, log_n, T, S(s), d_a.u32() + 4, P32(leaf_hashes));
+    if (!fused) {
+      // small layers: the two launches the fused kernel replaces
+      if (!in) fold_circle_into_line(d, q, log_n, T, QM31::from_u32(alpha_circle), false, S(s));
+      else if (circle) fold_line_and_circle(d, c, q, log_n, T, S(s), d_a.u32(), d_a.u32() + 4);
+      else fold_line(d, c, log_n, T, QM31::from_u32(alpha), S(s));
+      std::vector<const uint32_t*> cols(d, d + 4);
+      DevBuf d_cols = upload(cols, S(s));
+      merkle_layer(log_n - 1, nullptr, d_cols.as<const uint32_t*>(), 4, P32(leaf_hashes), S(s));
+    }
+    CM_HIP(hipStreamSynchronize(S(s)));
+  });
+}
 int32_t cm_accumulate_quotients(uint32_t log_size, const cm_handle* cols, uint32_t n_cols, const cm_sample_batches* b,
                                 const uint32_t random_coeff[4], const cm_handle out[4], cm_handle tw, cm_stream_t s) {
   return guard([&] {

@@ -115,18 +115,38 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
     while (qi < quotients.size() && q_logs[qi] - 1 == layer_log) {
       const uint32_t* src[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
       uint32_t* dst[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
+      // a blank layer fed by ONE group of quotient columns (the first inner layer): fold and leaf hashes in one pass
+      if (layer_is_blank && !cur->planned && !(qi + 1 < quotients.size() && q_logs[qi + 1] - 1 == layer_log)) {
+        cur->plan = cur->tree.plan_commit();
+        cur->planned = true;
+        const int nl = (int)layer_log;
+        if (cur->plan.size() > 1 && cur->plan[0].hi == nl && cur->plan[0].lo == nl &&
+            fold_circle_leaf(dst, src, q_logs[qi], *P.tw, st, d_alphas.u32(), cur->tree.layers[nl].u32())) {
+          cur->leaf_done = true;
+          layer_is_blank = false;
+          qi++;
+          continue;
+        }
+      }
       fold_circle_into_line(dst, src, q_logs[qi], *P.tw, unused_alpha, !layer_is_blank, st, d_alphas.u32());
       layer_is_blank = false;
       qi++;
     }
     CM_CHECK(!layer_is_blank, "fri: the first layer received no quotient column");
-    cur->tree.commit_prepared(st);
+    if (!cur->planned) { cur->plan = cur->tree.plan_commit(); cur->planned = true; }
+    for (size_t k = cur->leaf_done ? 1 : 0; k < cur->plan.size(); k++) cur->tree.run_launch(cur->plan[k], st);
     const size_t li = inner.size() + 1;
     chan_mix_root_draw(d_chan.u32(), cur->tree.layers[0].u32(), d_alphas.u32() + 4 * li, d_roots.u32() + 8 * li, st);
     // fold into the next layer: the next pre-allocated one, or a fresh buffer that the tail / last layer takes over
     uint32_t* dst[4];
+    uint32_t* next_leaves = nullptr;   // the leaf layer of the next tree, when that layer is a launch of its own (large layers)
     if (pi + 1 < pre.size()) {
-      for (int c = 0; c < 4; c++) dst[c] = pre[pi + 1]->eval.ptrs[c];
+      InnerLayer* nxt = pre[pi + 1].get();
+      for (int c = 0; c < 4; c++) dst[c] = nxt->eval.ptrs[c];
+      nxt->plan = nxt->tree.plan_commit();
+      nxt->planned = true;
+      const int nl = (int)layer_log - 1;
+      if (nxt->plan.size() > 1 && nxt->plan[0].hi == nl && nxt->plan[0].lo == nl) next_leaves = nxt->tree.layers[nl].u32();
     } else {
       layer = ColumnSet();
       layer.alloc(std::vector<uint32_t>(4, layer_log - 1), st, false);
@@ -138,10 +158,14 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
     if (next_outside_tail && qi < quotients.size() && q_logs[qi] == layer_log &&
         !(qi + 1 < quotients.size() && q_logs[qi + 1] == layer_log)) {
       const uint32_t* circ[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
-      fold_line_and_circle(dst, src, circ, layer_log, *P.tw, st, d_alphas.u32() + 4 * li, d_alphas.u32());
+      if (next_leaves && fold_line_leaf(dst, src, circ, layer_log, *P.tw, st, d_alphas.u32() + 4 * li, d_alphas.u32(), next_leaves))
+        pre[pi + 1]->leaf_done = true;
+      else fold_line_and_circle(dst, src, circ, layer_log, *P.tw, st, d_alphas.u32() + 4 * li, d_alphas.u32());
       qi++;
     } else {
-      fold_line(dst, src, layer_log, *P.tw, unused_alpha, st, d_alphas.u32() + 4 * li);
+      if (next_leaves && fold_line_leaf(dst, src, nullptr, layer_log, *P.tw, st, d_alphas.u32() + 4 * li, nullptr, next_leaves))
+        pre[pi + 1]->leaf_done = true;
+      else fold_line(dst, src, layer_log, *P.tw, unused_alpha, st, d_alphas.u32() + 4 * li);
     }
     layer_log--;
     inner.push_back(std::move(pre[pi]));

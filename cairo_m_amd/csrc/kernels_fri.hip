@@ -312,6 +312,80 @@ __global__ void __launch_bounds__(256) k_fold_line_circle(Ptr4 out, CPtr4 src, C
   st4(out.p, i, line * (ac * ac) + v);
 }
 
+// One pass for a FRI layer of 2^(log_n - 1) values AND the leaf layer of its Merkle tree: the folded value is hashed in the
+// registers it was computed in.  The separate leaf launch read the four coordinate columns back (16 B per leaf) behind a fold that
+// was a memory-bound launch of its own in front of an issue-bound one; here the fold's loads fly under the previous chunk's
+// compression.  MODE 0: fold_line (k_fold_line); MODE 1: fold_line + fold_circle of the quotient columns of that size
+// (k_fold_line_circle); MODE 2: fold_circle alone into a blank layer (the first inner layer: k_fold_circle, not accumulating).  Leaf framing and store pattern = k_merkle_narrow<RFC, false, 4> (merkle_kernels.hpp): a wave walks `npw`
+// chunks of 64 leaves, the hashes leave through a wave-private LDS window as two wave-contiguous 1 KiB stores.
+template <bool RFC, int MODE>
+__global__ void __launch_bounds__(256) k_fold_leaf(Ptr4 out, CPtr4 src, CPtr4 circle, uint32_t log_n, TwiddleView tw,
+                                                   const uint32_t* __restrict__ alpha_dev, const uint32_t* __restrict__ alpha_c_dev,
+                                                   uint32_t* __restrict__ hashes, uint32_t npw) {
+  __shared__ uint4 stage[4][128];           // per wave: 64 leaves x 32 B
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  uint4* st = stage[w];
+  const uint32_t leaf0 = (blockIdx.x * 4u + w) * 64u * npw;
+  __builtin_assume(leaf0 < (1u << 29));
+  QM31 alpha;
+  if (MODE != 2) alpha = QM31::from_u32(alpha_dev);
+  QM31 ac, ac2;
+  if (MODE >= 1) { ac = QM31::from_u32(alpha_c_dev); ac2 = ac * ac; }
+  const uint32_t L = MODE == 2 ? 0u : tw.R - (log_n + 1);
+  const uint32_t* __restrict__ ixt = tw.ixtw + ((1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)));
+  const uint32_t* __restrict__ iyt = tw.iytw + (1u << (log_n - 1));
+  // (plain scalars: indexed arrays of loads captured by reference went to scratch in k_merkle_narrow)
+  uint2 s0 = {0, 0}, s1 = {0, 0}, s2 = {0, 0}, s3 = {0, 0}, c0, c1, c2, c3;
+  uint32_t xw = 0, yw = 0;
+#define CM_FOLD_ISSUE(i_)                                                              \
+  {                                                                                    \
+    if (MODE != 2) {                                                                   \
+      s0 = reinterpret_cast<const uint2*>(src.p[0])[i_]; s1 = reinterpret_cast<const uint2*>(src.p[1])[i_];   \
+      s2 = reinterpret_cast<const uint2*>(src.p[2])[i_]; s3 = reinterpret_cast<const uint2*>(src.p[3])[i_];   \
+      xw = ixt[i_];                                                                    \
+    }                                                                                  \
+    if (MODE >= 1) {                                                                   \
+      c0 = reinterpret_cast<const uint2*>(circle.p[0])[i_]; c1 = reinterpret_cast<const uint2*>(circle.p[1])[i_]; \
+      c2 = reinterpret_cast<const uint2*>(circle.p[2])[i_]; c3 = reinterpret_cast<const uint2*>(circle.p[3])[i_]; \
+      yw = iyt[i_];                                                                    \
+    }                                                                                  \
+  }
+  CM_FOLD_ISSUE(leaf0 + lane)
+  for (uint32_t c = 0; c < npw; c++) {
+    const uint32_t i = leaf0 + 64u * c + lane;
+    const QM31 f0(M31(s0.x), M31(s1.x), M31(s2.x), M31(s3.x)), f1(M31(s0.y), M31(s1.y), M31(s2.y), M31(s3.y));
+    QM31 v;
+    if (MODE != 2) v = (f0 + f1) + alpha * ((f0 - f1) * M31(xw >> 1));
+    if (MODE >= 1) {
+      const QM31 g0(M31(c0.x), M31(c1.x), M31(c2.x), M31(c3.x)), g1(M31(c0.y), M31(c1.y), M31(c2.y), M31(c3.y));
+      const QM31 cf = (g0 + g1) + ac * ((g0 - g1) * M31(yw >> 1));
+      v = MODE == 2 ? cf : v * ac2 + cf;
+    }
+    if (c + 1 < npw) CM_FOLD_ISSUE(i + 64u)   // the next chunk's loads fly during this chunk's compression
+    st4(out.p, i, v);
+    uint32_t z[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) z[k] = 0;   // 12 literal zeros: most message additions of the compression fold away
+    z[0] = v.a.a.v; z[1] = v.a.b.v; z[2] = v.b.a.v; z[3] = v.b.b.v;
+    NodeFrame<RFC> fr(false, 4);
+    uint32_t h[8];
+    fr.init(h);
+    fr.absorb(h, z, 16);
+    st[lane * 2 + 0] = make_uint4(h[0], h[1], h[2], h[3]);
+    st[lane * 2 + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint4* o = reinterpret_cast<uint4*>(hashes + (size_t)(leaf0 + 64u * c) * 8);
+    o[lane] = st[lane];
+    o[64 + lane] = st[64 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#undef CM_FOLD_ISSUE
+}
+
 template <bool RFC>   // framing.hpp switch `hash_node`
 __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
   // Tree levels of <= 256 nodes: one node per QUAD of lanes (b2s_compress_quad, ~1.4 us instead of ~2.7 us per
@@ -460,6 +534,47 @@ void fold_line_and_circle(uint32_t* const out[4], const uint32_t* const src[4], 
   uint32_t n = 1u << (log_n - 1);
   hipLaunchKernelGGL(k_fold_line_circle, dim3((n + 255) / 256), dim3(256), 0, st, d, s, c, log_n, view(tw), d_alpha, d_alpha_circle);
   CM_HIP(hipGetLastError());
+}
+// fold_line (circle == nullptr) or fold_line_and_circle, plus the leaf hashes of the tree over `out` (2^(log_n - 1) leaves of
+// four coordinate words); true if the launch was made (the layer must be large enough for the wave-per-chunk walk)
+bool fold_line_leaf(uint32_t* const out[4], const uint32_t* const src[4], const uint32_t* const* circle, uint32_t log_n,
+                    const Twiddles& tw, hipStream_t st, const uint32_t* d_alpha, const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes) {
+  static const bool on = !(getenv("CM_FRI_FOLD_LEAF") && atoi(getenv("CM_FRI_FOLD_LEAF")) == 0);   // A/B: 0 = fold, then the leaf launch
+  if (!on || log_n < 15 || log_n + 1 > tw.R) return false;
+  const uint32_t n = 1u << (log_n - 1);
+  uint32_t npw = std::min(8u, std::max(1u, n >> 20));
+  while (npw > 1 && (n % (256u * npw)) != 0) npw >>= 1;
+  Ptr4 d; CPtr4 s, c;
+  for (int i = 0; i < 4; i++) { d.p[i] = out[i]; s.p[i] = src[i]; c.p[i] = circle ? circle[i] : nullptr; }
+  // algorithmic bytes: two source values (+ two quotient values) in, the folded value and its hash out
+  KProfScope kp("k_fold_leaf", ((circle ? 64.0 : 32.0) + 16.0 + 32.0) * (double)n, st, /* Blake2s compressions */ (double)n);
+  const dim3 grid(n / (256u * npw));
+  const bool rfc = framing().hash_node_rfc;
+#define CM_FL(R, M) hipLaunchKernelGGL((k_fold_leaf<R, M>), grid, dim3(256), 0, st, d, s, c, log_n, view(tw), d_alpha, d_alpha_circle, d_leaf_hashes, npw)
+  if (circle) { if (rfc) CM_FL(true, 1); else CM_FL(false, 1); }
+  else { if (rfc) CM_FL(true, 0); else CM_FL(false, 0); }
+#undef CM_FL
+  CM_HIP(hipGetLastError());
+  return true;
+}
+// fold_circle_into_line of ONE group of quotient columns (2^log_n circle evaluations) into a blank layer + its leaf hashes
+bool fold_circle_leaf(uint32_t* const out[4], const uint32_t* const circle[4], uint32_t log_n, const Twiddles& tw, hipStream_t st,
+                      const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes) {
+  static const bool on = !(getenv("CM_FRI_FOLD_LEAF") && atoi(getenv("CM_FRI_FOLD_LEAF")) == 0);
+  if (!on || log_n < 15 || log_n > tw.R) return false;
+  const uint32_t n = 1u << (log_n - 1);
+  uint32_t npw = std::min(8u, std::max(1u, n >> 20));
+  while (npw > 1 && (n % (256u * npw)) != 0) npw >>= 1;
+  Ptr4 d; CPtr4 s, c;
+  for (int i = 0; i < 4; i++) { d.p[i] = out[i]; s.p[i] = nullptr; c.p[i] = circle[i]; }
+  KProfScope kp("k_fold_leaf", (32.0 + 16.0 + 32.0) * (double)n, st, /* Blake2s compressions */ (double)n);
+  const dim3 grid(n / (256u * npw));
+  if (framing().hash_node_rfc)
+    hipLaunchKernelGGL((k_fold_leaf<true, 2>), grid, dim3(256), 0, st, d, s, c, log_n, view(tw), (const uint32_t*)nullptr, d_alpha_circle, d_leaf_hashes, npw);
+  else
+    hipLaunchKernelGGL((k_fold_leaf<false, 2>), grid, dim3(256), 0, st, d, s, c, log_n, view(tw), (const uint32_t*)nullptr, d_alpha_circle, d_leaf_hashes, npw);
+  CM_HIP(hipGetLastError());
+  return true;
 }
 void quotient_coeffs(const QuotientCoefJob* d_jobs, uint32_t n_jobs, const uint32_t* d_samples, const QM31& coeff, hipStream_t st) {
   if (!n_jobs) return;

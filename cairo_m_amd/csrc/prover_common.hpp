@@ -426,7 +426,11 @@ struct FriResume {
   QM31 alpha_c;                 // the circle-fold challenge (the first FRI challenge)
 };
 struct FriPhase {
-  struct InnerLayer { ColumnSet eval; uint32_t log; MerkleTree tree; hostch::Hash32 root; };
+  struct InnerLayer {
+    ColumnSet eval; uint32_t log; MerkleTree tree; hostch::Hash32 root;
+    std::vector<MerkleTree::CommitLaunch> plan;   // the tree's launches, planned when the fold INTO this layer is enqueued ...
+    bool planned = false, leaf_done = false;      // ... because that fold may already have hashed the leaves (fold_line_leaf)
+  };
   MerkleTree first_tree;
   std::vector<std::unique_ptr<InnerLayer>> inner;
   bool have_first = true;       // false after a resumed commit: no first-layer tree here

@@ -145,6 +145,15 @@ class Backend:
         self._ck(self.L.cm_fri_fold_line(self._harr(src4), _p(a), C.c_uint32(log_n), C.c_uint64(tw),
                                          self._harr(out4), C.c_uint64(0)))
 
+    def fri_fold_line_leaves(self, src4, alpha, log_n, tw, out4, leaf_hashes, circle4=None, alpha_circle=None):
+        """A FRI layer (fold_line of src4, fold_circle of circle4 accumulated in; either may be None) and the leaf hashes of the
+        folded layer in one pass."""
+        a = None if alpha is None else np.ascontiguousarray(alpha, dtype=np.uint32)
+        ac = None if alpha_circle is None else np.ascontiguousarray(alpha_circle, dtype=np.uint32)
+        self._ck(self.L.cm_fri_fold_line_leaves(None if src4 is None else self._harr(src4), None if circle4 is None else self._harr(circle4),
+                                                None if a is None else _p(a), None if ac is None else _p(ac), C.c_uint32(log_n),
+                                                C.c_uint64(tw), self._harr(out4), C.c_uint64(leaf_hashes), C.c_uint64(0)))
+
     def accumulate_quotients(self, log_size, cols, points, batch_off, col_index, values, coeff, out4, tw):
         """points: (n_batches, 8) u32; batch_off: n_batches+1; col_index: entries; values: (entries, 4)."""
         class Batches(C.Structure):

@@ -136,6 +136,15 @@ int32_t cm_fri_fold_circle_into_line(const cm_handle dst[4], const cm_handle src
 /* out (2^(log_n-1)) = fold_line(in (2^log_n), alpha) */
 int32_t cm_fri_fold_line(const cm_handle in[4], const uint32_t alpha[4], uint32_t log_n, cm_handle tw,
                          const cm_handle out[4], cm_stream_t s);
+/* A FRI layer and the leaf layer of its commitment in one pass (what FriProver::commit_inner_layers does per layer: fold, then
+ * MerkleProver::commit over the folded SecureColumn — prover.rs:131 -> Stwo fri.rs).  Sources, each with its challenge:
+ *   in (4 handles, 2^log_n line evaluations) + alpha              -> out = fold_line(in, alpha)
+ *   circle (4 handles, 2^log_n circle evaluations) + alpha_circle -> FriOps::fold_circle_into_line of the quotient columns of
+ *   that size: out = out * alpha_circle^2 + fold_circle(circle, alpha_circle); alone (in == NULL, alpha == NULL) it folds into a
+ *   blank layer: out = fold_circle(circle, alpha_circle).
+ * out: 4 handles of 2^(log_n-1).  leaf_hashes: 8 words per row of `out` = MerkleOps::commit_on_layer(log_n - 1, None, out). */
+int32_t cm_fri_fold_line_leaves(const cm_handle* in, const cm_handle* circle, const uint32_t* alpha, const uint32_t* alpha_circle,
+                                uint32_t log_n, cm_handle tw, const cm_handle out[4], cm_handle leaf_hashes, cm_stream_t s);
 
 /* ---- QuotientOps::accumulate_quotients ------------------------------------------------------ */
 /* One call per distinct LDE log size.  cols: the n_cols committed LDE columns of that size.

@@ -198,6 +198,7 @@ unsafe extern "C" {
     pub fn cm_batch_inverse_qm31(src: *const cm_handle, out: *const cm_handle, n: u64, s: cm_stream_t) -> i32;
     pub fn cm_fri_fold_circle_into_line(dst: *const cm_handle, src: *const cm_handle, alpha: *const u32, log_n: u32, tw: cm_handle, s: cm_stream_t) -> i32;
     pub fn cm_fri_fold_line(src: *const cm_handle, alpha: *const u32, log_n: u32, tw: cm_handle, out: *const cm_handle, s: cm_stream_t) -> i32;
+    pub fn cm_fri_fold_line_leaves(src: *const cm_handle, circle: *const cm_handle, alpha: *const u32, alpha_circle: *const u32, log_n: u32, tw: cm_handle, out: *const cm_handle, leaf_hashes: cm_handle, s: cm_stream_t) -> i32;
     pub fn cm_accumulate_quotients(log_size: u32, cols: *const cm_handle, n_cols: u32, batches: *const cm_sample_batches, random_coeff: *const u32, out: *const cm_handle, tw: cm_handle, s: cm_stream_t) -> i32;
     pub fn cm_vm_run(instr_words: *const u32, instr_lens: *const u32, n_instr: u32, entry_pc: u32, args: *const u32, n_args: u32, n_returns: u32, max_steps: u64, segment_index: u32, out: *mut *mut cm_host_input, n_segments_out: *mut u32) -> i32;
     pub fn cm_synth_fibonacci(n: u32, max_steps: u64, segment_index: u32, out: *mut *mut cm_host_input) -> i32;

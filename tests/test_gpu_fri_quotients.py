@@ -69,6 +69,41 @@ def test_fold_line(backend, oracle, log_n):
     backend.twiddles_free(tw)
 
 
+@pytest.mark.parametrize("mode", ["line", "line+circle", "circle"])
+@pytest.mark.parametrize("log_n", [5, 15, 20, 21])
+def test_fold_line_leaves(backend, oracle, log_n, mode):
+    """cm_fri_fold_line_leaves (k_fold_leaf: the fold of a FRI layer and the leaf layer of its Merkle tree in one pass; log_n < 15
+    takes the two separate launches): the folded layer equals the oracle's fold_line (with the quotient columns of that size
+    folded in: fold_circle_into_line accumulating with the circle challenge; or the circle fold alone into a blank layer, the
+    first inner layer), and every leaf hash equals the oracle's commitment layer over the four coordinate columns.
+    2^20 / 2^21 values: chunk counts 1 and 2 per wave."""
+    rng = np.random.default_rng(700 + log_n + 50 * ["line", "line+circle", "circle"].index(mode))
+    n_out = 1 << (log_n - 1)
+    tw = backend.twiddles(log_n + 1)
+    hs, hq, alpha, ac = None, None, None, None
+    want = np.zeros((4, n_out), dtype=np.uint32)
+    if mode != "circle":
+        src = rand_secure(rng, 1 << log_n)
+        alpha = rng.integers(0, P, size=4, dtype=np.uint32)
+        want = oracle.fold_line(src, log_n, alpha)
+        hs = [backend.upload(c) for c in src]
+    if mode != "line":
+        circ = rand_secure(rng, 1 << log_n)
+        ac = rng.integers(0, P, size=4, dtype=np.uint32)
+        want = oracle.fold_circle_into_line(want, circ, log_n, ac)   # dst * ac^2 + fold_circle(circ, ac); dst = 0 when alone
+        hq = [backend.upload(c) for c in circ]
+    ho = [backend.col_alloc(n_out) for _ in range(4)]
+    hh = backend.col_alloc(8 * n_out)
+    backend.fri_fold_line_leaves(hs, alpha, log_n, tw, ho, hh, circle4=hq, alpha_circle=ac)
+    got = np.stack([backend.download(h, n_out) for h in ho])
+    assert np.array_equal(got, want)
+    _, layers = oracle.merkle_commit([np.ascontiguousarray(want[k]) for k in range(4)])
+    assert np.array_equal(backend.download(hh, 8 * n_out).reshape(-1, 8), layers.reshape(-1, 8)[:n_out])
+    for h in (hs or []) + (hq or []) + ho + [hh]:
+        backend.col_free(h)
+    backend.twiddles_free(tw)
+
+
 @pytest.mark.parametrize("log_n,n_cols", [(3, 1), (6, 5), (11, 40), (14, 7)])
 def test_accumulate_quotients(backend, oracle, log_n, n_cols):
     """Two sample points (the OODS point and its mask-shifted neighbour): every column is sampled at point 0,

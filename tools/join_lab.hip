@@ -40,6 +40,10 @@ int main(int argc, char** argv) {
       {"3 sides, main last, default-flag events", 3, 250, 150, 0, false},
       {"3 sides, main last, then a pinned H2D copy before the marker", 3, 250, 150, DT, true},
       {"no fork, then a pinned H2D copy before the marker", 0, 200, 0, DT, true},
+      {"7 sides, NO kernel on main, slow side waited FIRST", 7, 0, 250, DT, false, 0, 0},
+      {"7 sides, NO kernel on main, slow side waited LAST", 7, 0, 250, DT, false, 0, 6},
+      {"7 sides, NO kernel on main, two slow sides (waited last)", 7, 0, 250, DT, false, 3, 6},
+      {"3 sides, NO kernel on main, slow side waited LAST", 3, 0, 250, DT, false, 0, 2},
       {"7 sides CHAINED, main last", 7, 250, 150, DT, false, 1, 0},
       {"7 sides CHAINED, first side of the chain last", 7, 150, 250, DT, false, 1, 0},
       {"7 sides CHAINED, middle side of the chain last", 7, 150, 250, DT, false, 1, 3},
@@ -61,10 +65,12 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(fork_ev, main_s));
       for (int i = 0; i < c.S; i++) {
         CK(hipStreamWaitEvent(side[i], fork_ev, 0));
-        hipLaunchKernelGGL(spin, dim3(64), dim3(64), 0, side[i], us2t(i == c.slow ? c.side_us : c.side_us * 0.6), t + 1 + i);
+        const bool slow = i == c.slow || (c.chain == 3 && i == c.slow - 1);
+        hipLaunchKernelGGL(spin, dim3(64), dim3(64), 0, side[i], us2t(slow ? c.side_us : c.side_us * 0.6), t + 1 + i);
       }
-      hipLaunchKernelGGL(spin, dim3(64), dim3(64), 0, main_s, us2t(c.main_us), t + 0);
-      if (c.chain == 0) {
+      if (c.main_us > 0) hipLaunchKernelGGL(spin, dim3(64), dim3(64), 0, main_s, us2t(c.main_us), t + 0);
+      else t[0] = 0;
+      if (c.chain == 0 || c.chain == 3) {
         for (int i = 0; i < c.S; i++) { CK(hipEventRecord(done[i], side[i])); CK(hipStreamWaitEvent(main_s, done[i], 0)); }
       } else {
         const int split = c.chain == 2 ? 4 : c.S;   // chain ends: split - 1 and S - 1
