@@ -91,11 +91,13 @@ struct MerkleTree {
 
   // sort the columns (stable, by size descending): fills `cols` / `col_logs`
   void prepare(const std::vector<const uint32_t*>& columns, const std::vector<uint32_t>& logs) {
-    std::vector<uint32_t> order(columns.size());
-    for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return logs[a] > logs[b]; });
-    cols.clear(); col_logs.clear();
-    for (auto i : order) { cols.push_back(columns[i]); col_logs.push_back(logs[i]); }
+    // a stable counting sort over the (at most 32) sizes: this runs on the host between two phases, with the GPU idle
+    const size_t n = columns.size();
+    uint32_t off[34] = {0};
+    for (size_t i = 0; i < n; i++) { CM_CHECK(logs[i] < 32, "merkle tree: column of 2^32 rows or more"); off[32 - logs[i]]++; }
+    for (uint32_t k = 0, run = 0; k < 34; k++) { const uint32_t c = off[k]; off[k] = run; run += c; }   // slot 32 - log: descending size
+    cols.resize(n); col_logs.resize(n);
+    for (size_t i = 0; i < n; i++) { const uint32_t p = off[32 - logs[i]]++; cols[p] = columns[i]; col_logs[p] = logs[i]; }
     d_cols_view = nullptr;
   }
   void commit(const std::vector<const uint32_t*>& columns, const std::vector<uint32_t>& logs, hipStream_t st) {

@@ -454,6 +454,11 @@ struct SegmentProver {
   void trace_commit() {
     // ---- tree 0: preprocessed trace (prover.rs:70-73) ----
     std::unique_ptr<Fork> pp_fork;
+    hipStream_t tree0_stream = nullptr;
+    struct DrainOnExit {   // an exception between the fork and the join must not return tree 0's buffers to the pool under its kernels
+      hipStream_t& s; bool joined = false;
+      ~DrainOnExit() { if (s && !joined) (void)hipStreamSynchronize(s); }
+    } tree0_guard{tree0_stream};
     bool build_tree0 = false;
     if (pp_cache_enabled() && tl_pp_cache.valid && tl_pp_cache.log_blowup == cfg.log_blowup_factor) {
       P.trees[0] = std::move(tl_pp_cache.tree);  // both handed back at the end of the proof
@@ -541,6 +546,7 @@ struct SegmentProver {
                              clog[air::C_POSEIDON2], tr_evals.dev(tr0[air::C_POSEIDON2]), fk.stream(air::C_POSEIDON2));
       fk.join();
       kreg.close();
+      ht.mark("trace_gen: launched + joined");
       flag_host[0] = 0xffffffffu;
       CM_HIP(hipMemcpyAsync(flag_host, flag.p, 4, hipMemcpyDeviceToHost, st));
     }
@@ -549,26 +555,40 @@ struct SegmentProver {
       // tree 0 (a chain of ~30 small launches) is built on a side stream while the transforms and hashes of tree 1 keep
       // the GPU busy; its root comes back together with the root of tree 1.  Forked from the stream position after the
       // trace-generation launches so that its chain does not queue in front of them.
-      pp_fork.reset(new Fork(st));
-      (void)pp_fork->stream(Fork::N - 1);   // the side stream waits for THIS point of the main stream (trace generation done)
+      // The side streams share four hardware queues with the main and the pipeline stream, and a queue runs its packets in order:
+      // on side stream 7 the whole tree sat BEHIND the transforms of tree 1 (same queue as the pipeline stream) and its Merkle
+      // chain ran alone after tree 1 had finished (0.17 ms of a nearly idle GPU, and the host learnt root 0 only then).  A stream
+      // of the highest priority class has hardware queues of its own.  CM_TREE0_PRIO=0: the side stream (A/B), 1: lowest class.
+      static const int t0_prio = getenv("CM_TREE0_PRIO") ? atoi(getenv("CM_TREE0_PRIO")) : -1;
+      if (t0_prio != 0) {
+        tree0_stream = thread_priority_stream(t0_prio);
+        hipEvent_t e = Prover::pipe_event();
+        CM_HIP(hipEventRecord(e, st));                       // trace generation launched, twiddles joined
+        CM_HIP(hipStreamWaitEvent(tree0_stream, e, 0));
+      } else {
+        pp_fork.reset(new Fork(st));
+        tree0_stream = pp_fork->stream(Fork::N - 1);   // the side stream waits for THIS point of the main stream (trace generation done)
+      }
     }
     P.tick("trace_gen");
     // tree 1 first: its large transforms start as soon as the trace exists and keep the GPU busy while the host issues tree 0's
     // chain of small launches (enqueued first, that chain delayed the first tree-1 kernel by the host time of ~30 launches)
     static const bool tree1_first = getenv("CM_TREE0_FIRST") == nullptr;   // A/B switch
-    if (build_tree0 && !tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
+    if (build_tree0 && !tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, tree0_stream);
     P.trees[1].merkle.pace_ev = Prover::pace_event(1);
     P.commit_enqueue(P.trees[1], &tr_evals, false, st, true, false, P.pipe_stream());
-    if (build_tree0 && tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, pp_fork->stream(Fork::N - 1));
+    if (build_tree0 && tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, tree0_stream);
     // Root 0 first (transcript order, prover.rs:70-82: root 0, claim, root 1): tree 0 has been running on its side stream next
     // to all of the above; its root is copied on THAT stream and waited for here, while the GPU is still busy with tree 1.
-    if (pp_fork) {
+    if (build_tree0) {
       static thread_local hipEvent_t ev_root0 = nullptr;
       if (!ev_root0) { CM_HIP(hipEventCreateWithFlags(&ev_root0, hipEventDisableTiming)); thread_event_owned(ev_root0); }
-      hipStream_t ps = pp_fork->stream(Fork::N - 1);
+      hipStream_t ps = tree0_stream;
       CM_HIP(hipMemcpyAsync(pinned_words() + PIN_ROOT0, P.trees[0].merkle.layers[0].p, 32, hipMemcpyDeviceToHost, ps));
       CM_HIP(hipEventRecord(ev_root0, ps));
-      pp_fork->join();
+      if (pp_fork) pp_fork->join();
+      else CM_HIP(hipStreamWaitEvent(st, ev_root0, 0));   // what follows on the main stream reads tree 0's LDE
+      tree0_guard.joined = true;
       CM_HIP(hipEventSynchronize(ev_root0));
       memcpy(P.trees[0].root.data(), pinned_words() + PIN_ROOT0, 32);
       ch.mix_root(P.trees[0].root);
@@ -588,7 +608,9 @@ struct SegmentProver {
       step_pow_relations(cw, P.trees[1].merkle.layers[0].u32(), INTERACTION_POW_BITS, air::N_RELATIONS, air::MAX_REL_SIZE, rel,
                          rel + 4 * air::N_RELATIONS, d_step1.u32(), st);
       CM_HIP(hipMemcpyAsync(pinned_words() + PIN_STEP1, d_step1.p, 16 * 4, hipMemcpyDeviceToHost, st));
+      ht.mark("trace_commit: enqueued");
       P.pace(&P.trees[1].merkle);
+      ht.mark("trace_commit: paced (tree 1 at its top)");
     }
     P.tick("trace_commit");
 
@@ -611,7 +633,9 @@ struct SegmentProver {
         it0[c] = logs.size();
         for (int k = 0; k < air::component_info(c).n_interaction; k++) logs.push_back(clog[c]);
       }
+      ht.mark("interaction: entered");
       it_evals.alloc(logs, st);
+      ht.mark("interaction: columns allocated");
     }
     {
       tail_scratch.emplace_back(air::N_COMPONENTS * 16);
@@ -626,6 +650,7 @@ struct SegmentProver {
           small_max_log = std::max(small_max_log, clog[c]);
         }
       DevBuf d_small = upload(small_jobs, st);
+      ht.mark("interaction: small jobs uploaded");
       KProfRegion kreg("k_logup(region)", st);
       Fork fk(st);
       // Side streams of this region: every stream the join waits on is one barrier packet at the head of the main queue, ~5.5 us
@@ -648,6 +673,7 @@ struct SegmentProver {
       }
       fk.join();
       kreg.close();
+      ht.mark("interaction: logup launched + joined");
       hipStream_t sf = st;
       if (defer_tail) {
         sf = thread_side_stream(1);   // (side stream 0 is the pipeline's transform stream)
@@ -670,6 +696,7 @@ struct SegmentProver {
       sums_ready = ev_sums;
       late.ready = ev_sums;
     }
+    ht.mark("interaction: tail enqueued");
     P.tick("interaction_gen");
     // interpolate in place: coeffs alias the evaluation buffer (every size group right in front of its extension)
     {
@@ -678,6 +705,7 @@ struct SegmentProver {
       t.merkle.pace_ev = Prover::pace_event(2);
       P.commit_enqueue(t, nullptr, true, st, true, /*evals_in_place=*/true, P.pipe_stream(), defer_tail ? &late : nullptr);
     }
+    ht.mark("interaction: tree 2 enqueued");
     {
       CM_HIP(hipEventSynchronize(sums_ready));
       tail_scratch.clear();

@@ -11,6 +11,7 @@
 #include "proof.hpp"
 #include "kprof.hpp"
 #include <atomic>
+#include <array>
 #include <chrono>
 #include <memory>
 #include <map>
@@ -156,11 +157,14 @@ struct Prover {
                       bool evals_in_place = false, hipStream_t s_tr = nullptr, const DeferredCols* defer = nullptr) {
     static const bool pipe_on = !(getenv("CM_COMMIT_PIPE") && atoi(getenv("CM_COMMIT_PIPE")) == 0);
     if (!pipe_on || !with_merkle || s_tr == s) s_tr = nullptr;
-    const std::vector<uint32_t> logs = from_coeffs ? t.coeffs.logs : evals->logs;
+    const std::vector<uint32_t>& logs = from_coeffs ? t.coeffs.logs : evals->logs;
+    // (the host side of this function sits between two phases with the GPU idle: ~150 us for the 474 / 1036 columns of trees 1 / 2
+    // before the size groups were built once instead of three times and the small columns' 1 / n came from a table)
+    auto groups = by_log(logs);
     if (s_tr) {   // a tree of ONE large size group (composition, preprocessed-like trees) has nothing to overlap: two cross-queue
                   // hand-overs (~20 us each) for nothing — composition_commit 0.77 -> 0.81 ms when it went through the pipeline
       uint32_t big_groups = 0;
-      for (auto& kv : by_log(logs)) if (!small_commit_serves(kv.first, cfg.log_blowup_factor)) big_groups++;
+      for (auto& kv : groups) if (!small_commit_serves(kv.first, cfg.log_blowup_factor)) big_groups++;
       if (big_groups < 2) s_tr = nullptr;
     }
     UploadBatch ub;
@@ -173,7 +177,8 @@ struct Prover {
     struct Grp { uint32_t log, n; size_t off; uint32_t n_early; };
     std::vector<Grp> grps;
     std::vector<const uint32_t*> table;
-    for (auto& kv : by_log(logs)) {
+    table.reserve(3 * logs.size());
+    for (auto& kv : groups) {
       Grp g{kv.first, (uint32_t)kv.second.size(), table.size(), (uint32_t)kv.second.size()};
       if (defer)
         g.n_early = (uint32_t)(std::stable_partition(kv.second.begin(), kv.second.end(), [&](size_t i) { return !defer->late[i]; }) -
@@ -192,11 +197,17 @@ struct Prover {
     }
     // small columns of every size: ONE fused interpolate + extend launch for all of them (k_small_commit)
     std::vector<SmallCommitJob> sjobs;
+    sjobs.reserve(logs.size());
     uint32_t small_max = 0;
+    static const std::array<uint32_t, 31> inv_pow2 = [] {   // 1 / 2^k in M31 (a host inversion per small column was ~50 us per tree)
+      std::array<uint32_t, 31> a{};
+      for (uint32_t k = 0; k < 31; k++) a[k] = inv(M31::from_u32(1u << k)).v;
+      return a;
+    }();
     for (size_t i = 0; i < logs.size(); i++)
       if (small_commit_serves(logs[i], cfg.log_blowup_factor)) {
         const uint32_t* src = !from_coeffs ? evals->ptrs[i] : evals_in_place ? t.coeffs.ptrs[i] : nullptr;
-        sjobs.push_back(SmallCommitJob{src, t.coeffs.ptrs[i], t.lde.ptrs[i], logs[i], inv(M31::from_u32(1u << logs[i])).v});
+        sjobs.push_back(SmallCommitJob{src, t.coeffs.ptrs[i], t.lde.ptrs[i], logs[i], inv_pow2[logs[i]]});
         small_max = std::max(small_max, logs[i]);
       }
     SmallCommitJob* d_sjobs = nullptr;
