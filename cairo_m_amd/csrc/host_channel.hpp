@@ -35,6 +35,53 @@ struct LogRef {
   LogRef& operator=(const LogRef&) { return *this; }
 };
 
+#if defined(__x86_64__) && defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__) && !defined(CM_HOST_B2S_SCALAR)
+}  // namespace hostch
+}  // namespace cm
+#include <emmintrin.h>
+namespace cm {
+namespace hostch {
+// The four columns (then the four diagonals) of a round in one 128-bit register each (SSE2, part of every x86-64): the host mixes
+// ~20 KB of sampled values into the transcript with the GPU idle (mix_felts: 54 -> ~30 us), and the verifier hashes every
+// decommitted node.  Same function as the scalar form below (CM_HOST_B2S_SCALAR builds that one).
+inline void compress(uint32_t h[8], const uint32_t m[16], uint64_t t, uint32_t f0) {
+  static const uint8_t S[10][16] = {
+      {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+      {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+      {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+      {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+      {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+  const __m128i h0 = _mm_loadu_si128((const __m128i*)h), h1 = _mm_loadu_si128((const __m128i*)(h + 4));
+  __m128i a = h0, b = h1;
+  __m128i c = _mm_set_epi32((int)0xA54FF53Au, (int)0x3C6EF372u, (int)0xBB67AE85u, (int)0x6A09E667u);
+  __m128i d = _mm_set_epi32((int)0x5BE0CD19u, (int)(0x1F83D9ABu ^ f0), (int)(0x9B05688Cu ^ (uint32_t)(t >> 32)), (int)(0x510E527Fu ^ (uint32_t)t));
+#define CM_HB_ROT(x, n) _mm_or_si128(_mm_srli_epi32(x, n), _mm_slli_epi32(x, 32 - (n)))
+#define CM_HB_G(x, y)                                                                  \
+  a = _mm_add_epi32(_mm_add_epi32(a, b), x); d = _mm_xor_si128(d, a); d = CM_HB_ROT(d, 16); \
+  c = _mm_add_epi32(c, d); b = _mm_xor_si128(b, c); b = CM_HB_ROT(b, 12);                  \
+  a = _mm_add_epi32(_mm_add_epi32(a, b), y); d = _mm_xor_si128(d, a); d = CM_HB_ROT(d, 8);  \
+  c = _mm_add_epi32(c, d); b = _mm_xor_si128(b, c); b = CM_HB_ROT(b, 7);
+  for (int r = 0; r < 10; r++) {
+    const uint8_t* s = S[r];
+    __m128i x = _mm_set_epi32((int)m[s[6]], (int)m[s[4]], (int)m[s[2]], (int)m[s[0]]);
+    __m128i y = _mm_set_epi32((int)m[s[7]], (int)m[s[5]], (int)m[s[3]], (int)m[s[1]]);
+    CM_HB_G(x, y)
+    b = _mm_shuffle_epi32(b, _MM_SHUFFLE(0, 3, 2, 1));   // diagonals: lane i takes b[i+1], c[i+2], d[i+3]
+    c = _mm_shuffle_epi32(c, _MM_SHUFFLE(1, 0, 3, 2));
+    d = _mm_shuffle_epi32(d, _MM_SHUFFLE(2, 1, 0, 3));
+    x = _mm_set_epi32((int)m[s[14]], (int)m[s[12]], (int)m[s[10]], (int)m[s[8]]);
+    y = _mm_set_epi32((int)m[s[15]], (int)m[s[13]], (int)m[s[11]], (int)m[s[9]]);
+    CM_HB_G(x, y)
+    b = _mm_shuffle_epi32(b, _MM_SHUFFLE(2, 1, 0, 3));
+    c = _mm_shuffle_epi32(c, _MM_SHUFFLE(1, 0, 3, 2));
+    d = _mm_shuffle_epi32(d, _MM_SHUFFLE(0, 3, 2, 1));
+  }
+#undef CM_HB_G
+#undef CM_HB_ROT
+  _mm_storeu_si128((__m128i*)h, _mm_xor_si128(h0, _mm_xor_si128(a, c)));
+  _mm_storeu_si128((__m128i*)(h + 4), _mm_xor_si128(h1, _mm_xor_si128(b, d)));
+}
+#else
 inline void compress(uint32_t h[8], const uint32_t m[16], uint64_t t, uint32_t f0) {
   static const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
   static const uint8_t S[10][16] = {
@@ -60,6 +107,7 @@ inline void compress(uint32_t h[8], const uint32_t m[16], uint64_t t, uint32_t f
   }
   for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
 }
+#endif
 inline Hash32 blake2s256(const uint8_t* data, size_t len) {
   uint32_t h[8] = {0x6A09E667u ^ 0x01010020u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
   uint64_t t = 0;
