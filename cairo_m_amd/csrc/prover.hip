@@ -559,8 +559,10 @@ struct SegmentProver {
       // on side stream 7 the whole tree sat BEHIND the transforms of tree 1 (same queue as the pipeline stream) and its Merkle
       // chain ran alone after tree 1 had finished (0.17 ms of a nearly idle GPU, and the host learnt root 0 only then).  A stream
       // of the highest priority class has hardware queues of its own.  CM_TREE0_PRIO=0: the side stream (A/B), 1: lowest class.
+      // A lone proof only: with several proofs in flight (cm_prove_many) the other proofs' kernels fill the queues anyway, and
+      // four high-priority chains cutting into them cost 0.5-1 ms per proof (9.6 -> 10.1-10.8 with four in flight).
       static const int t0_prio = getenv("CM_TREE0_PRIO") ? atoi(getenv("CM_TREE0_PRIO")) : -1;
-      if (t0_prio != 0) {
+      if (t0_prio != 0 && g_proofs_in_flight.load(std::memory_order_relaxed) <= 1) {
         tree0_stream = thread_priority_stream(t0_prio);
         hipEvent_t e = Prover::pipe_event();
         CM_HIP(hipEventRecord(e, st));                       // trace generation launched, twiddles joined
