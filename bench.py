@@ -365,7 +365,8 @@ def main():
     if world == 1 and args.pipelined > 1:
         # SURVEY §8f-4 segment pipeline: continuation segments are independent proofs, so several can be in
         # flight on one GPU (one host thread each); their launch gaps and host round trips overlap.
-        n_pipe = 4 * args.pipelined
+        n_pipe = 8 * args.pipelined   # like the streamed legs below: enough proofs that the fill and the drain of the pipeline
+                                      # (the last proofs run with fewer neighbours) stay below ~2 % of the figure
         for p in be.prove_many([dev] * args.pipelined, inflight=args.pipelined):   # every worker warms its own pool
             p.free()
         torch.cuda.synchronize()
