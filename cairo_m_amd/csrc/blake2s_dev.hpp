@@ -72,6 +72,26 @@ __device__ __forceinline__ void b2s_compress(uint32_t (&h)[8], const uint32_t (&
   h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
 }
 
+// mix_u64 of the channel whose digest is `dg` (framing.hpp switch `mix_u64`): U32S = false -> the raw compression
+// F(digest, [lo, hi, 0...], t = 0, f = 0); U32S = true -> Blake2s256(digest || le32(lo) || le32(hi)), one final 40-byte block
+template <bool U32S>
+__device__ __forceinline__ void mix_u64_dev(const uint32_t (&dg)[8], uint64_t v, uint32_t (&h)[8]) {
+  uint32_t m[16] = {0};
+  if (U32S) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) m[k] = dg[k];
+    m[8] = (uint32_t)v; m[9] = (uint32_t)(v >> 32);
+    h[0] = 0x6A09E667u ^ 0x01010020u; h[1] = 0xBB67AE85u; h[2] = 0x3C6EF372u; h[3] = 0xA54FF53Au;
+    h[4] = 0x510E527Fu; h[5] = 0x9B05688Cu; h[6] = 0x1F83D9ABu; h[7] = 0x5BE0CD19u;
+    b2s_compress(h, m, 40, 0xFFFFFFFFu);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = dg[k];
+    m[0] = (uint32_t)v; m[1] = (uint32_t)(v >> 32);
+    b2s_compress(h, m);
+  }
+}
+
 // ---- quad-lane compression: one Blake2s state spread over 4 adjacent lanes ----------------------------------
 // Wide-and-short Merkle layers (few nodes, hundreds of columns) and the top levels of every tree are one
 // sequential compression chain per node; with one node per lane a lone wave needs ~2.7 us per compression.

@@ -217,6 +217,7 @@ struct DevBuf {
 // Device->host results land in a per-thread pinned buffer: truly asynchronous (pool.hip).  Valid after the stream is
 // synchronised and until the next call on this thread.
 const void* stage_download_async(const void* src, size_t bytes, hipStream_t st);
+void* stage_landing(size_t bytes, hipStream_t st);   // the buffer alone (>= bytes): the caller enqueues its own copies into it
 // 1024 pinned words per host thread; fixed slots (words): 0 range-check flag, 2-3 grind nonce, 8-15 Merkle root,
 // 16-23 root of tree 0, 32-167 claimed sums, 172-175 random coefficient + 176-183 root of tree 2 (one copy), 208-219 the OODS felt + root 3 of the device-side step, 256-351 FRI challenges, 384-575 FRI roots, 640-1023 last FRI layer
 uint32_t* pinned_words();

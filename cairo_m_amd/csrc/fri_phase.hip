@@ -7,8 +7,8 @@
 
 namespace cm {
 
-void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
-                      const std::function<void()>& while_gpu_busy, const FriResume* resume) {
+void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs,
+                              const FriResume* resume) {
   hipStream_t st = P.st;
   Channel& ch = P.ch;
   // ---- FRI commit ----
@@ -21,7 +21,8 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
   if (resume) { have_first = false; inner_fold0 = 1 + resume->n_inner_before; }
   const uint32_t n_inner = layer_log > last_log ? layer_log - last_log : 0;
   // challenges and roots share one buffer ({alphas | roots}: they come back in ONE copy at the end)
-  DevBuf d_ar((size_t)(n_inner + 1) * 48);
+  d_ar.alloc((size_t)(n_inner + 1) * 48);
+  n_inner_ = n_inner; last_log_ = last_log; resumed_ = resume != nullptr;
   struct Words { uint32_t* p; uint32_t* u32() const { return p; } };
   const Words d_alphas{d_ar.u32()}, d_roots{d_ar.u32() + (size_t)(n_inner + 1) * 4};
   Words d_chan{nullptr};   // the device copy of the channel {digest[8], n_sent}: travels with the tree tables (one upload)
@@ -31,7 +32,6 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
   // every layer above the single-launch tail is allocated up front so that the column tables of all their
   // Merkle trees (and of the first-layer tree) travel in ONE host->device copy
   std::vector<std::unique_ptr<InnerLayer>> pre;
-  DevBuf fri_tables;
   {
     UploadBatch ub;
     std::vector<const uint32_t*> cols;
@@ -62,7 +62,8 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
       stage_upload(d_alphas.p, a4, sizeof(a4), st);   // slot 0 = the circle-fold challenge, as after a first-layer step
     }
   }
-  ColumnSet layer;
+  ColumnSet& layer = last_layer;
+  layer = ColumnSet();
   const bool resumed_layer = resume && resume->layer;
   bool layer_is_blank = !pre.empty() && !resumed_layer;   // pre[0] is written (not accumulated into) by the first circle fold: no memset
   if (pre.empty()) {
@@ -172,9 +173,19 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
     pi++;
   }
   CM_CHECK(qi == quotients.size(), "fri: not every quotient column was folded");
-  while_gpu_busy();   // host-only work of the caller, overlapped with the quotient / FRI kernels enqueued above
+  d_chan_ = d_chan.u32();
+}
 
-  // last layer (2^last_log values): interpolate on the host, keep 2^log_last_layer coefficients
+// The host's half of the commit phase: challenges, roots and the last layer come back, the transcript steps are replayed and
+// cross-checked, the last layer is interpolated (LinePoly) and mixed into the channel.  `from_pinned`: the device-side tail
+// (k_tail_last, tail_device.hpp) has already left all three in the calling thread's pinned words and the caller has
+// synchronised the stream.
+void FriPhase::commit_finish(Prover& P, const cm_pcs_config& cfg, ProofData& pf, bool from_pinned) {
+  hipStream_t st = P.st;
+  Channel& ch = P.ch;
+  const uint32_t n_inner = n_inner_, last_log = last_log_;
+  const bool resume = resumed_;
+  ColumnSet& layer = last_layer;
   {
     uint32_t n = 1u << last_log;
     const uint32_t* c4[4] = {layer.ptrs[0], layer.ptrs[1], layer.ptrs[2], layer.ptrs[3]};
@@ -186,12 +197,15 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
     CM_CHECK((n_inner + 1) * 12 <= PIN_LAST_LAYER - PIN_ALPHAS, "fri: too many layers");
     const uint32_t* h_alphas = pinned_words() + PIN_ALPHAS;
     const uint32_t* h_roots = h_alphas + (size_t)(n_inner + 1) * 4;
-    CM_HIP(hipMemcpyAsync((void*)h_alphas, d_ar.p, (size_t)(n_inner + 1) * 48, hipMemcpyDeviceToHost, st));
-    if (4 * n <= PIN_WORDS - PIN_LAST_LAYER) {
+    if (!from_pinned) CM_HIP(hipMemcpyAsync((void*)h_alphas, d_ar.p, (size_t)(n_inner + 1) * 48, hipMemcpyDeviceToHost, st));
+    if (from_pinned || 4 * n <= PIN_WORDS - PIN_LAST_LAYER) {
+      CM_CHECK(4 * n <= PIN_WORDS - PIN_LAST_LAYER, "fri: last layer does not fit the pinned slot");
       uint32_t* ll = pinned_words() + PIN_LAST_LAYER;
-      if (c4[1] == c4[0] + n && c4[2] == c4[0] + 2 * n && c4[3] == c4[0] + 3 * n) CM_HIP(hipMemcpyAsync(ll, c4[0], n * 16, hipMemcpyDeviceToHost, st));   // one arena
-      else for (int k = 0; k < 4; k++) CM_HIP(hipMemcpyAsync(ll + k * n, c4[k], n * 4, hipMemcpyDeviceToHost, st));
-      CM_HIP(hipStreamSynchronize(st));
+      if (!from_pinned) {
+        if (c4[1] == c4[0] + n && c4[2] == c4[0] + 2 * n && c4[3] == c4[0] + 3 * n) CM_HIP(hipMemcpyAsync(ll, c4[0], n * 16, hipMemcpyDeviceToHost, st));   // one arena
+        else for (int k = 0; k < 4; k++) CM_HIP(hipMemcpyAsync(ll + k * n, c4[k], n * 4, hipMemcpyDeviceToHost, st));
+        CM_HIP(hipStreamSynchronize(st));
+      }
       for (uint32_t i = 0; i < n; i++) {
         uint32_t w4[4] = {ll[i], ll[n + i], ll[2 * n + i], ll[3 * n + i]};
         vals.push_back(QM31::from_u32(w4));
@@ -239,6 +253,7 @@ void FriPhase::commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet
     pf.last_layer_log_size = cfg.log_last_layer_degree_bound;
     ch.mix_felts(pf.last_layer_poly.data(), pf.last_layer_poly.size());
   }
+  d_ar.release();
 }
 
 }  // namespace cm

@@ -4,6 +4,7 @@
 // hashes per proof) and inherently sequential, so it stays on the host; the heavy hashing (Merkle
 // layers, proof-of-work search) runs in kernels_hash.hip.
 #pragma once
+#include <algorithm>
 #include <stdint.h>
 #include <string.h>
 #include <array>
@@ -130,6 +131,43 @@ inline Hash32 blake2s256(const uint8_t* data, size_t len) {
   return out;
 }
 
+// Blake2s-256 over a message that arrives in pieces (same digest as blake2s256 over the concatenation)
+struct Blake2sStream {
+  uint32_t h[8];
+  uint64_t t = 0;
+  uint8_t buf[64];
+  size_t fill = 0;
+  Blake2sStream() {
+    static const uint32_t iv[8] = {0x6A09E667u ^ 0x01010020u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+    memcpy(h, iv, 32);
+  }
+  void update(const void* data, size_t len) {
+    const uint8_t* p = (const uint8_t*)data;
+    uint32_t m[16];
+    while (len) {
+      if (fill == 64) {   // a full buffer is only compressed once more input follows (the last block carries the final flag)
+        memcpy(m, buf, 64);
+        t += 64;
+        compress(h, m, t, 0);
+        fill = 0;
+      }
+      const size_t take = std::min(len, 64 - fill);
+      memcpy(buf + fill, p, take);
+      fill += take; p += take; len -= take;
+    }
+  }
+  Hash32 finish() {
+    uint32_t m[16];
+    if (fill < 64) memset(buf + fill, 0, 64 - fill);
+    memcpy(m, buf, 64);
+    t += fill;
+    compress(h, m, t, 0xFFFFFFFFu);
+    Hash32 out;
+    memcpy(out.data(), h, 32);
+    return out;
+  }
+};
+
 struct Channel {
   Hash32 digest{};
   uint32_t n_challenges = 0, n_sent = 0;
@@ -162,6 +200,29 @@ struct Channel {
     for (size_t i = 0; i < n; i++) f[i].to_u32(&w[4 * i]);
     absorb_u32s(w.data(), w.size());
     note("mix_felts", w.data(), w.size());
+  }
+  // mix_felts over felts that arrive in pieces (the OODS values come back from the GPU in two parts and the first is hashed
+  // while the second is still being computed): begin, update ..., end == one mix_felts over the concatenation
+  struct FeltMixer { Blake2sStream st; size_t n_words = 0; uint32_t first[16]; };
+  void mix_felts_begin(FeltMixer& fm) const { fm.st.update(digest.data(), 32); }
+  void mix_felts_update(FeltMixer& fm, const QM31* f, size_t n) const {
+    uint32_t w[64];
+    for (size_t i = 0; i < n;) {
+      const size_t c = std::min<size_t>(16, n - i);
+      for (size_t k = 0; k < c; k++) f[i + k].to_u32(&w[4 * k]);
+      for (size_t k = 0; k < 4 * c && fm.n_words + k < 16; k++) fm.first[fm.n_words + k] = w[k];
+      fm.st.update(w, 16 * c);
+      fm.n_words += 4 * c;
+      i += c;
+    }
+  }
+  void mix_felts_end(FeltMixer& fm) {
+    update(fm.st.finish());
+    if (log.p) {
+      TranscriptEntry e{"mix_felts", digest, (uint32_t)fm.n_words, {}};
+      e.words.assign(fm.first, fm.first + (fm.n_words < 16 ? fm.n_words : 16));
+      log.p->push_back(std::move(e));
+    }
   }
   // framing switch `mix_u64` (framing.hpp): raw compression F(digest, [lo, hi, 0...], t=0, f=0) — the form Stwo's SIMD grind
   // searches over — or mix_u32s(&[lo, hi])

@@ -3,6 +3,7 @@
 // zero hipMalloc/hipFree calls; cm_shutdown()/pool_trim() hands everything back.
 #include <algorithm>
 #include "engine.hpp"
+#include "tail_device.hpp"
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -185,6 +186,8 @@ Landing& landing() {
   return *l;
 }
 }  // namespace
+// the landing buffer itself (>= bytes), for callers that fill it with several copies
+void* stage_landing(size_t bytes, hipStream_t st) { return const_cast<void*>(stage_download_async(nullptr, bytes ? bytes : 1, st)); }
 const void* stage_download_async(const void* src, size_t bytes, hipStream_t st) {
   Landing& l = landing();
   if (bytes > l.cap) {
@@ -192,9 +195,33 @@ const void* stage_download_async(const void* src, size_t bytes, hipStream_t st) 
     l.cap = std::max(bytes * 2, (size_t)1 << 20);
     CM_HIP(hipHostMalloc((void**)&l.base, l.cap, hipHostMallocDefault));
   }
-  if (bytes) CM_HIP(hipMemcpyAsync(l.base, src, bytes, hipMemcpyDeviceToHost, st));
+  if (bytes && src) CM_HIP(hipMemcpyAsync(l.base, src, bytes, hipMemcpyDeviceToHost, st));
   return l.base;
 }
+
+// Pinned buffers of the device-side proof tail (tail_device.hpp), one pair per host thread, grown on demand: the kernels read
+// the decommitment descriptors from the first and write the witnesses into the second (no copy command in the tail).
+namespace {
+struct TailPinned { uint8_t* base[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0}; };
+void* tail_pinned(int which, size_t bytes) {
+  static thread_local TailPinned* t = nullptr;
+  if (!t) {
+    t = new TailPinned();
+    TailPinned* own = t;
+    at_thread_exit([own] { for (int i = 0; i < 2; i++) if (own->base[i]) (void)hipHostFree(own->base[i]); delete own; });
+  }
+  if (bytes > t->cap[which]) {
+    // (a proof ends with a synchronised stream: nothing of the previous proof still reads or writes the old buffer)
+    if (t->base[which]) { CM_HIP(hipDeviceSynchronize()); CM_HIP(hipHostFree(t->base[which])); t->base[which] = nullptr; t->cap[which] = 0; }
+    const size_t cap = std::max(bytes + bytes / 2, (size_t)1 << 16);
+    CM_HIP(hipHostMalloc((void**)&t->base[which], cap, hipHostMallocDefault));
+    t->cap[which] = cap;
+  }
+  return t->base[which];
+}
+}  // namespace
+void* tail_pinned_desc(size_t bytes) { return tail_pinned(0, bytes); }
+void* tail_pinned_out(size_t bytes) { return tail_pinned(1, bytes); }
 
 // 1024 pinned words per host thread for the small fixed-slot results of a proof (flag, nonce, roots, claimed sums,
 // FRI challenges): copies into pageable memory block the caller and cost 15-25 us each

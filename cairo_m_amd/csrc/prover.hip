@@ -10,6 +10,7 @@
 #include "point_eval.hpp"
 #include "host_adapter.hpp"
 #include "shard_kernels.hpp"
+#include "tail_plan.hpp"
 #include <atomic>
 #include <chrono>
 #include <deque>
@@ -328,6 +329,7 @@ static int fork_width(int dflt) {
 }
 // =========================================================================================================
 // CM_HOST_TRACE=1: host-side time between marks on stderr (where the GPU sits idle waiting for the host)
+constexpr uint32_t OODS_SPLIT_DEFAULT = 780;   // per mille of the sampled values in the chunk evaluated (and hashed) first; A/B: CM_OODS_SPLIT
 struct HostTrace {
   bool on = getenv("CM_HOST_TRACE") != nullptr || getenv("CM_HOST_MARKS") != nullptr;   // MARKS: no synchronising ticks
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -372,9 +374,10 @@ struct SegmentProver {
   std::vector<ColumnSet> quotients;
   FriPhase fri;
   struct ORef { int t; uint32_t c; bool prev; };
-  struct OJob { uint32_t log; bool prev; CPoint<QM31> pt; std::vector<ORef> refs; size_t off = 0, out_off = 0; };
+  struct OJob { uint32_t log; bool prev; CPoint<QM31> pt; std::vector<ORef> refs; size_t off = 0, out_off = 0; int chunk = 0; };
   std::vector<OJob> ojobs;                    // sampling jobs, built (and their pointer table uploaded) by oods_prepare()
   size_t n_oods_out = 0;
+  size_t n_oods_out0 = 0, n_flat0 = 0;       // sampled values / flat samples of chunk 0 (the part hashed while chunk 1 is evaluated)
   struct QRef { int t; uint32_t c; };
   struct QEntry { uint32_t col; uint32_t sidx; };   // column of the group, index of its sampled value in d_oods_out
   struct QBatch { CPoint<QM31> pt; std::vector<QEntry> entries; };
@@ -971,16 +974,35 @@ struct SegmentProver {
     ojobs.clear();
     n_oods_out = 0;
     {
-      std::map<uint32_t, std::vector<ORef>> groups;
-      for (int t = 0; t < 4; t++)
-        for (uint32_t c = 0; c < P.trees[t].coeffs.size(); c++) groups[P.trees[t].coeffs.logs[c]].push_back({t, c, false});
-      for (auto& kv : groups) ojobs.push_back(OJob{kv.first, false, {}, kv.second});
-      std::map<uint32_t, std::vector<ORef>> pgroups;
+      // Two chunks in the transcript's flat order (tree, column, mask): the sampled values of chunk 0 come back first and the
+      // host hashes them (channel.mix_felts, ~0.1 ms of sequential Blake2s over ~30 KB) while the GPU evaluates chunk 1 — the
+      // split makes the two take about as long (CM_OODS_SPLIT: per mille of the samples in chunk 0; 1000 = one chunk)
+      static const uint32_t split_pm = getenv("CM_OODS_SPLIT") ? (uint32_t)atoi(getenv("CM_OODS_SPLIT")) : OODS_SPLIT_DEFAULT;
+      std::vector<std::vector<char>> has_prev(4);
+      size_t total = 0;
+      for (int t = 0; t < 4; t++) { has_prev[t].assign(P.trees[t].coeffs.size(), 0); total += P.trees[t].coeffs.size(); }
       for (int c = 0; c < air::N_COMPONENTS; c++) {
-        int ni = air::component_info(c).n_interaction;
-        for (int k = ni - 4; k < ni; k++) pgroups[clog[c]].push_back({2, (uint32_t)(it0[c] + k), true});
+        const int ni = air::component_info(c).n_interaction;
+        for (int k = ni - 4; k < ni; k++) { has_prev[2][it0[c] + k] = 1; total++; }
       }
-      for (auto& kv : pgroups) ojobs.push_back(OJob{kv.first, true, {}, kv.second});
+      const size_t split = split_pm >= 1000 ? total : total * split_pm / 1000;
+      std::map<std::tuple<int, bool, uint32_t>, std::vector<ORef>> groups;   // (chunk, previous-row mask, log size)
+      size_t cum = 0;
+      n_flat0 = 0;
+      for (int t = 0; t < 4; t++)
+        for (uint32_t c = 0; c < P.trees[t].coeffs.size(); c++) {
+          const int chunk = cum < split ? 0 : 1;
+          const uint32_t log = P.trees[t].coeffs.logs[c];
+          if (has_prev[t][c]) groups[{chunk, true, log}].push_back({t, c, true});
+          groups[{chunk, false, log}].push_back({t, c, false});
+          cum += has_prev[t][c] ? 2 : 1;
+          if (chunk == 0) n_flat0 = cum;
+        }
+      for (auto& kv : groups) {
+        OJob j{std::get<2>(kv.first), std::get<1>(kv.first), {}, kv.second};
+        j.chunk = std::get<0>(kv.first);
+        ojobs.push_back(std::move(j));
+      }
     }
     {
       std::vector<const uint32_t*> table;
@@ -989,6 +1011,7 @@ struct SegmentProver {
         j.out_off = n_oods_out;
         for (auto& r : j.refs) table.push_back(P.trees[r.t].coeffs.ptrs[r.c]);
         n_oods_out += j.refs.size();
+        if (j.chunk == 0) n_oods_out0 = n_oods_out;
       }
       d_oods_table = upload(table, st);
       d_oods_out.alloc(n_oods_out * 16);
@@ -1012,7 +1035,8 @@ struct SegmentProver {
     // start without the host having seen root 3 (it used to cost the host replay + the launches: ~60 us of idle GPU).  The host
     // replays the same steps when root 3 arrives and checks the drawn felt.
     static const bool dev_oods = getenv("CM_HOST_OODS") == nullptr;
-    static thread_local hipEvent_t ev_root3 = nullptr;
+    static thread_local hipEvent_t ev_root3 = nullptr, ev_chunk0 = nullptr;
+    bool chunk0_event = false;
     if (dev_oods) P.tick("composition_commit");
     const uint32_t* oods_w = nullptr;
     DevBuf d_step3;
@@ -1024,17 +1048,27 @@ struct SegmentProver {
       CM_HIP(hipMemcpyAsync(pinned_words() + PIN_STEP3, d_step3.p, 48, hipMemcpyDeviceToHost, st));   // {felt[4], root 3 [8]}: one copy
       if (!ev_root3) { CM_HIP(hipEventCreateWithFlags(&ev_root3, hipEventDisableTiming)); thread_event_owned(ev_root3); }
       CM_HIP(hipEventRecord(ev_root3, st));
-      std::vector<EapJob> ej;
+      std::vector<EapJob> ej[2];
       for (auto& j : ojobs) {
         EapJob e{j.log, (uint32_t)j.refs.size(), d_oods_table.as<const uint32_t*>() + j.off, QM31(), QM31(), d_oods_out.u32() + 4 * j.out_off};
         if (j.prev) {
           CPoint<M31> step = point_at_index(subgroup_gen_index(j.log));
           e.has_shift = true; e.shift_x = step.x.v; e.shift_y = (-step.y).v;
         }
-        ej.push_back(e);
+        ej[j.chunk].push_back(e);
       }
-      eval_at_point_multi(ej, st, d_step3.u32());
-      oods_w = (const uint32_t*)stage_download_async(d_oods_out.p, n_oods_out * 16, st);
+      // chunk 0, its values to the host, chunk 1, its values (one pinned landing buffer, two copies)
+      uint8_t* land = (uint8_t*)stage_landing(n_oods_out * 16, st);
+      oods_w = (const uint32_t*)land;
+      eval_at_point_multi(ej[0], st, d_step3.u32());
+      if (n_oods_out0) CM_HIP(hipMemcpyAsync(land, d_oods_out.p, n_oods_out0 * 16, hipMemcpyDeviceToHost, st));
+      if (!ej[1].empty()) {
+        if (!ev_chunk0) { CM_HIP(hipEventCreateWithFlags(&ev_chunk0, hipEventDisableTiming)); thread_event_owned(ev_chunk0); }
+        CM_HIP(hipEventRecord(ev_chunk0, st));
+        chunk0_event = true;
+        eval_at_point_multi(ej[1], st, d_step3.u32());
+        CM_HIP(hipMemcpyAsync(land + n_oods_out0 * 16, d_oods_out.as<uint8_t>() + n_oods_out0 * 16, (n_oods_out - n_oods_out0) * 16, hipMemcpyDeviceToHost, st));
+      }
     }
     // ONE round trip for two roots: root 3 is waited for; root 2 and the random coefficient of the device-side step are
     // already in pinned memory.  Host replay in transcript order.
@@ -1166,19 +1200,46 @@ struct SegmentProver {
         stage_upload(d_qblob.p, qblob.data(), qblob.size(), st);
       }
       ht.mark("oods: overlapped quotient planning");
-      CM_HIP(hipStreamSynchronize(st));
-      ht.mark("oods: waited for gpu");
-      for (auto& j : jobs)
-        for (size_t i = 0; i < j.refs.size(); i++) {
-          auto& sv = pf.sampled_values[j.refs[i].t][j.refs[i].c];
-          (j.refs[i].prev ? sv.front() : sv.back()) = QM31::from_u32(&w[4 * (j.out_off + i)]);
-        }
+      // channel.mix_felts(flattened sampled values): chunk 0 is hashed as soon as it has landed, while chunk 1 is evaluated
+      Channel::FeltMixer fm;
+      ch.mix_felts_begin(fm);
       std::vector<QM31> flat;
       flat.reserve(n_samples);
-      for (auto& t : pf.sampled_values) for (auto& c : t) for (auto& sm : c) flat.push_back(sm);
-      ht.mark("oods: fill + flatten");
-      ch.mix_felts(flat.data(), flat.size());
-      ht.mark("oods: mix_felts");
+      auto fill = [&](int chunk) {
+        for (auto& j : jobs)
+          if (j.chunk == chunk)
+            for (size_t i = 0; i < j.refs.size(); i++) {
+              auto& sv = pf.sampled_values[j.refs[i].t][j.refs[i].c];
+              (j.refs[i].prev ? sv.front() : sv.back()) = QM31::from_u32(&w[4 * (j.out_off + i)]);
+            }
+      };
+      size_t ft = 0, fc = 0, n_mixed = 0;   // cursor of the flat order: (tree, column)
+      auto mix_upto = [&](size_t n_flat) {
+        flat.clear();
+        while (ft < 4 && n_mixed + flat.size() < n_flat) {
+          auto& tr = pf.sampled_values[ft];
+          if (fc == tr.size()) { ft++; fc = 0; continue; }
+          for (auto& sm : tr[fc]) flat.push_back(sm);
+          fc++;
+        }
+        ch.mix_felts_update(fm, flat.data(), flat.size());
+        n_mixed += flat.size();
+      };
+      if (chunk0_event) {
+        CM_HIP(hipEventSynchronize(ev_chunk0));
+        ht.mark("oods: chunk 0 landed");
+        fill(0);
+        mix_upto(n_flat0);
+        ht.mark("oods: chunk 0 filled + mixed");
+      }
+      CM_HIP(hipStreamSynchronize(st));
+      ht.mark("oods: waited for gpu");
+      if (!chunk0_event) fill(0);
+      fill(1);
+      mix_upto(n_samples);
+      CM_CHECK(n_mixed == n_samples, "oods: flat sample count");
+      ch.mix_felts_end(fm);
+      ht.mark("oods: fill + mix_felts");
     }
     P.tick("oods_sampling");
   }
@@ -1224,16 +1285,38 @@ struct SegmentProver {
 
   }
 
-  // FRI commit phase (FriPhase) and proof of work
+  // FRI commit phase (FriPhase), proof of work, and — device-side tail (tail_device.hpp) — the whole rest of the proof
+  DeviceTail tail;
+  bool tail_done = false;
   void fri_and_pow() {
     // ---- FRI commit (FriPhase::commit) ----
-    fri.commit(P, cfg, quotients, q_logs, pf, [&] {
-      check_composition_at_oods(pf, tr0, it0, clog, hrel, powers, coff, oods);
-    });
-    P.tick("fri_commit");
+    fri.commit_enqueue(P, cfg, quotients, q_logs);
+    const bool dev_tail = DeviceTail::supported(cfg, q_logs, fri);
+    // last layer -> PoW -> queries -> decommitment of every tree, enqueued behind the last fold: no host round trip
+    if (dev_tail) tail.enqueue(P, fri, quotients, q_logs);
+    check_composition_at_oods(pf, tr0, it0, clog, hrel, powers, coff, oods);   // host-only, overlapped with the kernels enqueued above
+    ht.mark("fri: enqueued, oods check done");
+    if (dev_tail) {
+      CM_HIP(hipStreamSynchronize(st));
+      ht.mark("tail: gpu done");
+      fri.commit_finish(P, cfg, pf, true);
+      if (tail.nonce_found()) {
+        pf.proof_of_work = tail.nonce();
+        ch.mix_u64(pf.proof_of_work);
+        CM_CHECK(ch.trailing_zeros() >= cfg.pow_bits, "pow: the device's nonce fails the host's check");
+        tail_done = true;
+        ht.mark("tail: host replay");
+        return;
+      }
+      // (no nonce within 16x the expected range, probability e^-16: search on with the host-driven form; the decommitment
+      // the device made from nothing is discarded)
+    } else {
+      fri.commit_finish(P, cfg, pf, false);
+      P.tick("fri_commit");
+    }
     pf.proof_of_work = grind_gpu(ch.digest.data(), cfg.pow_bits, st);
     ch.mix_u64(pf.proof_of_work);
-    P.tick("pow");
+    if (!dev_tail) P.tick("pow");
     ht.mark("pow done");
 
   }
@@ -1243,6 +1326,12 @@ struct SegmentProver {
     // ---- queries + decommitment ----
     Queries queries = Queries::draw(ch, cfg.n_queries, q_logs[0]);
     ht.mark("decommit: queries drawn");
+    if (tail_done) {   // the witnesses are already in pinned memory, in proof order
+      tail.finish(P, fri, queries, pf, [&](const char* w) { ht.mark(w); });
+      ht.mark("decommit: distributed the device tail's witnesses");
+      return;
+    }
+    const bool ticked = tail.enqueued;   // (device tail without a nonce: its phase events are already in the stream)
     std::map<uint32_t, std::vector<uint32_t>> qpos;
     for (auto l : q_logs) qpos[l] = queries.fold(queries.log_domain_size - l).positions;
     ht.mark("decommit: qpos");
@@ -1273,7 +1362,7 @@ struct SegmentProver {
       ht.mark("decommit: finish trees");
     }
     ht.mark("decommit: finish (locals released)");
-    P.tick("decommit");
+    if (!ticked) P.tick("decommit");
   }
 };
 ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) { return SegmentProver(din, cfg).run(); }
@@ -1829,6 +1918,22 @@ int32_t cm_kprof_enable(int32_t on) {
 int32_t cm_set_preprocessed_cache(int32_t on) {
   cm::g_pp_cache.store(on ? 1 : 0, std::memory_order_relaxed);
   return 0;
+}
+int32_t cm_set_device_tail(int32_t on) {
+  cm::g_device_tail.store(on ? 1 : 0);
+  return 0;
+}
+int32_t cm_tail_list(const uint32_t* positions, uint32_t n_positions, uint32_t log_domain, uint32_t qmask, uint32_t list, uint32_t k,
+                     uint32_t* out, uint32_t cap, uint32_t* n_out) {
+  return pguard([&] {
+    CM_CHECK(log_domain < cm::TAIL_MAX_SHIFTS && k <= log_domain && list <= 2, "cm_tail_list: bad arguments");
+    cm::TailTables tt;
+    tt.build(std::vector<uint32_t>(positions, positions + n_positions), log_domain, qmask);
+    const uint32_t* v = tt.list(list, k);
+    const uint32_t nv = tt.cnt[list][k];
+    for (uint32_t i = 0; i < nv && i < cap; i++) out[i] = v[i];
+    *n_out = nv;
+  });
 }
 int32_t cm_set_twiddle_cache(int32_t on) {
   cm::g_tw_cache.store(on ? 1 : 0, std::memory_order_relaxed);

@@ -447,7 +447,21 @@ struct FriPhase {
   bool have_first = true;       // false after a resumed commit: no first-layer tree here
   uint32_t inner_fold0 = 1;     // folds between the query domain and inner[0]
   void commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
-              const std::function<void()>& while_gpu_busy, const FriResume* resume = nullptr);
+              const std::function<void()>& while_gpu_busy, const FriResume* resume = nullptr) {
+    commit_enqueue(P, cfg, quotients, q_logs, resume);
+    while_gpu_busy();   // host-only work of the caller, overlapped with the quotient / FRI kernels enqueued above
+    commit_finish(P, cfg, pf, false);
+  }
+  // the two halves of commit(): everything the GPU does (no host round trip), then the host's replay of the transcript steps and
+  // the last layer.  Between them the single-GPU prover enqueues the device-side tail of the proof (tail_device.hpp).
+  void commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs,
+                      const FriResume* resume = nullptr);
+  void commit_finish(Prover& P, const cm_pcs_config& cfg, ProofData& pf, bool from_pinned);
+  DevBuf d_ar, fri_tables;        // {challenges | roots} of the commit phase; the trees' column tables + the device channel
+  ColumnSet last_layer;           // evaluations of the last layer (2^last_log_ values)
+  uint32_t n_inner_ = 0, last_log_ = 0;
+  bool resumed_ = false;
+  uint32_t* d_chan_ = nullptr;    // device copy of the channel {digest[8], n_sent} (inside fri_tables)
   // Decommitment of the FRI trees (first layer over the quotient columns, then one tree per inner layer): decommitment
   // positions + witness evaluations of every layer are requested through the caller's GatherBatch (one gather launch for the
   // whole proof), finish_decommit() distributes what came back.

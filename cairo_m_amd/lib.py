@@ -569,6 +569,7 @@ def _backend_set_preprocessed_cache(self, on):
 
 Backend.set_preprocessed_cache = _backend_set_preprocessed_cache
 Backend.set_twiddle_cache = lambda self, on: self._ck(self.L.cm_set_twiddle_cache(C.c_int32(1 if on else 0)))
+Backend.set_device_tail = lambda self, on: self._ck(self.L.cm_set_device_tail(C.c_int32(1 if on else 0)))
 Backend.pool_trim = lambda self: self._ck(self.L.cm_pool_trim())   # this thread's cached device blocks back to the driver
 
 

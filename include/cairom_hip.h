@@ -349,6 +349,19 @@ int32_t cm_set_preprocessed_cache(int32_t on);
  * default (pool memory, on a side stream next to trace generation).  on = keep one table per domain size for the whole
  * process (env CM_TWIDDLE_CACHE=1 sets the initial value).  Off in every quoted number.  Proof bytes are identical. */
 int32_t cm_set_twiddle_cache(int32_t on);
+/* Tail of a proof — everything stwo `prove` (prover.rs:131) does behind the last FRI fold: the last layer's polynomial, the
+ * proof of work, the query draws and the decommitment of every tree.  1 (default; env CM_DEVICE_TAIL=0 sets the initial value
+ * to 0) = four launches enqueued behind the last fold, witnesses written to pinned host memory in proof order, the host
+ * replays the transcript steps afterwards and refuses the proof on a mismatch (cairo_m_amd/csrc/tail_device.hpp);
+ * 0 = the host drives each step (round trip per step, symbolic decommitment walk on the host).  Proof bytes are identical. */
+int32_t cm_set_device_tail(int32_t on);
+/* The node lists the device-side tail gathers by (host code, no GPU: the mirror the prover checks the device against; the CPU
+ * tests compare it with a restatement of MerkleProver::decommit).  positions: the sorted, de-duplicated query positions on the
+ * domain of 2^log_domain points; qmask: bit l = the first FRI tree carries columns of 2^l rows; list: 0 = U[k] (queried nodes
+ * of the layer of 2^(log_domain - k) nodes), 1 = W[k] (their unqueried siblings), 2 = F[k] (hashes of the layer below that the
+ * first FRI tree's walk asks for at that layer).  Writes min(*n_out, cap) entries; *n_out = the list's length. */
+int32_t cm_tail_list(const uint32_t* positions, uint32_t n_positions, uint32_t log_domain, uint32_t qmask, uint32_t list, uint32_t k,
+                     uint32_t* out, uint32_t cap, uint32_t* n_out);
 /* Proof object from its flat word stream (host code, no GPU): re-serialise with cm_proof_json / verify with cm_verify_proof. */
 int32_t cm_proof_from_words(const uint32_t* words, uint64_t n_words, cm_proof** out);
 /* Flat u32 serialisation of the proof (format: cairo_m_amd/csrc/proof.hpp), used by the parity tests. */

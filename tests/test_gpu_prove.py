@@ -436,3 +436,32 @@ def test_log_blowup_factor_above_one_bit_exact(backend, oracle, cfg):
         assert p.verify()[0] != 0 and oracle.verify(got)[0] != 0
         p.free()
         inp.free()
+
+
+@pytest.mark.parametrize("cfg", [None, (0, 1, 0, 1), (10, 1, 2, 37), (4, 2, 2, 200), (6, 1, 0, 1024), (18, 1, 1, 64)])
+def test_device_tail_equals_host_walk(backend, oracle, cfg):
+    """The tail of a proof behind the last FRI fold (last layer, proof of work, query draws, decommitment of every tree:
+    stwo `prove`, prover.rs:131) runs as four launches without a host round trip (cairo_m_amd/csrc/tail_device.hpp).  Same input
+    proved with that form and with the host-driven one (cm_set_device_tail): identical words, equal to the oracle's, for PCS
+    configs that move every size the tail depends on — one query, 1024 queries (duplicates after the mask on small domains),
+    no proof of work and 18 bits of it, last layers of 2 .. 16 values, blowup 2."""
+    from cairo_m_amd.lib import vm_run
+    from tests.test_oracle_air import u32_loop_program
+    inputs = [synth_fibonacci(7), synth_fibonacci(3000), vm_run(u32_loop_program(40), entry_pc=0, args=(), n_returns=0)]
+    try:
+        for inp in inputs:
+            backend.set_device_tail(True)
+            p_dev = backend.prove(inp, cfg=cfg)
+            backend.set_device_tail(False)
+            p_host = backend.prove(inp, cfg=cfg)
+            w_dev, w_host = p_dev.words(), p_host.words()
+            assert w_dev.size == w_host.size and np.array_equal(w_dev, w_host)
+            want, _ = oracle.prove(inp.view, cfg=cfg) if cfg else oracle.prove(inp.view)
+            assert want.size == w_dev.size and np.array_equal(w_dev, want)
+            assert (p_dev.verify(cfg) if cfg else p_dev.verify())[0] == 0
+            p_dev.free()
+            p_host.free()
+    finally:
+        backend.set_device_tail(True)
+        for inp in inputs:
+            inp.free()

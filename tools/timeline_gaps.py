@@ -12,7 +12,9 @@ for r in csv.DictReader(open(k)):
 for r in csv.DictReader(open(m)):
     ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r['Direction'][12:], '-', ''))
 ev.sort()
-gi = [i for i, e in enumerate(ev) if 'k_grind' in e[2]]
+gi = [i for i, e in enumerate(ev) if 'k_tail_gather' in e[2]]   # device-side tail (round 5): the last kernel of a proof
+if not gi:
+    gi = [i for i, e in enumerate(ev) if 'k_grind' in e[2]]
 # a proof has ONE k_grind launch (the final PoW; the interaction PoW is part of k_step_pow_relations).  bench.py's LAST proof is
 # the verification proof made on the main host thread (cold device pool: hipMallocs), so the proof analysed is the one before
 # it: the last TIMED proof.
