@@ -183,6 +183,8 @@ struct Fork {
   ~Fork();
 };
 
+void fork_join_check();   // throws if a flag-join collector of the calling thread timed out (pool.hip); main stream synchronised
+
 // simple RAII device buffer
 struct DevBuf {
   void* p = nullptr;

@@ -237,15 +237,56 @@ uint32_t* pinned_words() {
 
 // ---- fork/join side streams ---------------------------------------------------------------------------
 namespace {
+// Join by flags (round 5).  An event join puts one barrier packet per joined side stream into the main stream's hardware queue
+// and each costs ~5.5 us whether its event has fired or not: 42-52 us behind a region of seven side streams
+// (tools/join_lab.hip, tools/flagjoin_lab.hip).  Instead every side stream ends with a one-thread kernel that stores the
+// join's epoch into its flag word, and the main stream runs ONE collector kernel whose lanes poll the flags: 4.7-4.9 us for the
+// same region.  Submission order makes it safe on shared hardware queues: the collector is enqueued after every flag kernel it
+// waits for.  A lane gives up after JOIN_LIMIT_S seconds of device clock and reports it through a pinned word that the prover
+// reads at the end of the proof (fork_join_check).  CM_FLAG_JOIN=0: the event form.
+constexpr double JOIN_LIMIT_S = 10.0;
+__global__ void k_join_flag(uint32_t* flag, uint32_t epoch) { __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__global__ void k_join_collect(const uint32_t* flags, uint32_t mask, uint32_t epoch, unsigned long long limit_ticks, uint32_t* timed_out) {
+  const uint32_t i = threadIdx.x;
+  if (i >= (uint32_t)Fork::N || !((mask >> i) & 1u)) return;
+  const unsigned long long t0 = wall_clock64();
+  // SYSTEM scope: the load must not be served from this XCD's L2 (the flag kernel ran on whichever XCD; its store reaches memory
+  // when that kernel ends) — with agent scope on ordinary device memory the lanes polled a stale line until the time limit
+  while ((int32_t)(__hip_atomic_load(flags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+    if (wall_clock64() - t0 > limit_ticks) {   // {1, lane, epoch, flag value seen}: read by fork_join_check
+      timed_out[1] = i; timed_out[2] = epoch; timed_out[3] = __hip_atomic_load(flags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      *timed_out = 1;
+      return;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
 struct SideStreams {
   hipStream_t s[Fork::N];
   hipEvent_t done[Fork::N], fork_ev;
+  uint32_t* flags = nullptr;       // device: one word per side stream
+  uint32_t* timed_out = nullptr;   // pinned
+  uint32_t epoch = 0;
+  unsigned long long limit_ticks = 0;
   SideStreams() {
     for (int i = 0; i < Fork::N; i++) {
       CM_HIP(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
       CM_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
     }
     CM_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+    const int mem = getenv("CM_FLAG_MEM") ? atoi(getenv("CM_FLAG_MEM")) : 0;   // development: 0 device, 1 fine-grained device, 2 pinned host
+    if (mem == 2) CM_HIP(hipHostMalloc((void**)&flags, Fork::N * 4, hipHostMallocDefault));
+    else if (mem == 1) CM_HIP(hipExtMallocWithFlags((void**)&flags, Fork::N * 4, hipDeviceMallocFinegrained));
+    else CM_HIP(hipMalloc((void**)&flags, Fork::N * 4));
+    CM_HIP(hipMemset(flags, 0, Fork::N * 4));
+    CM_HIP(hipDeviceSynchronize());   // (hipMemset runs on the NULL stream, the library's streams are non-blocking)
+    CM_HIP(hipHostMalloc((void**)&timed_out, 64, hipHostMallocDefault));
+    memset(timed_out, 0, 64);
+    int dev = 0, rate_khz = 100000;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
+    const double limit_s = getenv("CM_JOIN_LIMIT_S") ? atof(getenv("CM_JOIN_LIMIT_S")) : JOIN_LIMIT_S;
+    limit_ticks = (unsigned long long)(limit_s * 1e3 * (double)rate_khz);
   }
 };
 SideStreams& side() {
@@ -256,6 +297,8 @@ SideStreams& side() {
     at_thread_exit([own] {
       for (int i = 0; i < Fork::N; i++) { (void)hipStreamSynchronize(own->s[i]); (void)hipStreamDestroy(own->s[i]); (void)hipEventDestroy(own->done[i]); }
       (void)hipEventDestroy(own->fork_ev);
+      (void)hipFree(own->flags);
+      (void)hipHostFree(own->timed_out);
       delete own;
     });
   }
@@ -393,11 +436,32 @@ void Fork::join() {
   if (joined) return;
   joined = true;
   SideStreams& ss = side();
+  static const bool flag_join = !(getenv("CM_FLAG_JOIN") && atoi(getenv("CM_FLAG_JOIN")) == 0);
+  if (flag_join && used) {
+    const uint32_t epoch = ++ss.epoch;
+    for (int i = 0; i < N; i++)
+      if (used & (1u << i)) hipLaunchKernelGGL(k_join_flag, dim3(1), dim3(1), 0, ss.s[i], ss.flags + i, epoch);
+    hipLaunchKernelGGL(k_join_collect, dim3(1), dim3(64), 0, main, ss.flags, used, epoch, ss.limit_ticks, ss.timed_out);
+    static const bool dbg = getenv("CM_FLAG_JOIN_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[join] epoch %u used %02x main %p\n", epoch, used, (void*)main);
+    CM_HIP(hipGetLastError());
+    return;
+  }
   for (int i = 0; i < N; i++)
     if (used & (1u << i)) {
       CM_HIP(hipEventRecord(ss.done[i], ss.s[i]));
       CM_HIP(hipStreamWaitEvent(main, ss.done[i], 0));
     }
+}
+// a collector of this thread gave up (a side stream never reached its flag kernel): call with the main stream synchronised
+void fork_join_check() {
+  SideStreams& ss = side();
+  if (*ss.timed_out) {
+    const std::string what = "fork/join: a side stream did not reach its join flag (collector timed out: side " + std::to_string(ss.timed_out[1]) +
+                             ", epoch " + std::to_string(ss.timed_out[2]) + ", flag " + std::to_string(ss.timed_out[3]) + ")";
+    *ss.timed_out = 0;
+    throw CmError(2, what);
+  }
 }
 Fork::~Fork() {
   // never leave side work un-joined (exception paths): block the host instead of throwing from a destructor

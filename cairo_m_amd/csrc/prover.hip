@@ -407,6 +407,7 @@ struct SegmentProver {
 
     kprof_close_run();   // a run of timed launches still open on this thread
     P.finish();
+    fork_join_check();
     pf.phase_ms = P.phase_ms;
     pf.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - P.t0).count();
     pf.steps = 0;
