@@ -164,6 +164,9 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
       else fold_line_and_circle(dst, src, circ, layer_log, *P.tw, st, d_alphas.u32() + 4 * li, d_alphas.u32());
       qi++;
     } else {
+      // quotient columns of the next layer's size that were NOT folded in by this kernel (two groups of one size: the next
+      // iteration accumulates them into the layer) — its leaves must not be hashed before that
+      if (qi < quotients.size() && q_logs[qi] == layer_log) next_leaves = nullptr;
       if (next_leaves && fold_line_leaf(dst, src, nullptr, layer_log, *P.tw, st, d_alphas.u32() + 4 * li, nullptr, next_leaves))
         pre[pi + 1]->leaf_done = true;
       else fold_line(dst, src, layer_log, *P.tw, unused_alpha, st, d_alphas.u32() + 4 * li);

@@ -1467,25 +1467,40 @@ int32_t cm_prove_segment(const cm_prover_input* input, const cm_pcs_config* conf
   cm_input_free(di);
   return rc;
 }
-int32_t cm_shard_plan(const cm_prover_input* input, uint32_t world, int32_t owner_out[CM_N_COMPONENTS], uint64_t* staging_words) {
+int32_t cm_shard_plan(const cm_prover_input* input, const cm_pcs_config* config, uint32_t world, int32_t owner_out[CM_N_COMPONENTS],
+                      uint64_t* staging_words) {
   return pguard([&] {
     CM_CHECK(world >= 1 && world <= 8 && (world & (world - 1)) == 0, "cm_shard_plan: world must be 1, 2, 4 or 8");
+    const cm_pcs_config cfg = config ? *config : default_cfg();
+    CM_CHECK(cfg.log_blowup_factor >= 1 && cfg.log_blowup_factor <= 4, "cm_shard_plan: log_blowup_factor");
     uint32_t clog[air::N_COMPONENTS];
     cm::component_logs(*input, clog);
-    const cm::ShardPlan p = cm::make_shard_plan(clog, world);
+    // the SAME plan cm_prove_sharded will run under this config (components are split only at log_blowup_factor 1)
+    const cm::ShardPlan p = cm::make_shard_plan(clog, world, cfg.log_blowup_factor == 1);
     for (int c = 0; c < air::N_COMPONENTS; c++) if (owner_out) owner_out[c] = p.owner[c];
-    if (staging_words) *staging_words = cm::shard_staging_words(clog, p, world);
+    // (the bound is computed for a blowup of 2; the LDE, and with it every exchange, grows by 2^(B - 1))
+    if (staging_words) *staging_words = cm::shard_staging_words(clog, p, world) << (cfg.log_blowup_factor - 1);
   });
 }
-int32_t cm_shard_plan_columns(const cm_prover_input* input, uint32_t world, int32_t* trace_col_owner, uint32_t* n_trace_cols,
-                              int32_t* interaction_col_owner, uint32_t* n_interaction_cols, uint64_t load_cells[8]) {
+int32_t cm_shard_plan_columns(const cm_prover_input* input, const cm_pcs_config* config, uint32_t world, int32_t* trace_col_owner,
+                              uint32_t* n_trace_cols, int32_t* interaction_col_owner, uint32_t* n_interaction_cols, uint64_t load_cells[8]) {
   return pguard([&] {
     CM_CHECK(world >= 1 && world <= 8 && (world & (world - 1)) == 0, "cm_shard_plan_columns: world must be 1, 2, 4 or 8");
+    const cm_pcs_config cfg = config ? *config : default_cfg();
     uint32_t clog[air::N_COMPONENTS];
     cm::component_logs(*input, clog);
-    const cm::ShardPlan p = cm::make_shard_plan(clog, world);
-    if (trace_col_owner) for (size_t j = 0; j < p.tr_owner.size(); j++) trace_col_owner[j] = p.tr_owner[j];
-    if (interaction_col_owner) for (size_t j = 0; j < p.it_owner.size(); j++) interaction_col_owner[j] = p.it_owner[j];
+    const cm::ShardPlan p = cm::make_shard_plan(clog, world, cfg.log_blowup_factor == 1);
+    // n_*_cols: capacity of the array on entry, the number of columns on return; an array that is too small is an error, never
+    // an overrun
+    if (trace_col_owner) {
+      CM_CHECK(n_trace_cols && *n_trace_cols >= p.tr_owner.size(), "cm_shard_plan_columns: trace_col_owner is too small (set *n_trace_cols to its capacity)");
+      for (size_t j = 0; j < p.tr_owner.size(); j++) trace_col_owner[j] = p.tr_owner[j];
+    }
+    if (interaction_col_owner) {
+      CM_CHECK(n_interaction_cols && *n_interaction_cols >= p.it_owner.size(),
+               "cm_shard_plan_columns: interaction_col_owner is too small (set *n_interaction_cols to its capacity)");
+      for (size_t j = 0; j < p.it_owner.size(); j++) interaction_col_owner[j] = p.it_owner[j];
+    }
     if (n_trace_cols) *n_trace_cols = (uint32_t)p.tr_owner.size();
     if (n_interaction_cols) *n_interaction_cols = (uint32_t)p.it_owner.size();
     if (load_cells) for (int k = 0; k < 8; k++) load_cells[k] = p.load[k];
@@ -1584,6 +1599,7 @@ static int32_t prove_streamed(uint32_t n, Produce&& produce, const cm_pcs_config
     std::deque<cm::DeviceInput*> spent[3];         // proved: back to the producer that made them
     uint32_t outstanding[3] = {0, 0, 0};           // inputs of producer p that exist (being produced, ready, being proved, spent)
     uint32_t alive = 0, next_i = 0, workers_done = 0, producers_done = 0, n_producers = 1;
+    uint32_t extra_done = 0;                       // library-thread producers that have left `sh` for good (counted under `mu`)
     bool no_more = false, stop = false;
     int32_t rc = 0;
     std::string err;
@@ -1672,16 +1688,17 @@ static int32_t prove_streamed(uint32_t n, Produce&& produce, const cm_pcs_config
       release_spent(lk);
     }
   };
-  std::atomic<uint32_t> extra_done{0};
+  // (the completion count is bumped INSIDE the lock, like workers_done: the caller's wait below reads it under the same lock, so it
+  // cannot return — and destroy `sh` — between the count and the notify; the job touches nothing of `sh` after the guard)
   for (uint32_t pid = 1; pid < n_producers; pid++)
-    w.submit([&producer, &extra_done, &sh, pid] { producer(pid); extra_done.fetch_add(1); std::lock_guard<std::mutex> lk(sh.mu); sh.cv.notify_all(); });
+    w.submit([&producer, &sh, pid] { producer(pid); std::lock_guard<std::mutex> lk(sh.mu); sh.extra_done++; sh.cv.notify_all(); });
   {
     cm::AffinityScope cpu_scope;
     producer(0);
   }
   {
     std::unique_lock<std::mutex> lk(sh.mu);
-    sh.cv.wait(lk, [&] { return sh.workers_done == runners && extra_done.load() == n_producers - 1; });
+    sh.cv.wait(lk, [&] { return sh.workers_done == runners && sh.extra_done == n_producers - 1; });
   }
   if (sh.rc) { cm_set_last_error(sh.err.c_str()); return sh.rc; }
   return 0;

@@ -38,24 +38,31 @@ class CmComm(C.Structure):
         super().__init__(C.sizeof(CmComm), *fields, **kw)
 
 
-def shard_plan(host_input, world, lib=None):
-    """(owner per component, staging words) — host code, identical on every rank."""
+def _cfg_arg(cfg):
+    return (C.c_uint32 * 4)(*cfg) if cfg else None
+
+
+def shard_plan(host_input, world, lib=None, cfg=None):
+    """(owner per component, staging words) under PCS config `cfg` — host code, identical on every rank."""
     L = lib or load_library()
     owner = (C.c_int32 * N_COMPONENTS)()
     words = C.c_uint64(0)
-    rc = L.cm_shard_plan(host_input.view, C.c_uint32(world), owner, C.byref(words))
+    rc = L.cm_shard_plan(host_input.view, _cfg_arg(cfg), C.c_uint32(world), owner, C.byref(words))
     if rc:
         raise CmError(f"cm_shard_plan failed with status {rc}")
     return list(owner), words.value
 
 
-def shard_plan_columns(host_input, world, lib=None):
+def shard_plan_columns(host_input, world, lib=None, cfg=None):
     """column-level plan (cm_shard_plan_columns): (owner of every trace column, owner of every interaction column, cells per rank)"""
     L = lib or load_library()
-    tr, it = (C.c_int32 * 2048)(), (C.c_int32 * 2048)()
     ntr, nit = C.c_uint32(0), C.c_uint32(0)
     load = (C.c_uint64 * 8)()
-    rc = L.cm_shard_plan_columns(host_input.view, C.c_uint32(world), tr, C.byref(ntr), it, C.byref(nit), load)
+    rc = L.cm_shard_plan_columns(host_input.view, _cfg_arg(cfg), C.c_uint32(world), None, C.byref(ntr), None, C.byref(nit), load)   # the counts
+    if rc:
+        raise CmError(f"cm_shard_plan_columns failed with status {rc}")
+    tr, it = (C.c_int32 * max(1, ntr.value))(), (C.c_int32 * max(1, nit.value))()
+    rc = L.cm_shard_plan_columns(host_input.view, _cfg_arg(cfg), C.c_uint32(world), tr, C.byref(ntr), it, C.byref(nit), load)
     if rc:
         raise CmError(f"cm_shard_plan_columns failed with status {rc}")
     return list(tr[:ntr.value]), list(it[:nit.value]), list(load[:world])
@@ -218,9 +225,7 @@ def main():
     else:
         inp = synth_fibonacci(a.fib_n)
     cfg = tuple(int(x) for x in a.cfg.split(",")) if a.cfg else None
-    owner, words = shard_plan(inp, dist.get_world_size(), be.L)
-    if cfg and cfg[1] > 1:
-        words <<= cfg[1] - 1              # cm_shard_plan sizes the staging buffers for log_blowup_factor 1: the LDE grows by 2^(B - 1)
+    owner, words = shard_plan(inp, dist.get_world_size(), be.L, cfg)   # the plan and the staging bound of THIS config
     comm = RcclComm(be, words) if a.comm == "rccl" else TorchComm(words, device=local)
     dev = be.upload_input(inp)
     p = prove_sharded(be, dev, comm, cfg)     # warm-up + the proof that is written out

@@ -24,6 +24,9 @@
 #define CAIROM_HIP_H
 #include <stddef.h>
 #include <stdint.h>
+/* Revision of this header.  4: cm_comm.struct_size at offset 0 (breaking for cm_comm users).  5: cm_shard_plan* take the PCS
+ * config and column-array capacities; cm_set_device_tail, cm_tail_list. */
+#define CM_ABI_REVISION 5
 
 #ifdef __cplusplus
 extern "C" {
@@ -287,8 +290,10 @@ int32_t cm_verify_proof_words(const uint32_t* words, uint64_t n_words, const cm_
  * recv_words[s] words from rank s into recv_buf; all_gather sends send_buf[0, words_per_rank) and receives world blocks. */
 typedef struct cm_comm {
   uint32_t struct_size;              /* sizeof(cm_comm) as the CALLER compiled it: the fields behind all_gather are optional and are
-                                      * only read when this size covers them, so a caller built against an earlier header (or a
-                                      * binding that stops at all_gather) keeps working; smaller than that = status 1 */
+                                      * only read when this size covers them (a binding that stops at all_gather works); smaller
+                                      * than that = status 1.  ABI note: this field was inserted at offset 0 in header revision 4
+                                      * (CM_ABI_REVISION), which moved every other field — a caller compiled against a revision-3
+                                      * header is NOT compatible and is rejected with status 1 (its `rank` is read as a size) */
   uint32_t rank, world;              /* world: a power of two, 1..8 */
   void* ctx;
   uint32_t* send_buf;
@@ -307,15 +312,21 @@ typedef struct cm_comm {
   void (*abort)(void* ctx);
 } cm_comm;
 #define CM_COMM_STREAM_ORDERED 1u
-/* host code (no GPU): which rank owns which component, and the staging capacity (words) a sharded proof of `input` needs */
-int32_t cm_shard_plan(const cm_prover_input* input, uint32_t world, int32_t owner[CM_N_COMPONENTS], uint64_t* staging_words);
+/* host code (no GPU): which rank owns which component, and the staging capacity (words) a sharded proof of `input` needs UNDER
+ * `config` (NULL = REGULAR_96_BITS) — the plan and the bound are the ones cm_prove_sharded runs with that config (components are
+ * split only at log_blowup_factor 1; the exchanges grow with the blowup).  Revision 5: the `config` argument is new. */
+int32_t cm_shard_plan(const cm_prover_input* input, const cm_pcs_config* config, uint32_t world, int32_t owner[CM_N_COMPONENTS],
+                      uint64_t* staging_words);
 /* owner[c] = -1: component c is SPLIT over all ranks — a large opcode component (more than an eighth of a rank's fair share of
  * the cells, at least 2^12 rows) is generated, looked up and constrained by ROW RANGE on every rank, and its columns are
  * transformed by the ranks the plan gives them to one by one (the four cumulative-sum columns of its LogUp stay together).
- * cm_shard_plan_columns reports that column-level plan: the owner of every column of trees 1 / 2 in commitment order (arrays of
- * at least 2048 entries; the counts come back in n_*_cols) and the cells every rank transforms (load_cells[r], r < world). */
-int32_t cm_shard_plan_columns(const cm_prover_input* input, uint32_t world, int32_t* trace_col_owner, uint32_t* n_trace_cols,
-                              int32_t* interaction_col_owner, uint32_t* n_interaction_cols, uint64_t load_cells[8]);
+ * cm_shard_plan_columns reports that column-level plan: the owner of every column of trees 1 / 2 in commitment order and the
+ * cells every rank transforms (load_cells[r], r < world).  *n_trace_cols / *n_interaction_cols: the CAPACITY of the array on
+ * entry, the column count on return; an array that is too small is status 1 (nothing is written past it).  Pass NULL arrays to
+ * learn the counts. */
+int32_t cm_shard_plan_columns(const cm_prover_input* input, const cm_pcs_config* config, uint32_t world, int32_t* trace_col_owner,
+                              uint32_t* n_trace_cols, int32_t* interaction_col_owner, uint32_t* n_interaction_cols,
+                              uint64_t load_cells[8]);
 int32_t cm_prove_sharded(const cm_device_input* input, const cm_pcs_config* config, const cm_comm* comm, cm_proof** out);
 /* In-library cm_comm on RCCL (xGMI inside a node), stream-ordered: no host synchronisation around an exchange, nothing but
  * the library in the data path.  Rank 0 makes the 128-byte id (cm_rccl_unique_id) and the launcher hands it to every rank;

@@ -215,8 +215,8 @@ unsafe extern "C" {
     pub fn cm_prove_device(input: *const cm_device_input, config: *const cm_pcs_config, out: *mut *mut cm_proof) -> i32;
     pub fn cm_verify_proof(p: *const cm_proof, expected: *const cm_pcs_config) -> i32;
     pub fn cm_verify_proof_words(words: *const u32, n_words: u64, expected: *const cm_pcs_config) -> i32;
-    pub fn cm_shard_plan(input: *const cm_prover_input, world: u32, owner: *mut i32, staging_words: *mut u64) -> i32;
-    pub fn cm_shard_plan_columns(input: *const cm_prover_input, world: u32, trace_col_owner: *mut i32, n_trace_cols: *mut u32, interaction_col_owner: *mut i32, n_interaction_cols: *mut u32, load_cells: *mut u64) -> i32;
+    pub fn cm_shard_plan(input: *const cm_prover_input, config: *const cm_pcs_config, world: u32, owner: *mut i32, staging_words: *mut u64) -> i32;
+    pub fn cm_shard_plan_columns(input: *const cm_prover_input, config: *const cm_pcs_config, world: u32, trace_col_owner: *mut i32, n_trace_cols: *mut u32, interaction_col_owner: *mut i32, n_interaction_cols: *mut u32, load_cells: *mut u64) -> i32;
     pub fn cm_prove_sharded(input: *const cm_device_input, config: *const cm_pcs_config, comm: *const cm_comm, out: *mut *mut cm_proof) -> i32;
     pub fn cm_rccl_unique_id(id_out: *mut u8) -> i32;
     pub fn cm_rccl_comm_create(id: *const u8, rank: u32, world: u32, staging_words: u64, out: *mut *mut cm_rccl_comm) -> i32;

@@ -125,9 +125,6 @@ pub fn prove_cairo_m_hip(input: &mut ProverInput, pcs_config: Option<PcsConfig>)
     Ok(proof)
 }
 
-/// `verify_cairo_m::<Blake2sMerkleChannel>` stays the reference's own function: the value returned above is an ordinary
-/// `Proof<Blake2sMerkleHasher>`.  This helper is the library-side verifier (host code, no GPU) for callers that want the
-/// check without Stwo: same acceptance conditions, error mapped onto the reference's enum.
 /// Streaming form for a service that proves the continuation segments of a run (crates/runner/src/vm/mod.rs:184-240 cuts them,
 /// crates/prover/tests/prover.rs:203-243 proves them one by one): `cm_prove_many_host` uploads segment k + 1 on the calling
 /// thread while up to `inflight` library threads prove the segments before it, so the 6 ms PCIe copy of a 2^22-step segment hides
@@ -163,6 +160,9 @@ pub fn prove_segments_hip(
         .collect()
 }
 
+/// `verify_cairo_m::<Blake2sMerkleChannel>` stays the reference's own function: the value returned above is an ordinary
+/// `Proof<Blake2sMerkleHasher>`.  This helper is the library-side verifier (host code, no GPU) for callers that want the
+/// check without Stwo: same acceptance conditions, error mapped onto the reference's enum.
 pub fn verify_words_hip(proof: &ProofHandleRef, pcs_config: Option<PcsConfig>) -> Result<(), VerificationError> {
     let cfg = pcs(&pcs_config.unwrap_or(REGULAR_96_BITS));
     let rc = unsafe { cm_verify_proof(proof.0, &cfg) };

@@ -6,6 +6,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FFI = open(os.path.join(ROOT, "integration", "prover-hip", "src", "ffi.rs")).read()
 LIB = open(os.path.join(ROOT, "integration", "prover-hip", "src", "lib.rs")).read()
@@ -99,3 +101,73 @@ def test_opcode_groups_equal_the_component_table():
                 "u32_store_fp_imm": "u32_store_bitwise_fp_imm" if "AND" in row else "u32_store_fp_imm"}.get(stem, stem)
         assert stem == module or module in (first, stem) or first.replace("_rem", "") == module or \
             re.sub(r"_(add|sub|mul|div|lt|eq)_", "_\\1_", first) == module, (row, module, stem)
+
+
+# ---- syntax gate (tools/rs_syntax_gate.py): the only compiler substitute in an image without rustc ---------------------------
+def _gate():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rs_syntax_gate", os.path.join(ROOT, "tools", "rs_syntax_gate.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _shim_sources():
+    base = os.path.join(ROOT, "integration", "prover-hip")
+    out = []
+    for sub in ("src", "tests"):
+        d = os.path.join(base, sub)
+        out += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(".rs")]
+    out.append(os.path.join(base, "build.rs"))
+    return [p for p in out if os.path.exists(p)]
+
+
+def test_shim_sources_pass_the_syntax_gate():
+    g = _gate()
+    files = _shim_sources()
+    assert len(files) >= 5
+    for p in files:
+        assert g.check_file(p) > 50, p
+
+
+def test_syntax_gate_rejects_what_it_is_there_for(tmp_path):
+    """The gate is not vacuous: each of these edits of a shim source — the slips a never-compiled crate accumulates — is refused."""
+    g = _gate()
+    src = open(os.path.join(ROOT, "integration", "prover-hip", "src", "lib.rs")).read()
+    edits = {
+        "dropped brace": lambda s: s[::-1].replace("}", "", 1)[::-1],
+        "dropped paren": lambda s: s.replace("ensure_init();", "ensure_init);", 1),
+        "unterminated string": lambda s: s.replace('"', "", 1),
+        "let without semicolon": lambda s: re.sub(r"(let rc = unsafe \{[^\n]*\});", r"\1", s, count=1),
+        "dangling doc comment": lambda s: s.rstrip() + "\n/// a comment that documents nothing\n",
+        "stray keyword in item position": lambda s: s.replace("\npub fn ", "\npub return fn ", 1),
+        "field without a type": lambda s: s.replace("pub struct ProofHandleRef(pub *const cm_proof);", "pub struct ProofHandleRef { handle, }"),
+        "crossed delimiters": lambda s: s.replace("{", "(", 1),
+    }
+    for name, f in edits.items():
+        bad = f(src)
+        assert bad != src, name
+        p = tmp_path / "m.rs"
+        p.write_text(bad)
+        with pytest.raises(g.GateError):
+            g.check_file(str(p))
+    p = tmp_path / "ok.rs"
+    p.write_text(src)
+    assert g.check_file(str(p)) > 0
+
+
+def test_syntax_gate_accepts_compiler_accepted_code():
+    """Calibration against code a compiler HAS seen: every .rs file of the reference's prover / runner / common crates passes
+    (build container only: /root/reference does not travel)."""
+    ref = "/root/reference/crates"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    g = _gate()
+    n = 0
+    for crate in ("prover", "runner", "common"):
+        for d, _, fs in os.walk(os.path.join(ref, crate)):
+            for f in fs:
+                if f.endswith(".rs"):
+                    g.check_file(os.path.join(d, f))
+                    n += 1
+    assert n > 60

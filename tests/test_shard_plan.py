@@ -47,3 +47,28 @@ def test_world_one_owns_everything():
         assert set(owner) == {0}
     finally:
         inp.free()
+
+
+def test_plan_follows_the_pcs_config_and_checks_capacities():
+    """cm_shard_plan* describe the plan cm_prove_sharded RUNS under the given config: components are split only at
+    log_blowup_factor 1, and the staging bound grows with the blowup.  The column arrays carry their capacity: too small is an
+    error, not an overrun."""
+    import ctypes as C
+    from cairo_m_amd.lib import load_library
+    L = load_library()
+    inp = synth_fibonacci(100_000)
+    try:
+        owner1, words1 = shard_plan(inp, 4)
+        owner2, words2 = shard_plan(inp, 4, cfg=(16, 2, 0, 80))
+        assert -1 in owner1 and -1 not in owner2          # blowup 2: whole components only
+        assert words2 >= 2 * min(words1, words2) // 2 and words2 > 0
+        tr2, it2, load2 = shard_plan_columns(inp, 4, cfg=(16, 2, 0, 80))
+        for c0, o in enumerate(owner2[:1]):
+            assert all(x == tr2[0] for x in tr2[:5])        # a whole component's columns sit on one rank
+        # capacity too small -> status 1, nothing written past the array
+        tr = (C.c_int32 * 8)(*([77] * 8))
+        ntr, nit = C.c_uint32(4), C.c_uint32(0)
+        rc = L.cm_shard_plan_columns(inp.view, None, C.c_uint32(4), tr, C.byref(ntr), None, C.byref(nit), None)
+        assert rc == 1 and list(tr) == [77] * 8
+    finally:
+        inp.free()
