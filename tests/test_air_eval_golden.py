@@ -25,10 +25,17 @@ def _names(oracle):
     return {oracle.L.orc_component_name(C.c_int(c)).decode(): c for c in range(34)}
 
 
-def _eval_row(oracle, cid, row):
+# reference column id (PreProcessedColumn::id: range_check/mod.rs:69-73, bitwise.rs:338-342) -> air::PreprocId
+PP_INDEX = {"bitwise_stacked_col_0": 0, "bitwise_stacked_col_1": 1, "bitwise_stacked_col_2": 2, "bitwise_stacked_col_3": 3,
+            "range_check_8": 4, "range_check_16": 5, "range_check_20": 6}
+
+
+def _eval_row(oracle, cid, row, preproc=None):
     cap = 4096
     r = np.ascontiguousarray(row, dtype=np.uint32)
     pp = np.zeros(7, dtype=np.uint32)
+    for cid_str, v in (preproc or {}).items():
+        pp[PP_INDEX[cid_str]] = v
     cons, ents = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32)
     nc, ne = C.c_uint32(0), C.c_uint32(0)
     u = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
@@ -45,8 +52,8 @@ def _eval_row(oracle, cid, row):
 def test_every_interpreted_component_is_covered(oracle):
     names = _names(oracle)
     assert set(GOLD) <= set(names)
-    # all 26 opcode components + memory, merkle, clock_update, poseidon2 (the four lookup tables are one relation entry each)
-    assert len(GOLD) == 30 and all(names[n] <= 29 for n in GOLD)
+    # all 26 opcode components + memory, merkle, clock_update, poseidon2 + the four lookup tables (tools/rsref/rs_lookup.py)
+    assert len(GOLD) == 34 and sorted(names[n] for n in GOLD) == list(range(34))
 
 
 @pytest.mark.parametrize("name", sorted(GOLD))
@@ -55,7 +62,7 @@ def test_eval_matches_reference_derived_vectors(oracle, name):
     g = GOLD[name]
     for k, row in enumerate(g["rows"]):
         assert len(row["trace"]) == g["n_trace"]
-        cons, ents, n_batches = _eval_row(oracle, cid, row["trace"])
+        cons, ents, n_batches = _eval_row(oracle, cid, row["trace"], row.get("preproc"))
         assert cons == row["constraints"], (name, k, "constraint values")
         want = []
         for rel, mult, vals in row["relations"]:
@@ -67,4 +74,7 @@ def test_eval_matches_reference_derived_vectors(oracle, name):
         for j, (got, w) in enumerate(zip(ents, want)):
             assert got[0] == w[0] and got[1] == w[1], (name, k, j, "relation / multiplicity")
             assert got[2][:len(w[2])] == w[2] and not any(got[2][len(w[2]):]), (name, k, j, "tuple", got[2], w[2])
-        assert row["finalize"] == "pairs" and n_batches == (len(want) + 1) // 2
+        if row["finalize"] == "pairs":
+            assert n_batches == (len(want) + 1) // 2
+        else:   # finalize_logup(): one fraction per batch (the lookup tables)
+            assert row["finalize"] == "single" and n_batches == len(want)

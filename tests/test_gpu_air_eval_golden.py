@@ -12,7 +12,7 @@ to shift * D_last - N_last — and the kernel's accumulator must equal
 where C_k are the golden constraint values and N_j the numerators of the paired fractions built from the golden relation entries
 (multiplicity, tuple) — computed HERE in plain Python integers (M31 / QM31 arithmetic below), from the vectors alone.  Nothing of
 cairo_m_amd/csrc/air/*.hpp, of the oracle or of the library's field code is on the expected side, so this pins the GPU
-instantiation of all 30 interpreted components (column order, every constraint, every relation entry, the pairing, the
+instantiation of all 34 components (column order, every constraint, every relation entry, the pairing, the
 coefficient order, the vanishing-polynomial inverse) directly to the reference-derived data.  (tests/test_air_eval_golden.py pins
 the CPU instantiation of the same descriptions.)"""
 import json
@@ -28,6 +28,9 @@ REL_ID = {"registers": 0, "memory": 1, "merkle": 2, "poseidon2": 3, "range_check
           "range_check_20": 6, "bitwise": 7}
 N_REL, MAX_REL = 8, 16
 PREPROC_LOG = [18, 18, 18, 18, 8, 16, 20]
+# reference column id (PreProcessedColumn::id) -> air::PreprocId; only the four lookup-table components read these columns
+PP_INDEX = {"bitwise_stacked_col_0": 0, "bitwise_stacked_col_1": 1, "bitwise_stacked_col_2": 2, "bitwise_stacked_col_3": 3,
+            "range_check_8": 4, "range_check_16": 5, "range_check_20": 6}
 P = 2**31 - 1
 LOG = 4
 
@@ -105,9 +108,10 @@ def expected_row(g_row, rels_z, rels_apow, coeffs, n_base, dinv, shift=(0, 0, 0,
             den = qadd(den, qscale(rels_apow[r][i], v))
         ents.append((mult % P, qsub(den, rels_z[r])))
     j = 0
-    n_batches = (len(ents) + 1) // 2
-    for i in range(0, len(ents), 2):
-        if i + 1 < len(ents):
+    per = 2 if g_row.get("finalize", "pairs") == "pairs" else 1    # finalize_logup_in_pairs / finalize_logup
+    n_batches = (len(ents) + per - 1) // per
+    for i in range(0, len(ents), per):
+        if per == 2 and i + 1 < len(ents):
             (n0, d0), (n1, d1) = ents[i], ents[i + 1]
             num, den = qadd(qscale(d1, n0), qscale(d0, n1)), qmul(d0, d1)
         else:
@@ -157,13 +161,18 @@ def test_hip_domain_eval_matches_reference_derived_vectors(backend, oracle, name
     shift = qscale(tuple(int(x) for x in claimed), pow(1 << LOG, P - 2, P))
     h_tr = [backend.upload(tr[c]) for c in range(n_trace)]
     h_it = [backend.upload(np.zeros(n_eval, dtype=np.uint32)) for _ in range(n_inter)]
-    h_pp = [backend.upload(np.zeros(n_eval, dtype=np.uint32)) for _ in PREPROC_LOG]    # not read by these 30 components
+    pp = np.zeros((len(PREPROC_LOG), n_eval), dtype=np.uint32)      # read by the four lookup-table components only
+    for r, k in place.items():
+        for cid_str, v in rows[k].get("preproc", {}).items():
+            pp[PP_INDEX[cid_str], r] = v
+    h_pp = [backend.upload(pp[i]) for i in range(len(PREPROC_LOG))]
     h_acc = [backend.upload(np.zeros(n_eval, dtype=np.uint32)) for _ in range(4)]
     try:
         backend.constraints_accumulate(cid, h_tr, h_it, h_pp, LOG, rel, coeff, claimed, h_acc)
         acc = np.stack([backend.download(h, n_eval) for h in h_acc])
         for r, k in sorted(place.items()):
-            n_batches = (len(rows[k]["relations"]) + 1) // 2
+            per = 2 if rows[k].get("finalize", "pairs") == "pairs" else 1
+            n_batches = (len(rows[k]["relations"]) + per - 1) // per
             want, j = expected_row(rows[k], rels_z, rels_apow, coeffs, n_cons - n_batches, dinv[r >> LOG], shift)
             assert j == n_batches and n_inter == 4 * n_batches
             assert tuple(int(x) for x in acc[:, r]) == want, (name, "evaluation-domain row", r, "golden row", k)
