@@ -59,6 +59,21 @@ def pmc_traffic(kernel_class):
         return None, None
 
 
+def traced_idle():
+    """GPU-idle time inside one proof from the committed kernel + copy timeline of the measurement set profiles/LATEST names
+    (tools/gaps.sh: rocprofv3 --kernel-trace --memory-copy-trace of this bench, tools/timeline_gaps.py) — the sum of the intervals
+    in which no kernel and no copy of the proof runs.  Not measured in this run (it needs the tracer)."""
+    f = latest_profile("gaps.txt")
+    if not f:
+        return None
+    try:
+        import re
+        m = re.match(r"span ([\d.]+) ms\s+busy ([\d.]+) ms\s+idle ([\d.]+) ms", open(f).readline())
+        return {"span_ms": float(m.group(1)), "busy_ms": float(m.group(2)), "idle_ms": float(m.group(3)), "source": os.path.relpath(f, ROOT)}
+    except (OSError, AttributeError, ValueError):
+        return None
+
+
 def latest_profile(suffix):
     """profiles/<tag>_<suffix> of the measurement set of HEAD: the tag is the first word of profiles/LATEST (written when a set is
     committed; file names do not sort by age — r03zz sorts behind r03h).  None when that set has no such file."""
@@ -228,6 +243,11 @@ def main():
     ap.add_argument("--alt-fib-n", type=int, default=838_000,
                     help="the alternative reading of the metric config (largest column = 2^22 rows), reported as `alt_reading`; 0 = skip")
     ap.add_argument("--alt-steps", type=int, default=3)
+    ap.add_argument("--big-fib-n", type=int, default=1_677_000,
+                    help="untimed-line leg: fibonacci_loop whose largest LDE column has 2^24 rows (BASELINE configs[3] size on ONE GPU); 0 = skip")
+    ap.add_argument("--big-mixed-iters", type=int, default=0,
+                    help="untimed-line leg: all-opcodes loop (BASELINE configs[4]); 1_163_000 iterations = 2^26 rows, ~116 GiB and ~2 min of "
+                         "host-side input generation: off by default, run by tools/measure_round.sh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-timeout", type=int, default=300, help="N > 1: time limit in seconds of the sharded-mode child job")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the second mode (one proof sharded over all ranks)")
@@ -402,6 +422,44 @@ def main():
         a_inp.free()
         be.pool_trim()
 
+    big_legs = []
+    if world == 1 and rank == 0:
+        # whole-path model at the larger sizes north_star names (same 52 B / cell model): the share of protocol-serial latency
+        # (17 tree tops, 12 FRI layers, transcript steps) shrinks with the size, so the fraction of the HBM roofline rises
+        def leg(name, make_input, reps):
+            try:
+                b_inp = make_input()
+                b_dev = be.upload_input(b_inp)
+                be.prove_device(b_dev).free()
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                for _ in range(reps):
+                    pb = be.prove_device(b_dev)
+                    b_stats = pb.stats()
+                    pb.free()
+                torch.cuda.synchronize()
+                b_dt = (time.perf_counter() - tb) / reps
+                big_legs.append({"workload": name, "vm_steps": b_inp.steps, "cells": b_stats["cells"], "ms_per_proof": b_dt * 1e3,
+                                 "value": b_stats["cells"] / b_dt, "unit": "M31 trace cells/s",
+                                 "largest_column_log2": max(be.component_log_size(b_dev, c) for c in range(34)),
+                                 "whole_path_model": {"bytes_per_cell": MODEL_BYTES_PER_CELL,
+                                                      "achieved_GBs": MODEL_BYTES_PER_CELL * b_stats["cells"] / b_dt / 1e9,
+                                                      "frac": MODEL_BYTES_PER_CELL * b_stats["cells"] / b_dt / 1e9 / HBM_PEAK_GBS},
+                                 "proofs_timed": reps})
+                be.free_input(b_dev)
+                b_inp.free()
+                be.pool_trim()
+            except Exception as e:  # noqa: BLE001  (a leg that does not fit costs only its own entry)
+                big_legs.append({"workload": name, "error": str(e)[:200]})
+        if args.big_fib_n > 0:
+            leg(f"fibonacci_loop n={args.big_fib_n} (one segment, 2^24-row LDE columns; BASELINE configs[3] size on one GPU)",
+                lambda: synth_fibonacci(args.big_fib_n), 2)
+        if args.big_mixed_iters > 0:
+            from cairo_m_amd.lib import vm_run
+            from cairo_m_amd.workloads import all_opcodes_program
+            leg(f"all-opcodes loop, {args.big_mixed_iters} iterations (BASELINE configs[4] on one GPU)",
+                lambda: vm_run(all_opcodes_program(args.big_mixed_iters)[0], entry_pc=0, args=(), n_returns=0), 1)
+
     sharded = None
     if world > 1 and not args.no_sharded:
         # Second mode (BASELINE configs[3]): the `world` ranks prove ONE segment together — components split across
@@ -493,7 +551,11 @@ def main():
             name, k = dom
             achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(name)
-            roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound`: what limits the class.  The Blake2s and butterfly classes are integer-VALU-issue-bound (DESIGN.md §3,
+            # profiles/*_pmc_sq.json: the SIMDs' VALU is saturated while HBM runs at a quarter of its peak) — "valu", with the
+            # HBM figures (achieved / peak / frac: algorithmic bytes over the HIP-event duration) kept beside it and the
+            # integer-ALU fraction in `alu`
+            roofline = {"bound": "valu" if name in ALU_PEAK else "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_ms": k["ms"] / k["calls"], "launches": k["calls"],
                         "alu": ({"unit": ALU_PEAK[name][1], "achieved": k.get("work", 0.0) / (k["ms"] * 1e-3),
@@ -510,6 +572,7 @@ def main():
                         "whole_path_model": {"bytes_per_cell": MODEL_BYTES_PER_CELL,
                                              "achieved_GBs": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9,
                                              "frac": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "whole_path_model_larger_sizes": big_legs or None,
                         "stages": stage_roofline(kprof_all, n_prof, cells),
                         "stages_note": "SURVEY §8d per-stage check: bytes per cell x committed cells / summed HIP-event intervals of the "
                                        "stage's kernel classes in the instrumented pass.  With the commitment pipeline the transform and "
@@ -524,7 +587,6 @@ def main():
         # constraint evaluation ... decommitment (everything after the three trace commitments)
         trace_log = max(20, max(be.component_log_size(dev, c) for c in range(34)))
         stark_ms = sum(phases[k] for k in ("constraints", "composition_commit", "oods_sampling", "quotients", "fri_commit", "pow", "decommit"))
-        busy_ms = sum(v["ms"] for v in kprof_all.values()) / n_prof if kprof_all else None
         out = {"metric": "M31 trace cells/sec proved, fibonacci_loop 2^22 rows; end-to-end proof ms",
                "value": value, "unit": "M31 trace cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -540,12 +602,7 @@ def main():
                "mhz": {"value": (1 << trace_log) / (stark_ms * 1e-3) / 1e6, "trace_log_size": trace_log, "stark_prove_ms": stark_ms,
                        "note": "the reference's own figure, prover.rs:133-138: 2^trace_log_size / duration of the Stwo `prove` call "
                                "(constraints ... decommit phases of the last timed proof)"},
-               "gpu_idle_ms": (ms_per_step - busy_ms) if busy_ms is not None else None,
-               "gpu_idle_note": "ms_per_step minus the summed HIP-event intervals of every instrumented kernel class / fork-join region "
-                                "of the instrumented pass: host round trips, cross-stream hand-overs, copies and the few un-instrumented "
-                                "small kernels.  Since round 4 the transforms and the Merkle launches of a tree overlap on two streams, "
-                                "so the sum counts shared time twice and this figure UNDERSTATES the idle time (it can be negative); "
-                                "profiles/*_gaps.txt (traced timeline) is the reliable view",
+               "gpu_idle_traced": traced_idle(),
                "alt_reading": alt,
                "phase_ms": phases, "roofline": roofline, "pipelined": pipelined, "sharded": sharded, "end_to_end": end_to_end,
                "proof_verified": verified}

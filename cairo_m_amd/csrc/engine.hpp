@@ -95,6 +95,21 @@ void merkle_multi(const MerkleMultiArgs& a, double alg_bytes, hipStream_t st);
 // every block reduces 256 nodes of layer top_log to one node of layer top_log - 8, the last block to finish (ticket)
 // hashes the remaining <= 256 nodes up to the root.  Replaces 2-3 k_merkle_multi launches + k_merkle_tail.
 constexpr uint32_t MERKLE_TOP_MAX_LOG = 16;
+// Optional extras of the tree-top launch (FRI layer trees, round 5):
+//  * the transcript step behind the tree — Blake2sChannel::mix_root(root) + draw_felt() — by the block that hashes the root
+//    (chan != null): one launch less on the protocol-serial chain of every FRI layer (k_chan_mix_root_draw: ~5 us each);
+//  * the fold that PRODUCES the layer (fold_mode 1 = fold_line of `fold_src`, 2 = fold_line + fold_circle of the quotient columns
+//    `fold_circ` of that size): the leaf level computes the folded value, stores it to `fold_dst` (= the tree's four columns) and
+//    hashes it in registers.  Only when the launch covers the whole tree (top_log = the layer's log, prev = null).
+struct MerkleTopExtra {
+  uint32_t *chan = nullptr, *felt_out = nullptr, *root_log = nullptr;
+  uint32_t fold_mode = 0;
+  const uint32_t* fold_src[4] = {nullptr, nullptr, nullptr, nullptr};
+  const uint32_t* fold_circ[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* fold_dst[4] = {nullptr, nullptr, nullptr, nullptr};
+  const uint32_t *ixt = nullptr, *iyt = nullptr;      // inverse twiddles of the fold, indexed by output position (entries are 2 * value)
+  const uint32_t *alpha = nullptr, *alpha_c = nullptr;
+};
 struct MerkleTopArgs {
   uint32_t top_log;
   const uint32_t* prev;                          // hashes of layer top_log + 1, or null
@@ -103,6 +118,7 @@ struct MerkleTopArgs {
   uint32_t col_end[MERKLE_TOP_MAX_LOG + 1];
   uint32_t* layers[MERKLE_TOP_MAX_LOG + 1];      // output buffer of layer l
   uint32_t* ticket;                              // zero on entry; the last block leaves it zero again
+  MerkleTopExtra x;
 };
 void merkle_top(MerkleTopArgs& a, hipStream_t st);   // fills a.ticket
 // device-side transcript step of the FRI commit phase: chan = {digest[8], n_sent} (9 u32);
@@ -175,7 +191,7 @@ struct Fork {
   static constexpr int MAIN = 1 << 20;
   static int main_or(int side_index);   // MAIN, or side_index when CM_FORK_MAIN=0
   hipStream_t main;
-  uint32_t used = 0;
+  uint32_t used = 0, fork_epoch = 0;
   bool joined = false;
   explicit Fork(hipStream_t main_stream);
   hipStream_t stream(int i);

@@ -32,6 +32,7 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
   // every layer above the single-launch tail is allocated up front so that the column tables of all their
   // Merkle trees (and of the first-layer tree) travel in ONE host->device copy
   std::vector<std::unique_ptr<InnerLayer>> pre;
+  static const bool top_fuse = getenv("CM_FRI_TOP_FUSE") && atoi(getenv("CM_FRI_TOP_FUSE")) != 0;   // measured: no gain (profiles/r05f_ab_fri_top_fuse.txt) — the small layers are bound by the dependent-compression chain, not by launches; off
   {
     UploadBatch ub;
     std::vector<const uint32_t*> cols;
@@ -54,8 +55,11 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
     ub.add(chan_words, &d_chan.p);
     fri_tables = ub.flush(st);
     if (!resume) {
+      // (round 5) the transcript step behind a tree — mix_root + the draw of the folding challenge — runs in the block that hashes
+      // the root (MerkleTopExtra): one launch less per layer on the protocol-serial chain.  A/B: CM_FRI_TOP_FUSE=0
+      if (top_fuse) first_tree.top_extra = MerkleTopExtra{d_chan.u32(), d_alphas.u32(), d_roots.u32()};
       first_tree.commit_prepared(st);
-      chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
+      if (!first_tree.top_launch_has_extras) chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
     } else {
       uint32_t a4[4];
       resume->alpha_c.to_u32(a4);
@@ -75,6 +79,13 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
   }
   size_t qi = resume ? resume->qi : 0, pi = 0;
   const QM31 unused_alpha;
+  // the transcript step of inner layer `li` (1-based slot in alphas / roots), placed into the layer's tree-top launch
+  auto set_step = [&](InnerLayer* il, size_t li) {
+    if (!top_fuse) return;
+    il->tree.top_extra.chan = d_chan.u32();
+    il->tree.top_extra.felt_out = d_alphas.u32() + 4 * li;
+    il->tree.top_extra.root_log = d_roots.u32() + 8 * li;
+  };
   while (layer_log > last_log) {
     if (layer_log <= fri_tail_log()) {
       // every remaining layer in one launch (k_fri_tail); buffers are laid out here so that the decommitment
@@ -118,6 +129,7 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
       uint32_t* dst[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
       // a blank layer fed by ONE group of quotient columns (the first inner layer): fold and leaf hashes in one pass
       if (layer_is_blank && !cur->planned && !(qi + 1 < quotients.size() && q_logs[qi + 1] - 1 == layer_log)) {
+        set_step(cur, inner.size() + 1);
         cur->plan = cur->tree.plan_commit();
         cur->planned = true;
         const int nl = (int)layer_log;
@@ -134,18 +146,37 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
       qi++;
     }
     CM_CHECK(!layer_is_blank, "fri: the first layer received no quotient column");
-    if (!cur->planned) { cur->plan = cur->tree.plan_commit(); cur->planned = true; }
-    for (size_t k = cur->leaf_done ? 1 : 0; k < cur->plan.size(); k++) cur->tree.run_launch(cur->plan[k], st);
     const size_t li = inner.size() + 1;
-    chan_mix_root_draw(d_chan.u32(), cur->tree.layers[0].u32(), d_alphas.u32() + 4 * li, d_roots.u32() + 8 * li, st);
+    if (!cur->planned) { set_step(cur, li); cur->plan = cur->tree.plan_commit(); cur->planned = true; }
+    for (size_t k = cur->leaf_done ? 1 : 0; k < cur->plan.size(); k++) cur->tree.run_launch(cur->plan[k], st);
+    if (!cur->tree.top_launch_has_extras) chan_mix_root_draw(d_chan.u32(), cur->tree.layers[0].u32(), d_alphas.u32() + 4 * li, d_roots.u32() + 8 * li, st);
     // fold into the next layer: the next pre-allocated one, or a fresh buffer that the tail / last layer takes over
     uint32_t* dst[4];
     uint32_t* next_leaves = nullptr;   // the leaf layer of the next tree, when that layer is a launch of its own (large layers)
+    const bool one_circle_next = qi < quotients.size() && q_logs[qi] == layer_log && !(qi + 1 < quotients.size() && q_logs[qi + 1] == layer_log);
+    const bool no_circle_next = !(qi < quotients.size() && q_logs[qi] == layer_log);
+    bool fold_in_top = false;   // the next layer is produced by its own tree-top launch (layers of at most 2^MERKLE_TOP_MAX_LOG values)
     if (pi + 1 < pre.size()) {
       InnerLayer* nxt = pre[pi + 1].get();
       for (int c = 0; c < 4; c++) dst[c] = nxt->eval.ptrs[c];
+      set_step(nxt, li + 1);
+      if (top_fuse && (one_circle_next || no_circle_next)) {
+        MerkleTopExtra& x = nxt->tree.top_extra;
+        x.fold_mode = one_circle_next ? 2u : 1u;
+        const uint32_t R = P.tw->R, L = R - (layer_log + 1);
+        x.ixt = P.tw->ixtw + ((1u << (R - 1)) - (1u << (R - 1 - L)));
+        x.iyt = P.tw->iytw + (1u << (layer_log - 1));
+        x.alpha = d_alphas.u32() + 4 * li;
+        x.alpha_c = d_alphas.u32();
+        for (int c = 0; c < 4; c++) {
+          x.fold_src[c] = cur->eval.ptrs[c];
+          x.fold_dst[c] = nxt->eval.ptrs[c];
+          x.fold_circ[c] = one_circle_next ? quotients[qi].ptrs[c] : nullptr;
+        }
+      }
       nxt->plan = nxt->tree.plan_commit();
       nxt->planned = true;
+      fold_in_top = nxt->tree.top_launch_has_fold;
       const int nl = (int)layer_log - 1;
       if (nxt->plan.size() > 1 && nxt->plan[0].hi == nl && nxt->plan[0].lo == nl) next_leaves = nxt->tree.layers[nl].u32();
     } else {
@@ -156,7 +187,9 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
     const uint32_t* src[4] = {cur->eval.ptrs[0], cur->eval.ptrs[1], cur->eval.ptrs[2], cur->eval.ptrs[3]};
     // the quotient columns of the next layer's size are folded in by the same kernel (the single-launch tail does its own)
     const bool next_outside_tail = pi + 1 < pre.size();
-    if (next_outside_tail && qi < quotients.size() && q_logs[qi] == layer_log &&
+    if (fold_in_top) {
+      if (one_circle_next) qi++;   // folded in by the same launch
+    } else if (next_outside_tail && qi < quotients.size() && q_logs[qi] == layer_log &&
         !(qi + 1 < quotients.size() && q_logs[qi + 1] == layer_log)) {
       const uint32_t* circ[4] = {quotients[qi].ptrs[0], quotients[qi].ptrs[1], quotients[qi].ptrs[2], quotients[qi].ptrs[3]};
       if (next_leaves && fold_line_leaf(dst, src, circ, layer_log, *P.tw, st, d_alphas.u32() + 4 * li, d_alphas.u32(), next_leaves))

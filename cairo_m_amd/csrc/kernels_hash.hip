@@ -241,8 +241,13 @@ void merkle_top(MerkleTopArgs& a, hipStream_t st) {
   CM_CHECK(a.top_log >= 9 && a.top_log <= MERKLE_TOP_MAX_LOG, "merkle_top: bad layer range");
   a.ticket = next_ticket(st);
   KProfScope kp("k_merkle_top", 0.0, st);
-  if (framing().hash_node_rfc) hipLaunchKernelGGL(k_merkle_top<true>, dim3(1u << (a.top_log - 8)), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_merkle_top<false>, dim3(1u << (a.top_log - 8)), dim3(256), 0, st, a);
+  const dim3 grid(1u << (a.top_log - 8));
+  CM_CHECK(a.x.fold_mode <= 2 && (a.x.fold_mode == 0 || (a.prev == nullptr && a.x.fold_src[0] && a.x.fold_dst[0] && a.x.alpha && a.x.ixt)),
+           "merkle_top: incomplete fold description");
+#define CM_TOP(R, F) hipLaunchKernelGGL((k_merkle_top<R, F>), grid, dim3(256), 0, st, a)
+  if (framing().hash_node_rfc) { if (a.x.fold_mode == 2) CM_TOP(true, 2); else if (a.x.fold_mode == 1) CM_TOP(true, 1); else CM_TOP(true, 0); }
+  else { if (a.x.fold_mode == 2) CM_TOP(false, 2); else if (a.x.fold_mode == 1) CM_TOP(false, 1); else CM_TOP(false, 0); }
+#undef CM_TOP
   CM_HIP(hipGetLastError());
 }
 void merkle_tail(const MerkleTailArgs& a, hipStream_t st) {

@@ -380,11 +380,12 @@ __global__ void __launch_bounds__(1024) k_merkle_tail(MerkleTailArgs a) {
 // Layers 2^top_log .. 2^0 in one launch (see MerkleTopArgs).  Phase 1: 9 levels per block (256 nodes -> 1), one node
 // per lane while >= 128 nodes are active, one node per quad of lanes below (half the dependent latency).  Phase 2: the
 // block that draws the last ticket reads the 2^(top_log-8) nodes the blocks produced and finishes like k_merkle_tail.
-template <bool RFC>
+template <bool RFC, int FOLD = 0>
 __global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
   __shared__ uint32_t bufA[256 * 8];
   __shared__ uint32_t bufB[128 * 8];
   __shared__ uint32_t s_last;
+  __shared__ uint32_t s_x8[8], s_felt[4];
   __shared__ WideLds<256, 16> wide;   // phase 2 only
   uint32_t* buf[2];
   buf[0] = bufA;
@@ -403,6 +404,30 @@ __global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
         const uint32_t i = node0 + tid;
         uint32_t h[8];
         const uint32_t* ch = lv > 0 ? buf[cur ^ 1] + tid * 16 : (a.prev ? a.prev + (size_t)i * 16 : nullptr);
+        if (FOLD && lv == 0) {
+          // the FRI layer itself: fold_line of the layer above (+ fold_circle of the quotient columns of this size), stored and
+          // hashed as the leaf (k_fold_line / k_fold_line_circle + the leaf framing of k_merkle_layer: one 16-byte block)
+          const uint2 s0 = reinterpret_cast<const uint2*>(a.x.fold_src[0])[i], s1 = reinterpret_cast<const uint2*>(a.x.fold_src[1])[i];
+          const uint2 s2 = reinterpret_cast<const uint2*>(a.x.fold_src[2])[i], s3 = reinterpret_cast<const uint2*>(a.x.fold_src[3])[i];
+          const QM31 alpha = QM31::from_u32(a.x.alpha);
+          const QM31 f0(M31(s0.x), M31(s1.x), M31(s2.x), M31(s3.x)), f1(M31(s0.y), M31(s1.y), M31(s2.y), M31(s3.y));
+          QM31 v = (f0 + f1) + alpha * ((f0 - f1) * M31(a.x.ixt[i] >> 1));
+          if (FOLD == 2) {
+            const uint2 c0 = reinterpret_cast<const uint2*>(a.x.fold_circ[0])[i], c1 = reinterpret_cast<const uint2*>(a.x.fold_circ[1])[i];
+            const uint2 c2 = reinterpret_cast<const uint2*>(a.x.fold_circ[2])[i], c3 = reinterpret_cast<const uint2*>(a.x.fold_circ[3])[i];
+            const QM31 ac = QM31::from_u32(a.x.alpha_c);
+            const QM31 g0(M31(c0.x), M31(c1.x), M31(c2.x), M31(c3.x)), g1(M31(c0.y), M31(c1.y), M31(c2.y), M31(c3.y));
+            v = v * (ac * ac) + ((g0 + g1) + ac * ((g0 - g1) * M31(a.x.iyt[i] >> 1)));
+          }
+          a.x.fold_dst[0][i] = v.a.a.v; a.x.fold_dst[1][i] = v.a.b.v; a.x.fold_dst[2][i] = v.b.a.v; a.x.fold_dst[3][i] = v.b.b.v;
+          uint32_t z[16];
+#pragma unroll
+          for (int k = 0; k < 16; k++) z[k] = 0;
+          z[0] = v.a.a.v; z[1] = v.a.b.v; z[2] = v.b.a.v; z[3] = v.b.b.v;
+          NodeFrame<RFC> fr(false, 4);
+          fr.init(h);
+          fr.absorb(h, z, 16);
+        } else
         merkle_node_thread<RFC>(ch, a.cols, c_begin, c_end, i, h);
         uint4* o = reinterpret_cast<uint4*>(a.layers[l] + (size_t)i * 8);
         o[0] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -465,6 +490,8 @@ __global__ void __launch_bounds__(256) k_merkle_top(MerkleTopArgs a) {
     __syncthreads();
     cur ^= 1;
   }
+  // the transcript step behind the tree (FRI layer trees): the root sits in buf[cur ^ 1][0..8)
+  if (a.x.chan && tid < 4) chan_mix_root_draw_quad(tid, a.x.chan, buf[cur ^ 1], a.x.felt_out, a.x.root_log, s_x8, s_felt);
 }
 
 // One layer, one node per quad of lanes: for mid-size layers that carry hundreds of columns (poseidon2: 443

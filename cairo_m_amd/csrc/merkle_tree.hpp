@@ -86,6 +86,8 @@ struct MerkleTree {
   // it enqueues the next phase (Prover::pace): its wake-up and launch latency hide behind the tree top.
   hipEvent_t pace_ev = nullptr;
   bool pace_recorded = false;
+  MerkleTopExtra top_extra;                      // extras of the tree-top launch (engine.hpp): set before plan_commit()
+  bool top_launch_has_extras = false, top_launch_has_fold = false;   // what the last plan_commit() could place
   const uint32_t* const* d_cols_view = nullptr;  // device copy of `cols` inside somebody else's upload (UploadBatch)
   const uint32_t* const* dcols() const { return d_cols_view ? d_cols_view : d_cols.as<const uint32_t*>(); }
 
@@ -127,6 +129,7 @@ struct MerkleTree {
     const int tail_top = (int)std::min<uint32_t>(max_log, MERKLE_TAIL_LOG);
     static const bool use_top = getenv("CM_NO_MERKLE_TOP") == nullptr;   // A/B switch
     pace_recorded = false;
+    top_launch_has_extras = top_launch_has_fold = false;
     bool pace_planned = false;
     auto push = [&](int hi, int lo, std::function<void(hipStream_t)> f) {
       const bool pace = !pace_planned && hi <= (int)MERKLE_PACE_LOG;
@@ -156,6 +159,10 @@ struct MerkleTree {
             layers[l].alloc((size_t)32 << l);
             a.layers[l] = layers[l].u32();
           }
+          a.x = top_extra;
+          if (log != (int)max_log) a.x.fold_mode = 0;   // the fold makes the leaf level: only a launch that starts there may carry it
+          top_launch_has_extras = a.x.chan != nullptr;
+          top_launch_has_fold = a.x.fold_mode != 0;
           push(log, 0, [a](hipStream_t st) mutable { merkle_top(a, st); });
           return plan;
         }

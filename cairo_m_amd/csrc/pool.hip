@@ -266,7 +266,7 @@ struct SideStreams {
   hipEvent_t done[Fork::N], fork_ev;
   uint32_t* flags = nullptr;       // device: one word per side stream
   uint32_t* timed_out = nullptr;   // pinned
-  uint32_t epoch = 0;
+  uint32_t epoch = 0, fork_epoch = 0;
   unsigned long long limit_ticks = 0;
   SideStreams() {
     for (int i = 0; i < Fork::N; i++) {
@@ -275,8 +275,8 @@ struct SideStreams {
     }
     CM_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
     const int mem = getenv("CM_FLAG_MEM") ? atoi(getenv("CM_FLAG_MEM")) : 0;   // development: 0 device, 1 fine-grained device, 2 pinned host
-    if (mem == 2) CM_HIP(hipHostMalloc((void**)&flags, Fork::N * 4, hipHostMallocDefault));
-    else if (mem == 1) CM_HIP(hipExtMallocWithFlags((void**)&flags, Fork::N * 4, hipDeviceMallocFinegrained));
+    if (mem == 2) CM_HIP(hipHostMalloc((void**)&flags, (Fork::N + 1) * 4, hipHostMallocDefault));
+    else if (mem == 1) CM_HIP(hipExtMallocWithFlags((void**)&flags, (Fork::N + 1) * 4, hipDeviceMallocFinegrained));
     else CM_HIP(hipMalloc((void**)&flags, Fork::N * 4));
     CM_HIP(hipMemset(flags, 0, Fork::N * 4));
     CM_HIP(hipDeviceSynchronize());   // (hipMemset runs on the NULL stream, the library's streams are non-blocking)
@@ -323,7 +323,22 @@ hipStream_t thread_priority_stream(int rel) {
   }
   return s;
 }
-Fork::Fork(hipStream_t main_stream) : main(main_stream) { CM_HIP(hipEventRecord(side().fork_ev, main)); }
+// Fork by flags (round 5), the mirror image of the flag join: a one-thread kernel on the main stream stores the fork's epoch, and
+// every side stream starts with a one-wave collector that polls it — 3-8 us from the end of the main stream's kernel to the start
+// of the side kernels instead of 10-30 us through an event and a barrier packet per side stream (tools/flagjoin_lab.hip).
+// CM_FLAG_FORK=0: the event form.
+static bool flag_fork_on() {
+  static const bool on = !(getenv("CM_FLAG_FORK") && atoi(getenv("CM_FLAG_FORK")) == 0);
+  return on;
+}
+Fork::Fork(hipStream_t main_stream) : main(main_stream) {
+  SideStreams& ss = side();
+  if (flag_fork_on()) {
+    fork_epoch = ++ss.fork_epoch;
+    hipLaunchKernelGGL(k_join_flag, dim3(1), dim3(1), 0, main, ss.flags + N, fork_epoch);
+    CM_HIP(hipGetLastError());
+  } else CM_HIP(hipEventRecord(ss.fork_ev, main));
+}
 int Fork::main_or(int side_index) {
   static const bool on = !(getenv("CM_FORK_MAIN") && atoi(getenv("CM_FORK_MAIN")) == 0);
   return on ? MAIN : side_index;
@@ -333,7 +348,10 @@ hipStream_t Fork::stream(int i) {
   i = ((i % N) + N) % N;
   SideStreams& ss = side();
   if (!(used & (1u << i))) {
-    CM_HIP(hipStreamWaitEvent(ss.s[i], ss.fork_ev, 0));
+    if (flag_fork_on()) {
+      hipLaunchKernelGGL(k_join_collect, dim3(1), dim3(64), 0, ss.s[i], ss.flags + N, 1u, fork_epoch, ss.limit_ticks, ss.timed_out);
+      CM_HIP(hipGetLastError());
+    } else CM_HIP(hipStreamWaitEvent(ss.s[i], ss.fork_ev, 0));
     used |= 1u << i;
   }
   return ss.s[i];

@@ -104,5 +104,35 @@ int main() {
     printf("%-48s median %7.1f us   min %7.1f   max %7.1f%s\n", c.name, gaps[reps / 2], gaps[0], gaps[reps - 1], *timed_out ? "   (a poll TIMED OUT)" : "");
     *timed_out = 0;
   }
+  // ---- the FORK side: main runs kernel A, then S side streams each start one kernel that must come after A -------------------
+  //   events : hipEventRecord(main) behind A + hipStreamWaitEvent on every side stream (what Fork::Fork / Fork::stream do)
+  //   flags  : a one-thread kernel behind A on main stores the epoch; every side stream first runs a one-wave collector that polls it
+  // Reports (start of the LAST side kernel to start) - (end of A), median.
+  printf("\n-- fork: side kernels behind a kernel on main --\n");
+  for (int S : {1, 3, 7})
+    for (int mode = 0; mode < 2; mode++) {
+      std::vector<double> gaps;
+      for (int r = 0; r < reps; r++) {
+        epoch++;
+        hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, main_s, us2t(200), t + 0);
+        if (mode == 0) {
+          CK(hipEventRecord(fork_ev, main_s));
+          for (int i = 0; i < S; i++) CK(hipStreamWaitEvent(side[i], fork_ev, 0));
+        } else {
+          hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, main_s, flags_dev + 8, epoch);
+          for (int i = 0; i < S; i++) hipLaunchKernelGGL(collect, dim3(1), dim3(64), 0, side[i], flags_dev + 8, 1, epoch, us2t(5e5), timed_out);
+        }
+        for (int i = 0; i < S; i++) hipLaunchKernelGGL(mark, dim3(1), dim3(64), 0, side[i], t + 1 + i);
+        CK(hipStreamSynchronize(main_s));
+        for (int i = 0; i < S; i++) CK(hipStreamSynchronize(side[i]));
+        unsigned long long last_start = 0;
+        for (int i = 0; i < S; i++) last_start = std::max(last_start, t[1 + i]);
+        gaps.push_back(((double)last_start - (double)t[0]) * us_per_tick);
+      }
+      std::sort(gaps.begin(), gaps.end());
+      printf("%s %d sides                                  median %7.1f us   min %7.1f   max %7.1f%s\n", mode ? "flags " : "events", S, gaps[reps / 2], gaps[0],
+             gaps[reps - 1], *timed_out ? "   (a poll TIMED OUT)" : "");
+      *timed_out = 0;
+    }
   return 0;
 }
