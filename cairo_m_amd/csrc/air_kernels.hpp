@@ -35,6 +35,9 @@ void launch_clock_update_trace(const void* rows, uint32_t n, uint32_t log_size, 
 void launch_poseidon2_trace(const void* init, uint32_t ni, const void* fin, uint32_t nf, uint32_t log_size,
                             uint32_t* const* d_cols, hipStream_t st);
 void launch_hist(int cid, const uint32_t* const* d_cols, uint32_t log_size, const HistPtrs& h, hipStream_t st);
+// both in one launch (the histogram from the row still in registers): the prover's path for the large components
+void launch_opcode_trace_hist(int cid, const void* bundles, uint32_t n, const void* acc, uint32_t log_size, uint32_t* const* d_cols,
+                              const HistPtrs& h, hipStream_t st);
 void launch_logup(int cid, const uint32_t* const* d_cols, const uint32_t* const* d_pp, uint32_t log_size,
                   const DevRelations* d_rels, uint32_t* const* d_out, hipStream_t st);
 void launch_constraints(int cid, const ConstraintArgs& a, hipStream_t st);

@@ -71,7 +71,8 @@ struct HistEval : air::LogupStream<HistEval, M31, EmptyEF> {
   int ci = 0;
   HistPtrs h;
   uint32_t* lds;  // [rc20: HIST_SMALL][rc16: HIST_SMALL][rc8: 256][cache tags][cache counts], block-private
-  __device__ M31 next() { return M31(cols[ci++][row]); }
+  const M31* vals = nullptr;   // the row's trace cells still in registers (k_opcode_trace_hist), else read back from `cols`
+  __device__ M31 next() { return vals ? vals[ci++] : M31(cols[ci++][row]); }
   __device__ M31 preproc(int) { return M31(); }
   __device__ M31 c(uint32_t v) { return M31(v); }
   __device__ void constraint(M31) {}

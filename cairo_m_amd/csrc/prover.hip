@@ -537,8 +537,12 @@ struct SegmentProver {
         if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
         hipStream_t sc = fk.stream(spos == 0 ? Fork::main_or(0) : spos % fork_width(Fork::N - 2));   // by_size: the first one is the largest
         spos++;
-        launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
-        launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, sc);
+        static const bool fuse_th = !(getenv("CM_TRACE_HIST_FUSE") && atoi(getenv("CM_TRACE_HIST_FUSE")) == 0);   // A/B
+        if (fuse_th) launch_opcode_trace_hist(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), h, sc);
+        else {
+          launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
+          launch_hist(c, (const uint32_t* const*)tr_evals.dev(tr0[c]), clog[c], h, sc);
+        }
       }
       launch_memory_trace(din.init_mem.p, (uint32_t)in.n_initial_memory, din.fin_mem.p, (uint32_t)in.n_final_memory, in.initial_root,
                           in.final_root, clog[air::C_MEMORY], tr_evals.dev(tr0[air::C_MEMORY]), fk.stream(air::C_MEMORY));
@@ -633,6 +637,8 @@ struct SegmentProver {
     static const bool defer_tail = !(getenv("CM_LOGUP_DEFER") && atoi(getenv("CM_LOGUP_DEFER")) == 0);
     std::vector<DevBuf> tail_scratch;   // alive until the host has seen the sums
     Prover::DeferredCols late;
+    Prover::CommitPrep tree2_prep;
+    bool tree2_prepared = false;
     {
       std::vector<uint32_t> logs;
       for (int c = 0; c < air::N_COMPONENTS; c++) {
@@ -677,6 +683,23 @@ struct SegmentProver {
                      drel.as<DevRelations>(), it_evals.dev(it0[c]), fk.stream(spos == 0 ? Fork::main_or(0) : spos % lw));
         spos++;
       }
+      // Tree 2's host-side preparation (size groups, pointer tables, layer buffers, launch plan: ~0.1 ms for 1036 columns) HERE,
+      // while the LogUp kernels just launched execute — it used to sit between the LogUp tail and the first transform with the
+      // GPU idle (50 us in the round-5 timeline).  Its one host->device copy lands on the main stream behind the region's
+      // largest kernel.  CM_COMMIT_PREP_EARLY=0: prepared at the launch (A/B).
+      static const bool prep_early = !(getenv("CM_COMMIT_PREP_EARLY") && atoi(getenv("CM_COMMIT_PREP_EARLY")) == 0);
+      if (defer_tail) {
+        late.late.assign(it_evals.ptrs.size(), 0);
+        for (int c = 0; c < air::N_COMPONENTS; c++)
+          for (int k = 0; k < 4; k++) late.late[it0[c] + air::component_info(c).n_interaction - 4 + k] = 1;
+      }
+      if (prep_early) {
+        CommittedTree& t = P.trees[2];
+        t.coeffs = std::move(it_evals);   // (the kernels above hold the column pointers; the arena just changes its owner)
+        t.merkle.pace_ev = Prover::pace_event(2);
+        tree2_prep = P.commit_prepare(t, nullptr, true, st, true, /*evals_in_place=*/true, P.pipe_stream(), defer_tail ? &late : nullptr);
+        tree2_prepared = true;
+      }
       fk.join();
       kreg.close();
       ht.mark("interaction: logup launched + joined");
@@ -686,9 +709,6 @@ struct SegmentProver {
         hipEvent_t e = Prover::pipe_event();
         CM_HIP(hipEventRecord(e, st));
         CM_HIP(hipStreamWaitEvent(sf, e, 0));
-        late.late.assign(it_evals.ptrs.size(), 0);
-        for (int c = 0; c < air::N_COMPONENTS; c++)
-          for (int k = 0; k < 4; k++) late.late[it0[c] + air::component_info(c).n_interaction - 4 + k] = 1;
       }
       logup_finalize_all(jobs, d_sums, sf, defer_tail ? &tail_scratch : nullptr);
       static_assert(PIN_SUMS + air::N_COMPONENTS * 4 <= PIN_COEFF, "pinned slot layout");
@@ -705,7 +725,8 @@ struct SegmentProver {
     ht.mark("interaction: tail enqueued");
     P.tick("interaction_gen");
     // interpolate in place: coeffs alias the evaluation buffer (every size group right in front of its extension)
-    {
+    if (tree2_prepared) P.commit_launch(tree2_prep);
+    else {
       CommittedTree& t = P.trees[2];
       t.coeffs = std::move(it_evals);
       t.merkle.pace_ev = Prover::pace_event(2);

@@ -153,11 +153,39 @@ struct Prover {
   // Columns whose evaluations are still being finished on another stream when the tree is enqueued (tree 2: the four running-sum
   // columns of every component while the LogUp tail runs): transformed last within their size group, behind `ready`.
   struct DeferredCols { std::vector<char> late; hipEvent_t ready = nullptr; };
+  // commit_enqueue = commit_prepare (host-only work + ONE host->device copy of every table of the tree, enqueued on `s`) followed
+  // by commit_launch (the transforms and Merkle launches).  Callers that have GPU work in flight call commit_prepare EARLY — the
+  // interaction phase right behind its LogUp launches: the ~0.1 ms the host spends on the 1036 columns of tree 2 (size groups,
+  // pointer tables, layer buffers, the launch plan) then runs while the LogUp kernels execute instead of between the LogUp tail
+  // and the first transform (round-5 timeline: 50 us of idle GPU there).
+  struct Grp { uint32_t log, n; size_t off; uint32_t n_early; };
+  struct CommitPrep {
+    CommittedTree* t = nullptr;
+    bool from_coeffs = false, with_merkle = true, evals_in_place = false;
+    hipStream_t s = nullptr, s_tr = nullptr;
+    const DeferredCols* defer = nullptr;
+    std::vector<uint32_t> logs;
+    std::vector<Grp> grps;
+    const uint32_t** d_table = nullptr;
+    std::vector<SmallCommitJob> sjobs;
+    SmallCommitJob* d_sjobs = nullptr;
+    uint32_t small_max = 0;
+    std::vector<MerkleTree::CommitLaunch> plan;
+  };
   void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true,
                       bool evals_in_place = false, hipStream_t s_tr = nullptr, const DeferredCols* defer = nullptr) {
+    CommitPrep cp = commit_prepare(t, evals, from_coeffs, s, with_merkle, evals_in_place, s_tr, defer);
+    commit_launch(cp);
+  }
+  // `defer->late` must be final; `defer->ready` may still be null (it is read by commit_launch)
+  CommitPrep commit_prepare(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true,
+                            bool evals_in_place = false, hipStream_t s_tr = nullptr, const DeferredCols* defer = nullptr) {
     static const bool pipe_on = !(getenv("CM_COMMIT_PIPE") && atoi(getenv("CM_COMMIT_PIPE")) == 0);
     if (!pipe_on || !with_merkle || s_tr == s) s_tr = nullptr;
-    const std::vector<uint32_t>& logs = from_coeffs ? t.coeffs.logs : evals->logs;
+    CommitPrep cp;
+    cp.t = &t; cp.from_coeffs = from_coeffs; cp.with_merkle = with_merkle; cp.evals_in_place = evals_in_place; cp.s = s; cp.defer = defer;
+    cp.logs = from_coeffs ? t.coeffs.logs : evals->logs;
+    const std::vector<uint32_t>& logs = cp.logs;
     // (the host side of this function sits between two phases with the GPU idle: ~150 us for the 474 / 1036 columns of trees 1 / 2
     // before the size groups were built once instead of three times and the small columns' 1 / n came from a table)
     auto groups = by_log(logs);
@@ -167,6 +195,7 @@ struct Prover {
       for (auto& kv : groups) if (!small_commit_serves(kv.first, cfg.log_blowup_factor)) big_groups++;
       if (big_groups < 2) s_tr = nullptr;
     }
+    cp.s_tr = s_tr;
     UploadBatch ub;
     if (!from_coeffs) { t.coeffs.alloc(logs, s, false); ub.add(t.coeffs.ptrs, &t.coeffs.d_view); }
     std::vector<uint32_t> lde_logs(logs);
@@ -174,8 +203,7 @@ struct Prover {
     t.lde.alloc(lde_logs, s, false);
     ub.add(t.lde.ptrs, &t.lde.d_view);
     // pointer table of all size groups of the tree: [src | coeffs | lde] per group
-    struct Grp { uint32_t log, n; size_t off; uint32_t n_early; };
-    std::vector<Grp> grps;
+    std::vector<Grp>& grps = cp.grps;
     std::vector<const uint32_t*> table;
     table.reserve(3 * logs.size());
     for (auto& kv : groups) {
@@ -188,17 +216,15 @@ struct Prover {
       for (auto i : kv.second) table.push_back(t.lde.ptrs[i]);
       grps.push_back(g);
     }
-    const uint32_t** d_table = nullptr;
-    ub.add(table, &d_table);
+    ub.add(table, &cp.d_table);
     std::vector<const uint32_t*> cols(t.lde.ptrs.begin(), t.lde.ptrs.end());
     if (with_merkle) {        // (the sharded prover hashes row slices of the LDE instead: prover_sharded.inc)
       t.merkle.prepare(cols, t.lde.logs);
       ub.add(t.merkle.cols, &t.merkle.d_cols_view);
     }
     // small columns of every size: ONE fused interpolate + extend launch for all of them (k_small_commit)
-    std::vector<SmallCommitJob> sjobs;
+    std::vector<SmallCommitJob>& sjobs = cp.sjobs;
     sjobs.reserve(logs.size());
-    uint32_t small_max = 0;
     static const std::array<uint32_t, 31> inv_pow2 = [] {   // 1 / 2^k in M31 (a host inversion per small column was ~50 us per tree)
       std::array<uint32_t, 31> a{};
       for (uint32_t k = 0; k < 31; k++) a[k] = inv(M31::from_u32(1u << k)).v;
@@ -208,11 +234,24 @@ struct Prover {
       if (small_commit_serves(logs[i], cfg.log_blowup_factor)) {
         const uint32_t* src = !from_coeffs ? evals->ptrs[i] : evals_in_place ? t.coeffs.ptrs[i] : nullptr;
         sjobs.push_back(SmallCommitJob{src, t.coeffs.ptrs[i], t.lde.ptrs[i], logs[i], inv_pow2[logs[i]]});
-        small_max = std::max(small_max, logs[i]);
+        cp.small_max = std::max(cp.small_max, logs[i]);
       }
-    SmallCommitJob* d_sjobs = nullptr;
-    if (!sjobs.empty()) ub.add(sjobs, &d_sjobs);
+    if (!sjobs.empty()) ub.add(sjobs, &cp.d_sjobs);
     t.tables = ub.flush(s);   // ONE host->device copy for the whole tree
+    if (with_merkle && s_tr) cp.plan = t.merkle.plan_commit();
+    return cp;
+  }
+  void commit_launch(CommitPrep& cp) {
+    CommittedTree& t = *cp.t;
+    const bool from_coeffs = cp.from_coeffs, with_merkle = cp.with_merkle, evals_in_place = cp.evals_in_place;
+    hipStream_t s = cp.s, s_tr = cp.s_tr;
+    const DeferredCols* defer = cp.defer;
+    const std::vector<uint32_t>& logs = cp.logs;
+    std::vector<Grp>& grps = cp.grps;
+    const uint32_t** d_table = cp.d_table;
+    std::vector<SmallCommitJob>& sjobs = cp.sjobs;
+    SmallCommitJob* d_sjobs = cp.d_sjobs;
+    const uint32_t small_max = cp.small_max;
     hipStream_t ts = s;       // the stream of the transforms
     if (s_tr) {               // the tables (and whatever else sits in front of this tree on `s`) first
       hipEvent_t e = pipe_event();
@@ -220,9 +259,8 @@ struct Prover {
       CM_HIP(hipStreamWaitEvent(s_tr, e, 0));
       ts = s_tr;
     }
-    std::vector<MerkleTree::CommitLaunch> plan;
+    std::vector<MerkleTree::CommitLaunch>& plan = cp.plan;
     size_t next_launch = 0;
-    if (with_merkle && s_tr) plan = t.merkle.plan_commit();
     // the Merkle launches whose columns all have at least 2^ready_log rows: behind what `ts` holds right now
     auto hash_ready = [&](int ready_log) {
       if (!s_tr) return;

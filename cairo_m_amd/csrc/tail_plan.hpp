@@ -161,13 +161,15 @@ struct DeviceTail {
     pf.decommitments.resize(4);
     pf.queried_values.resize(4);
     pf.fri_inner.resize(fri.inner.size());
+    // one pass per vector: bulk assign from the pinned words (no zero-fill first, no element-wise push_back)
+    static_assert(sizeof(Hash32) == 32 && sizeof(QM31) == 16, "witness words map onto the proof's element types");
     auto hashes = [&](std::vector<Hash32>& v, const uint32_t* w, size_t words) {
-      v.resize(words / 8);
-      if (words) memcpy(v[0].data(), w, words * 4);
+      const Hash32* p = reinterpret_cast<const Hash32*>(w);
+      v.assign(p, p + words / 8);
     };
     auto felts = [&](std::vector<QM31>& v, const uint32_t* w, size_t words) {
-      v.reserve(words / 4);
-      for (size_t i = 0; i < words; i += 4) v.push_back(QM31::from_u32(w + i));
+      const QM31* p = reinterpret_cast<const QM31*>(w);   // QM31 = four canonical M31 words (QM31::from_u32 copies them)
+      v.assign(p, p + words / 4);
     };
     for (const Span& sp : spans) {
       const uint32_t* w = h_out + off[sp.d0];
