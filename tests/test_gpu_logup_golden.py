@@ -1,0 +1,87 @@
+"""`write_interaction_trace` as the GPU runs it: for each of the 26 opcode components the reference-derived TRACE cells
+(tests/golden/air_witness_vectors.npz, from the reference's `write_trace` closures) go through the HIP k_logup / LogUp-tail kernels
+(cm_interaction_write) under fixed relation parameters, and the interaction columns must equal the reference-derived LogUp
+vectors (tests/golden/air_logup_vectors.npz: tools/rsref/rs_logup.py interprets the reference's `write_interaction_trace` text —
+which lookup tuples pair up in which column, every numerator and denominator — on the lookup data the same run's `write_trace`
+produced).  Nothing of cairo_m_amd/csrc/air/*.hpp, of the oracle or of the library's field code is on the expected side; the
+arithmetic HERE is QM31 addition only.
+
+Column j < last: the HIP column (4 coordinate columns) == sum of the fractions of columns 0..j of the row — exactly what
+LogupTraceGenerator::finalize_col leaves there.  The LAST column is prefix-summed over the rows by finalize_last; with T(r) the
+row's total and shift = claimed_sum / n it satisfies c(r) - c(prev(r)) = T(r) - shift for the cyclic predecessor prev(r) of the
+trace domain, so — independent of the row order convention — the multiset { c(r) - T(r) + shift } equals the multiset { c(r) },
+and the returned claimed sum equals sum_r T(r)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WIT = np.load(os.path.join(ROOT, "tests", "golden", "air_witness_vectors.npz"))
+LOG = np.load(os.path.join(ROOT, "tests", "golden", "air_logup_vectors.npz"))
+from tests.test_air_witness_golden import OPCODE_FILES  # noqa: E402
+
+P = 2**31 - 1
+N_REL, MAX_REL, N_PP = 8, 16, 7
+
+
+def cmul(x, y):
+    return ((x[0] * y[0] - x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P)
+
+
+def qmul(x, y):
+    a, b, c, d = x[:2], x[2:], y[:2], y[2:]
+    ac, bd = cmul(a, c), cmul(b, d)
+    r = cmul(bd, (2, 1))
+    ad, bc = cmul(a, d), cmul(b, c)
+    return ((ac[0] + r[0]) % P, (ac[1] + r[1]) % P, (ad[0] + bc[0]) % P, (ad[1] + bc[1]) % P)
+
+
+def relation_words():
+    """cm_relations: z[8][4] then alpha_pow[8][16][4]"""
+    z = LOG["rel_z"].astype(np.uint32)
+    pw = np.zeros((N_REL, MAX_REL, 4), dtype=np.uint32)
+    for r in range(N_REL):
+        a, cur = tuple(int(x) for x in LOG["rel_alpha"][r]), (1, 0, 0, 0)
+        for i in range(MAX_REL):
+            pw[r, i] = cur
+            cur = qmul(cur, a)
+    return np.concatenate([z.reshape(-1), pw.reshape(-1)])
+
+
+def test_same_run_as_the_witness_vectors():
+    assert int(LOG["iters"][0]) == int(WIT["iters"][0]) and int(LOG["seed"][0]) == int(WIT["seed"][0])
+    assert all(f in LOG.files for f in OPCODE_FILES)
+
+
+@pytest.mark.parametrize("cid", range(26), ids=OPCODE_FILES)
+def test_hip_logup_columns_equal_reference_derived_fractions(backend, cid):
+    name = OPCODE_FILES[cid]
+    trace, want = WIT[name], LOG[name].astype(np.int64)            # (n_trace, n) / (n_cols, n, 4)
+    n = trace.shape[1]
+    log = n.bit_length() - 1
+    n_trace, n_inter, _ = backend.component_info(cid)
+    assert trace.shape[0] == n_trace and want.shape == (n_inter // 4, n, 4)
+    h_tr = [backend.upload(np.ascontiguousarray(trace[c])) for c in range(n_trace)]
+    h_pp = [backend.upload(np.zeros(n, dtype=np.uint32)) for _ in range(N_PP)]     # opcode components read no preprocessed column
+    h_out = [backend.col_alloc(n) for _ in range(n_inter)]
+    try:
+        cs = backend.interaction_write(cid, h_tr, h_pp, log, relation_words(), h_out)
+        got = np.stack([backend.download(h, n) for h in h_out]).astype(np.int64).reshape(n_inter // 4, 4, n)
+        last = n_inter // 4 - 1
+        for j in range(last):
+            bad = np.argwhere(got[j].T != want[j])
+            assert bad.size == 0, f"{name}: LogUp column {j}: first differing (row, coordinate) {bad[:4].tolist()}"
+        total = want[last]                                              # T(r): all fractions of row r
+        claimed = total.sum(axis=0) % P
+        assert [int(x) for x in cs] == [int(x) for x in claimed], f"{name}: claimed sum"
+        shift = claimed * pow(n, P - 2, P) % P
+        c = got[last].T                                                 # (n, 4)
+        lhs = (c - total + shift) % P
+        key = lambda a: sorted(map(tuple, a.tolist()))
+        assert key(lhs) == key(c), f"{name}: last column is not the running sum of the row totals minus the shift"
+        assert np.any(total % P)                                        # the vectors are not trivially zero
+    finally:
+        for h in h_tr + h_pp + h_out:
+            backend.col_free(h)

@@ -109,7 +109,7 @@ def pack(bundles, row):
                   span_start=[l[10] for l in lanes], span_len=[l[11] for l in lanes])
 
 
-def interpret_component(fname, bundles, accesses, consts):
+def interpret_component(fname, bundles, accesses, consts, keep_lookup=None):
     src = strip_comments(open(f"{REF}/prover/src/components/opcodes/{fname}.rs").read())
     m = re.search(CLOSURE_RE, src)
     if not m:
@@ -141,6 +141,8 @@ def interpret_component(fname, bundles, accesses, consts):
         env.vars.update({"row_index": vec_row, "row": row, "input": pack(bundles, vec_row), "lookup_data": ld})
         interp.eval(block, env)
         assert sorted(row.d) == list(range(n_cols)), (fname, sorted(row.d))
+        if keep_lookup is not None:
+            keep_lookup.append(ld)       # tools/rsref/rs_logup.py: the closure's `lookup_data` of this packed row
         for c in range(n_cols):
             out[c, vec_row * N_LANES:(vec_row + 1) * N_LANES] = [x.v for x in row.d[c].lanes]
     return out
@@ -179,7 +181,7 @@ def closure_text(src, anchor_re):
     return src[i:j - 1].strip().rstrip(",").strip()
 
 
-def interpret_prepacked(fname, bundles, accesses, consts):
+def interpret_prepacked(fname, bundles, accesses, consts, keep_lookup=None):
     """store_fp_fp.rs / store_fp_imm.rs: write_trace first maps every chunk of 16 bundles through a closure that packs them AND
     derives per-lane hints (operand inverse, two opcode-flag bits), then runs the row closure on (input, hints...).  Both
     closures are interpreted.  The one construct outside the interpreter's subset — a `match` on the Instruction variant that
@@ -213,6 +215,8 @@ def interpret_prepacked(fname, bundles, accesses, consts):
         row, ld = Slots(), LookupData()
         rowfn((vec_row, (row, packed, ld)))
         assert sorted(row.d) == list(range(n_cols)), (fname, sorted(row.d))
+        if keep_lookup is not None:
+            keep_lookup.append(ld)
         for c in range(n_cols):
             out[c, vec_row * N_LANES:(vec_row + 1) * N_LANES] = [x.v for x in row.d[c].lanes]
     return out
