@@ -246,8 +246,8 @@ def main():
     ap.add_argument("--big-fib-n", type=int, default=1_677_000,
                     help="untimed-line leg: fibonacci_loop whose largest LDE column has 2^24 rows (BASELINE configs[3] size on ONE GPU); 0 = skip")
     ap.add_argument("--big-mixed-iters", type=int, default=0,
-                    help="untimed-line leg: all-opcodes loop (BASELINE configs[4]); 1_163_000 iterations = 2^26 rows, ~116 GiB and ~2 min of "
-                         "host-side input generation: off by default, run by tools/measure_round.sh")
+                    help="untimed-line leg: all-opcodes loop (BASELINE configs[4]); 1_545_000 iterations = 2^26 rows, ~116 GiB of HBM and "
+                         "about a minute of host-side input generation: off by default, run by tools/measure_round.sh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-timeout", type=int, default=300, help="N > 1: time limit in seconds of the sharded-mode child job")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the second mode (one proof sharded over all ranks)")
@@ -426,10 +426,10 @@ def main():
     if world == 1 and rank == 0:
         # whole-path model at the larger sizes north_star names (same 52 B / cell model): the share of protocol-serial latency
         # (17 tree tops, 12 FRI layers, transcript steps) shrinks with the size, so the fraction of the HBM roofline rises
-        def leg(name, make_input, reps):
+        def leg(name, make_input, reps, upload=None):
             try:
                 b_inp = make_input()
-                b_dev = be.upload_input(b_inp)
+                b_dev = (upload or be.upload_input)(b_inp)
                 be.prove_device(b_dev).free()
                 torch.cuda.synchronize()
                 tb = time.perf_counter()
@@ -439,7 +439,7 @@ def main():
                     pb.free()
                 torch.cuda.synchronize()
                 b_dt = (time.perf_counter() - tb) / reps
-                big_legs.append({"workload": name, "vm_steps": b_inp.steps, "cells": b_stats["cells"], "ms_per_proof": b_dt * 1e3,
+                big_legs.append({"workload": name, "vm_steps": b_stats["steps"], "cells": b_stats["cells"], "ms_per_proof": b_dt * 1e3,
                                  "value": b_stats["cells"] / b_dt, "unit": "M31 trace cells/s",
                                  "largest_column_log2": max(be.component_log_size(b_dev, c) for c in range(34)),
                                  "whole_path_model": {"bytes_per_cell": MODEL_BYTES_PER_CELL,
@@ -455,10 +455,10 @@ def main():
             leg(f"fibonacci_loop n={args.big_fib_n} (one segment, 2^24-row LDE columns; BASELINE configs[3] size on one GPU)",
                 lambda: synth_fibonacci(args.big_fib_n), 2)
         if args.big_mixed_iters > 0:
-            from cairo_m_amd.lib import vm_run
+            from cairo_m_amd.lib import vm_segment
             from cairo_m_amd.workloads import all_opcodes_program
-            leg(f"all-opcodes loop, {args.big_mixed_iters} iterations (BASELINE configs[4] on one GPU)",
-                lambda: vm_run(all_opcodes_program(args.big_mixed_iters)[0], entry_pc=0, args=(), n_returns=0), 1)
+            leg(f"all-opcodes loop, {args.big_mixed_iters} iterations (BASELINE configs[4] on one GPU; runner segment -> device adapter)",
+                lambda: vm_segment(all_opcodes_program(args.big_mixed_iters)[0], entry_pc=0, args=(), n_returns=0), 1, upload=be.adapt_segment)
 
     sharded = None
     if world > 1 and not args.no_sharded:
