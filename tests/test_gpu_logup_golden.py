@@ -1,4 +1,4 @@
-"""`write_interaction_trace` as the GPU runs it: for each of the 26 opcode components the reference-derived TRACE cells
+"""`write_interaction_trace` as the GPU runs it: for each of the 26 opcode components and for memory, merkle and clock_update the reference-derived TRACE cells
 (tests/golden/air_witness_vectors.npz, from the reference's `write_trace` closures) go through the HIP k_logup / LogUp-tail kernels
 (cm_interaction_write) under fixed relation parameters, and the interaction columns must equal the reference-derived LogUp
 vectors (tests/golden/air_logup_vectors.npz: tools/rsref/rs_logup.py interprets the reference's `write_interaction_trace` text —
@@ -52,12 +52,17 @@ def relation_words():
 
 def test_same_run_as_the_witness_vectors():
     assert int(LOG["iters"][0]) == int(WIT["iters"][0]) and int(LOG["seed"][0]) == int(WIT["seed"][0])
-    assert all(f in LOG.files for f in OPCODE_FILES)
+    assert all(f in LOG.files for f in NAMES)
 
 
-@pytest.mark.parametrize("cid", range(26), ids=OPCODE_FILES)
+# component id -> name in the golden files: the 26 opcode components, then memory / merkle / clock_update (the builtins whose
+# write_trace closure has the regular shape; clock_update on the synthetic entries of tools/rsref/rs_witness.py)
+NAMES = list(OPCODE_FILES) + ["memory", "merkle", "clock_update"]
+
+
+@pytest.mark.parametrize("cid", range(29), ids=NAMES)
 def test_hip_logup_columns_equal_reference_derived_fractions(backend, cid):
-    name = OPCODE_FILES[cid]
+    name = NAMES[cid]
     trace, want = WIT[name], LOG[name].astype(np.int64)            # (n_trace, n) / (n_cols, n, 4)
     n = trace.shape[1]
     log = n.bit_length() - 1

@@ -15,7 +15,7 @@ from cairo_m_amd.workloads import all_opcodes_program
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOG = np.load(os.path.join(ROOT, "tests", "golden", "air_logup_vectors.npz"))
 from tests.test_air_witness_golden import OPCODE_FILES  # noqa: E402
-from tests.test_gpu_logup_golden import P, relation_words  # noqa: E402  (plain-Python helpers; nothing there touches a GPU at import)
+from tests.test_gpu_logup_golden import NAMES, P, relation_words  # noqa: E402  (plain-Python helpers; nothing there touches a GPU at import)
 
 
 @pytest.fixture(scope="module")
@@ -27,9 +27,10 @@ def golden_input():
     inp.free()
 
 
-@pytest.mark.parametrize("cid", range(26), ids=OPCODE_FILES)
+# (clock_update, id 28, is left to the GPU test: its golden rows are synthetic entries, not this program's — it has none)
+@pytest.mark.parametrize("cid", range(28), ids=NAMES[:28])
 def test_oracle_logup_columns_equal_reference_derived_fractions(oracle, golden_input, cid):
-    name = OPCODE_FILES[cid]
+    name = NAMES[cid]
     want = LOG[name].astype(np.int64)
     n_cols, n = want.shape[0], want.shape[1]
     log = n.bit_length() - 1

@@ -269,7 +269,10 @@ class Parser:
         return lhs
 
     def range_expr(self):
-        lhs = self.binop(0)
+        if self.at("op", "..") or self.at("op", "..="):      # `..n` / `..=n`: from zero
+            lhs = ("num", 0)
+        else:
+            lhs = self.binop(0)
         if self.at("op", "..") or self.at("op", "..="):
             incl = self.eat("op")[1] == "..="
             if self.at("op", "]") or self.at("op", ")"):

@@ -163,6 +163,43 @@ def interaction_body(src):
     return body[:body.index("let (trace, claimed_sum)")]
 
 
+def logup_columns(src, lookups, n_rows, n_live, consts, relations):
+    """interpret write_interaction_trace of `src` on the per-packed-row lookup data -> (n_columns, n_rows, 4): per column and row the
+    running sum of the fractions of columns 0..j"""
+    from rs_interp import Struct, parse_block
+    g = standard_globals()
+    g.update(consts)
+    n_vec = n_rows // N_LANES
+    gen = LogupGen(n_vec)
+    g.update({"PackedQM31::from": PQ.of, "PackedQM31::one": lambda: PQ([(1, 0, 0, 0)] * N_LANES),
+              "PackedQM31::zero": lambda: PQ([(0, 0, 0, 0)] * N_LANES),
+              "LogupTraceGenerator::new": lambda log_size: gen, "Enabler::new": lambda n: W.Enabler(n)})
+    interp = LogupInterp(g)
+    W.file_consts(src, interp)
+    # lookup_data.<kind>[i] = the per-packed-row values the write_trace closure stored
+    ld_all = W.LookupData()
+    for kind in ("memory", "registers", "range_check_8", "range_check_16", "range_check_20", "bitwise", "merkle", "poseidon2"):
+        slots = {}
+        for vec_row, ld in enumerate(lookups):
+            for idx, val in getattr(ld, kind).d.items():
+                slots.setdefault(idx, [None] * n_vec)[vec_row] = val
+        setattr(ld_all, kind, [slots[i] for i in range(len(slots))] if slots else [])
+    outer = Env()
+    outer.vars.update({"relations": relations, "interaction_claim_data": Struct(lookup_data=ld_all, non_padded_length=n_live)})
+    interp.eval(parse_block("{" + interaction_body(src) + "}"), outer)
+    assert gen.cols and all(c.done for c in gen.cols)
+    cum = np.zeros((len(gen.cols), n_rows, 4), dtype=np.uint32)
+    running = [[(0, 0, 0, 0)] * N_LANES for _ in range(n_vec)]
+    for j, col in enumerate(gen.cols):
+        for vec_row in range(n_vec):
+            num, den = col.fracs[vec_row][0]
+            for lane in range(N_LANES):
+                frac = qmul(num.lanes[lane], qinv(den.lanes[lane]))
+                running[vec_row][lane] = tuple((a + b) % P for a, b in zip(running[vec_row][lane], frac))
+                cum[j, vec_row * N_LANES + lane] = running[vec_row][lane]
+    return cum
+
+
 def main():
     from cairo_m_amd.lib import prover_input_arrays, vm_run
     from cairo_m_amd.workloads import all_opcodes_program
@@ -184,43 +221,17 @@ def main():
         cols = W.interpret_component(fname, bundles, arrs["data_accesses"], consts, keep_lookup=lookups)
         if cols is None:
             cols = W.interpret_prepacked(fname, bundles, arrs["data_accesses"], consts, keep_lookup=lookups)
-        n_rows = cols.shape[1]
         src = strip_comments(open(f"{REF}/prover/src/components/opcodes/{fname}.rs").read())
-        g = standard_globals()
-        g.update(consts)
-        n_vec = n_rows // N_LANES
-        gen = LogupGen(n_vec)
-        g.update({"PackedQM31::from": PQ.of, "PackedQM31::one": lambda: PQ([(1, 0, 0, 0)] * N_LANES),
-                  "PackedQM31::zero": lambda: PQ([(0, 0, 0, 0)] * N_LANES),
-                  "LogupTraceGenerator::new": lambda log_size: gen, "Enabler::new": lambda n: W.Enabler(n)})
-        interp = LogupInterp(g)
-        W.file_consts(src, interp)
-        # lookup_data.<kind>[i] = the per-packed-row values the write_trace closure stored
-        ld_all = W.LookupData()
-        for kind in ("memory", "registers", "range_check_8", "range_check_16", "range_check_20", "bitwise", "merkle", "poseidon2"):
-            slots = {}
-            for vec_row, ld in enumerate(lookups):
-                for idx, val in getattr(ld, kind).d.items():
-                    slots.setdefault(idx, [None] * n_vec)[vec_row] = val
-            setattr(ld_all, kind, [slots[i] for i in range(len(slots))] if slots else [])
-        from rs_interp import Struct, parse_block
-        outer = Env()
-        outer.vars.update({"relations": relations,
-                           "interaction_claim_data": Struct(lookup_data=ld_all, non_padded_length=len(bundles))})
-        interp.eval(parse_block("{" + interaction_body(src) + "}"), outer)
-        assert gen.cols and all(c.done for c in gen.cols), fname
-        cum = np.zeros((len(gen.cols), n_rows, 4), dtype=np.uint32)
-        running = [[(0, 0, 0, 0)] * N_LANES for _ in range(n_vec)]
-        for j, col in enumerate(gen.cols):
-            for vec_row in range(n_vec):
-                num, den = col.fracs[vec_row][0]
-                for lane in range(N_LANES):
-                    frac = qmul(num.lanes[lane], qinv(den.lanes[lane]))
-                    running[vec_row][lane] = tuple((a + b) % P for a, b in zip(running[vec_row][lane], frac))
-                    cum[j, vec_row * N_LANES + lane] = running[vec_row][lane]
-        blocks = gen.cols
-        out[fname] = cum
-        print(f"{cid:2d} {fname:28s} {len(bundles):4d} live rows, {len(blocks)} LogUp columns x {n_rows} rows")
+        out[fname] = logup_columns(src, lookups, cols.shape[1], len(bundles), consts, relations)
+        print(f"{cid:2d} {fname:28s} {len(bundles):4d} live rows, {out[fname].shape[0]} LogUp columns x {cols.shape[1]} rows")
+    # the builtins with a regular closure (rows as in rs_witness.py: memory, merkle, synthetic clock updates)
+    consts2, mem, tree, cu = W.builtin_inputs(arrs, consts)
+    for name, rows in (("memory", mem), ("merkle", tree), ("clock_update", cu)):
+        lookups = []
+        cols = W.interpret_builtin(name, rows, len(rows), consts2, keep_lookup=lookups)
+        src = strip_comments(open(f"{REF}/prover/src/components/{name}.rs").read())
+        out[name] = logup_columns(src, lookups, cols.shape[1], len(rows), consts2, relations)
+        print(f"   {name:28s} {len(rows):4d} live rows, {out[name].shape[0]} LogUp columns x {cols.shape[1]} rows")
     inp.free()
     path = os.path.join(ROOT, "tests", "golden", "air_logup_vectors.npz")
     np.savez_compressed(path, **out)

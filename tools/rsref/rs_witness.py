@@ -222,7 +222,7 @@ def interpret_prepacked(fname, bundles, accesses, consts, keep_lookup=None):
     return out
 
 
-def interpret_builtin(fname, rows, n_live, consts):
+def interpret_builtin(fname, rows, n_live, consts, keep_lookup=None):
     """memory.rs / merkle.rs / clock_update.rs: `input` is the packed array of input columns built in front of the closure
     (memory.rs:104-133, merkle.rs:103-132, clock_update.rs:86-104: rows padded with zeros, transposed 16 at a time)."""
     src = strip_comments(open(f"{REF}/prover/src/components/{fname}.rs").read())
@@ -253,9 +253,27 @@ def interpret_builtin(fname, rows, n_live, consts):
         env.vars.update({"row_index": vec_row, "row": row, "input": inp, "lookup_data": ld})
         interp.eval(block, env)
         assert sorted(row.d) == list(range(n_cols)), (fname, sorted(row.d))
+        if keep_lookup is not None:
+            keep_lookup.append(ld)
         for c in range(n_cols):
             out[c, vec_row * N_LANES:(vec_row + 1) * N_LANES] = [x.v for x in row.d[c].lanes]
     return out
+
+
+def builtin_inputs(arrs, consts):
+    """rows of the builtins with a regular closure: memory (initial ++ final cells), merkle (initial ++ final tree nodes),
+    clock_update (the small program has none: synthetic entries (address, prev_clock, value[4]))"""
+    consts2 = dict(consts)
+    consts2.update({"TREE_HEIGHT": 30, "RC20_LIMIT": (1 << 20) - 1})       # adapter/merkle.rs:58-62, adapter/memory.rs:16
+    roots = arrs["roots"]
+    def mem_rows(a, root):      # cm_memory_cell = (address, value[4], clock, multiplicity) -> [address, clock, v0..v3, multiplicity, root]
+        return np.array([[r[0], r[5], r[1], r[2], r[3], r[4], r[6], root] for r in a], dtype=np.int64).reshape(-1, 8)
+    def tree_rows(a, root):     # cm_merkle_node (8 words) + root
+        return np.array([list(r) + [root] for r in a], dtype=np.int64).reshape(-1, 9)
+    mem = np.concatenate([mem_rows(arrs["initial_memory"], roots[0]), mem_rows(arrs["final_memory"], roots[1])])
+    tree = np.concatenate([tree_rows(arrs["initial_tree"], roots[0]), tree_rows(arrs["final_tree"], roots[1])])
+    cu = np.array([[100 + k, 7 * k + 1, 3 * k, k, 0, k + 5] for k in range(19)], dtype=np.int64)
+    return consts2, mem, tree, cu
 
 
 def main():
@@ -274,17 +292,7 @@ def main():
         out[fname] = cols
         print(f"{cid:2d} {fname:28s} {arrs[f'bundles{cid}'].shape[0]:4d} live rows -> {cols.shape[0]} columns x {cols.shape[1]} rows")
     # builtins with a regular closure: memory (rows = initial ++ final cells), merkle (initial ++ final tree nodes), clock_update
-    consts2 = dict(consts)
-    consts2.update({"TREE_HEIGHT": 30, "RC20_LIMIT": (1 << 20) - 1})       # adapter/merkle.rs:58-62, adapter/memory.rs:16
-    roots = arrs["roots"]
-    def mem_rows(a, root):      # cm_memory_cell = (address, value[4], clock, multiplicity) -> [address, clock, v0..v3, multiplicity, root]
-        return np.array([[r[0], r[5], r[1], r[2], r[3], r[4], r[6], root] for r in a], dtype=np.int64).reshape(-1, 8)
-    def tree_rows(a, root):     # cm_merkle_node (8 words) + root
-        return np.array([list(r) + [root] for r in a], dtype=np.int64).reshape(-1, 9)
-    mem = np.concatenate([mem_rows(arrs["initial_memory"], roots[0]), mem_rows(arrs["final_memory"], roots[1])])
-    tree = np.concatenate([tree_rows(arrs["initial_tree"], roots[0]), tree_rows(arrs["final_tree"], roots[1])])
-    # clock updates: the small program has none, so the vector is made from synthetic entries (address, prev_clock, value[4])
-    cu = np.array([[100 + k, 7 * k + 1, 3 * k, k, 0, k + 5] for k in range(19)], dtype=np.int64)
+    consts2, mem, tree, cu = builtin_inputs(arrs, consts)
     for name, rows in (("memory", mem), ("merkle", tree), ("clock_update", cu)):
         out[name] = interpret_builtin(name, rows, len(rows), consts2)
         print(f"   {name:28s} {len(rows):4d} live rows -> {out[name].shape[0]} columns x {out[name].shape[1]} rows")
