@@ -327,8 +327,42 @@ hipStream_t thread_priority_stream(int rel) {
 // every side stream starts with a one-wave collector that polls it — 3-8 us from the end of the main stream's kernel to the start
 // of the side kernels instead of 10-30 us through an event and a barrier packet per side stream (tools/flagjoin_lab.hip).
 // CM_FLAG_FORK=0: the event form.
+// Flag synchronisation needs kernels of different streams to RUN CONCURRENTLY: a collector spins until a flag kernel on another
+// stream has run.  Tools that serialise kernel execution — rocprofv3 with --pmc (counter collection runs one kernel at a time),
+// some debuggers — turn that into a wait for the collector's time limit (the first PMC pass of round 5's measurement script sat in
+// it until gpurun's limit).  One self-test per process decides: a collector with a 100 ms limit on one stream, THEN its flag kernel
+// on another; where kernels overlap it returns in microseconds, under a serialising tool it times out once and every fork / join
+// of the process uses events.
+static bool flag_sync_usable() {
+  static const bool ok = [] {
+    hipStream_t a = nullptr, b = nullptr;
+    uint32_t *flag = nullptr, *to = nullptr;
+    bool good = false;
+    if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&b, hipStreamNonBlocking) == hipSuccess &&
+        hipMalloc((void**)&flag, 4) == hipSuccess && hipHostMalloc((void**)&to, 64, hipHostMallocDefault) == hipSuccess) {
+      memset(to, 0, 64);
+      int dev = 0, rate_khz = 100000;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
+      if (hipMemsetAsync(flag, 0, 4, a) == hipSuccess && hipStreamSynchronize(a) == hipSuccess) {
+        hipLaunchKernelGGL(k_join_collect, dim3(1), dim3(64), 0, a, flag, 1u, 1u, (unsigned long long)(0.1 * 1e3 * (double)rate_khz), to);
+        hipLaunchKernelGGL(k_join_flag, dim3(1), dim3(1), 0, b, flag, 1u);
+        good = hipStreamSynchronize(b) == hipSuccess && hipStreamSynchronize(a) == hipSuccess && to[0] == 0;
+      }
+    }
+    if (flag) (void)hipFree(flag);
+    if (to) (void)hipHostFree(to);
+    if (a) (void)hipStreamDestroy(a);
+    if (b) (void)hipStreamDestroy(b);
+    if (!good && getenv("CM_QUIET") == nullptr)
+      fprintf(stderr, "[cairom_hip] kernels of different streams do not run concurrently here (a profiler collecting counters?): "
+                      "fork / join through events instead of flags\n");
+    return good;
+  }();
+  return ok;
+}
 static bool flag_fork_on() {
-  static const bool on = !(getenv("CM_FLAG_FORK") && atoi(getenv("CM_FLAG_FORK")) == 0);
+  static const bool on = !(getenv("CM_FLAG_FORK") && atoi(getenv("CM_FLAG_FORK")) == 0) && flag_sync_usable();
   return on;
 }
 Fork::Fork(hipStream_t main_stream) : main(main_stream) {
@@ -454,7 +488,7 @@ void Fork::join() {
   if (joined) return;
   joined = true;
   SideStreams& ss = side();
-  static const bool flag_join = !(getenv("CM_FLAG_JOIN") && atoi(getenv("CM_FLAG_JOIN")) == 0);
+  static const bool flag_join = !(getenv("CM_FLAG_JOIN") && atoi(getenv("CM_FLAG_JOIN")) == 0) && flag_sync_usable();
   if (flag_join && used) {
     const uint32_t epoch = ++ss.epoch;
     for (int i = 0; i < N; i++)
