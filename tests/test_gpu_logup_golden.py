@@ -1,4 +1,4 @@
-"""`write_interaction_trace` as the GPU runs it: for each of the 26 opcode components and for memory, merkle and clock_update the reference-derived TRACE cells
+"""`write_interaction_trace` as the GPU runs it: for each of the 34 components (the 26 opcode components, memory, merkle, clock_update, poseidon2, the four lookup tables) the reference-derived TRACE cells
 (tests/golden/air_witness_vectors.npz, from the reference's `write_trace` closures) go through the HIP k_logup / LogUp-tail kernels
 (cm_interaction_write) under fixed relation parameters, and the interaction columns must equal the reference-derived LogUp
 vectors (tests/golden/air_logup_vectors.npz: tools/rsref/rs_logup.py interprets the reference's `write_interaction_trace` text —
@@ -57,19 +57,26 @@ def test_same_run_as_the_witness_vectors():
 
 # component id -> name in the golden files: the 26 opcode components, then memory / merkle / clock_update (the builtins whose
 # write_trace closure has the regular shape; clock_update on the synthetic entries of tools/rsref/rs_witness.py)
-NAMES = list(OPCODE_FILES) + ["memory", "merkle", "clock_update"]
+NAMES = list(OPCODE_FILES) + ["memory", "merkle", "clock_update", "poseidon2", "range_check_8", "range_check_16", "range_check_20", "bitwise"]
+# the four lookup tables (ids 30..33): trace = the multiplicity column, the table entries come in through the preprocessed
+# columns (air::PreprocId: bitwise 0..3, range_check_8 / 16 / 20 = 4 / 5 / 6); 64 seeded rows stored with the vectors
+TABLE_PP = {"range_check_8": [4], "range_check_16": [5], "range_check_20": [6], "bitwise": [0, 1, 2, 3]}
 
 
-@pytest.mark.parametrize("cid", range(29), ids=NAMES)
+@pytest.mark.parametrize("cid", range(34), ids=NAMES)
 def test_hip_logup_columns_equal_reference_derived_fractions(backend, cid):
     name = NAMES[cid]
-    trace, want = WIT[name], LOG[name].astype(np.int64)            # (n_trace, n) / (n_cols, n, 4)
+    want = LOG[name].astype(np.int64)                               # (n_cols, n, 4)
+    trace = LOG[name + "_mults"][None, :] if name in TABLE_PP else WIT[name]     # (n_trace, n)
     n = trace.shape[1]
     log = n.bit_length() - 1
     n_trace, n_inter, _ = backend.component_info(cid)
     assert trace.shape[0] == n_trace and want.shape == (n_inter // 4, n, 4)
     h_tr = [backend.upload(np.ascontiguousarray(trace[c])) for c in range(n_trace)]
-    h_pp = [backend.upload(np.zeros(n, dtype=np.uint32)) for _ in range(N_PP)]     # opcode components read no preprocessed column
+    pp = np.zeros((N_PP, n), dtype=np.uint32)                       # only the lookup tables read preprocessed columns
+    for k, idx in enumerate(TABLE_PP.get(name, [])):
+        pp[idx] = LOG[name + "_values"][k]
+    h_pp = [backend.upload(np.ascontiguousarray(pp[i])) for i in range(N_PP)]
     h_out = [backend.col_alloc(n) for _ in range(n_inter)]
     try:
         cs = backend.interaction_write(cid, h_tr, h_pp, log, relation_words(), h_out)

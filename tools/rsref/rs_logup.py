@@ -200,6 +200,27 @@ def logup_columns(src, lookups, n_rows, n_live, consts, relations):
     return cum
 
 
+def logup_table(src, name, per_row, n_rows, relations):
+    """write_interaction_trace of a lookup-table component (range_check_macro.rs:125-146, bitwise.rs:170-192): the relation is the
+    function's first parameter, `interaction_claim_data.<name>` the packed [table values.., multiplicity] rows"""
+    from rs_interp import Struct, parse_block
+    g = standard_globals()
+    n_vec = n_rows // N_LANES
+    gen = LogupGen(n_vec)
+    g.update({"PackedQM31::from": PQ.of, "LogupTraceGenerator::new": lambda log_size: gen})
+    interp = LogupInterp(g)
+    outer = Env()
+    outer.vars.update({name: getattr(relations, name), "interaction_claim_data": Struct(**{name: per_row})})
+    interp.eval(parse_block("{" + interaction_body(src) + "}"), outer)
+    assert len(gen.cols) == 1 and gen.cols[0].done
+    cum = np.zeros((1, n_rows, 4), dtype=np.uint32)
+    for vec_row in range(n_vec):
+        num, den = gen.cols[0].fracs[vec_row][0]
+        for lane in range(N_LANES):
+            cum[0, vec_row * N_LANES + lane] = qmul(num.lanes[lane], qinv(den.lanes[lane]))
+    return cum
+
+
 def main():
     from cairo_m_amd.lib import prover_input_arrays, vm_run
     from cairo_m_amd.workloads import all_opcodes_program
@@ -232,6 +253,35 @@ def main():
         src = strip_comments(open(f"{REF}/prover/src/components/{name}.rs").read())
         out[name] = logup_columns(src, lookups, cols.shape[1], len(rows), consts2, relations)
         print(f"   {name:28s} {len(rows):4d} live rows, {out[name].shape[0]} LogUp columns x {cols.shape[1]} rows")
+    # poseidon2: the 200 hash inputs of the witness golden (rs_poseidon2.py), its closure through the full interpreter
+    import rs_poseidon2 as P2
+    p2src, p2interp, p2g = P2.make_interp()
+    nodes = np.concatenate([arrs["initial_tree"], arrs["final_tree"]])
+    p2in = np.zeros((nodes.shape[0], P2.T), dtype=np.int64)
+    p2in[:, 0], p2in[:, 1] = nodes[:, 2], nodes[:, 3]
+    p2in = p2in[:200]
+    lookups = []
+    cells = P2.witness_cells(p2src, p2interp, p2g, p2in, keep_lookup=lookups)
+    out["poseidon2"] = logup_columns(p2src, lookups, cells.shape[1], len(p2in), {k: v for k, v in p2g.items() if isinstance(v, int)}, relations)
+    print(f"   {'poseidon2':28s} {len(p2in):4d} live rows, {out['poseidon2'].shape[0]} LogUp columns x {cells.shape[1]} rows")
+    # the four lookup tables: one fraction per row, multiplicity / combine(table entry).  Inputs: seeded table values and
+    # multiplicities on 64 rows (the per-op entry point takes the log size and the preprocessed columns from the caller), stored
+    # with the vectors: `<name>_values` (n_preprocessed, 64), `<name>_mults` (64)
+    PRE = f"{REF}/prover/src/preprocessed"
+    macro = strip_comments(open(f"{PRE}/range_check/range_check_macro.rs").read())
+    rc_mod = open(f"{PRE}/range_check/mod.rs").read()
+    tables = [(f"range_check_{bits}", macro.replace("[<range_check_ $bit_size>]", f"range_check_{bits}"), 1)
+              for bits, _, _ in re.findall(r"define_range_check!\((\d+), (\w+), (\w+)\);", rc_mod)]
+    tables.append(("bitwise", strip_comments(open(f"{PRE}/bitwise.rs").read()), 4))
+    n_tab = 64
+    for name, tsrc, n_vals in tables:
+        vals = np.array([[rng.randrange(P) for _ in range(n_tab)] for _ in range(n_vals)], dtype=np.int64)
+        mults = np.array([rng.randrange(1 << 20) for _ in range(n_tab)], dtype=np.int64)
+        per_row = [[Packed([Felt(int(vals[k][v * N_LANES + i])) for i in range(N_LANES)]) for k in range(n_vals)] +
+                   [Packed([Felt(int(mults[v * N_LANES + i])) for i in range(N_LANES)])] for v in range(n_tab // N_LANES)]
+        out[name] = logup_table(tsrc, name, per_row, n_tab, relations)
+        out[name + "_values"], out[name + "_mults"] = vals.astype(np.uint32), mults.astype(np.uint32)
+        print(f"   {name:28s} {n_tab:4d} rows, {out[name].shape[0]} LogUp column")
     inp.free()
     path = os.path.join(ROOT, "tests", "golden", "air_logup_vectors.npz")
     np.savez_compressed(path, **out)

@@ -118,7 +118,7 @@ def eval_vectors(src, interp, g):
     return n, rows
 
 
-def witness_cells(src, interp, g, inputs):
+def witness_cells(src, interp, g, inputs, keep_lookup=None):
     """inputs: (n, 16) hash inputs = NodeData::to_hash_input of initial_tree ++ final_tree (adapter/mod.rs:165-176)."""
     rx = r"\.for_each\(\|\(row_index, \(mut row, mut state, lookup_data\)\)\| \{"
     body = extract_fn_body(src, rx)
@@ -137,6 +137,8 @@ def witness_cells(src, interp, g, inputs):
         env.vars.update({"row_index": vec_row, "row": row, "state": state, "lookup_data": ld})
         interp.eval(block, env)
         assert sorted(row.d) == list(range(out.shape[0]))
+        if keep_lookup is not None:
+            keep_lookup.append(ld)      # tools/rsref/rs_logup.py
         for c in range(out.shape[0]):
             out[c, vec_row * N_LANES:(vec_row + 1) * N_LANES] = [x.v for x in row.d[c].lanes]
     return out
