@@ -1319,19 +1319,23 @@ struct SegmentProver {
     check_composition_at_oods(pf, tr0, it0, clog, hrel, powers, coff, oods);   // host-only, overlapped with the kernels enqueued above
     ht.mark("fri: enqueued, oods check done");
     if (dev_tail) {
-      CM_HIP(hipStreamSynchronize(st));
-      ht.mark("tail: gpu done");
-      fri.commit_finish(P, cfg, pf, true);
+      CM_HIP(hipEventSynchronize(tail.ev_last));        // challenges, roots and the last layer are in pinned memory ...
+      ht.mark("tail: last layer landed");
+      fri.commit_finish(P, cfg, pf, true);               // ... replayed while the proof of work and the tables run
+      ht.mark("tail: commit phase replayed");
+      CM_HIP(hipEventSynchronize(tail.ev_tables));
       if (tail.nonce_found()) {
         pf.proof_of_work = tail.nonce();
         ch.mix_u64(pf.proof_of_work);
         CM_CHECK(ch.trailing_zeros() >= cfg.pow_bits, "pow: the device's nonce fails the host's check");
+        tail.plan(Queries::draw(ch, cfg.n_queries, q_logs[0]));   // host tables while the gathers write the witnesses
         tail_done = true;
-        ht.mark("tail: host replay");
+        ht.mark("tail: nonce, queries, host tables");
         return;
       }
       // (no nonce within 16x the expected range, probability e^-16: search on with the host-driven form; the decommitment
       // the device made from nothing is discarded)
+      CM_HIP(hipStreamSynchronize(st));
     } else {
       fri.commit_finish(P, cfg, pf, false);
       P.tick("fri_commit");
@@ -1345,14 +1349,16 @@ struct SegmentProver {
 
   // queries, one batched gather for every tree, proof assembly
   void decommit() {
+    if (tail_done) {   // the witnesses land in pinned memory in proof order: wait for the last gather, copy them
+      CM_HIP(hipStreamSynchronize(st));
+      ht.mark("tail: gpu done");
+      tail.copy(P, fri, pf);
+      ht.mark("decommit: copied the device tail's witnesses");
+      return;
+    }
     // ---- queries + decommitment ----
     Queries queries = Queries::draw(ch, cfg.n_queries, q_logs[0]);
     ht.mark("decommit: queries drawn");
-    if (tail_done) {   // the witnesses are already in pinned memory, in proof order
-      tail.finish(P, fri, queries, pf, [&](const char* w) { ht.mark(w); });
-      ht.mark("decommit: distributed the device tail's witnesses");
-      return;
-    }
     const bool ticked = tail.enqueued;   // (device tail without a nonce: its phase events are already in the stream)
     std::map<uint32_t, std::vector<uint32_t>> qpos;
     for (auto l : q_logs) qpos[l] = queries.fold(queries.log_domain_size - l).positions;

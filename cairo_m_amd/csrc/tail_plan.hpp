@@ -25,6 +25,11 @@ struct DeviceTail {
   uint32_t *hdr = nullptr, *h_pos = nullptr, *h_out = nullptr;
   size_t out_bound = 0;
   bool enqueued = false;
+  // the host follows the tail in three steps instead of one wait at its end: behind k_tail_last it replays the commit phase
+  // (FriPhase::commit_finish) while the proof of work runs, behind k_tail_tables it checks the nonce, draws the queries and builds
+  // its tables while the gathers run, and only the witness copy waits for the last kernel
+  hipEvent_t ev_last = nullptr, ev_tables = nullptr;
+  std::vector<size_t> off;   // first output word of every piece, from the host's tables (plan())
 
   static bool supported(const cm_pcs_config& cfg, const std::vector<uint32_t>& q_logs, const FriPhase& fri) {
     if (!device_tail_enabled() || q_logs.empty() || !fri.have_first) return false;
@@ -126,6 +131,13 @@ struct DeviceTail {
       a.nonce = (unsigned long long*)d_nonce.p;
       tail_last_layer(a, st);
     }
+    {
+      static thread_local hipEvent_t evs[2] = {nullptr, nullptr};
+      for (auto& e : evs)
+        if (!e) { CM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); thread_event_owned(e); }
+      ev_last = evs[0]; ev_tables = evs[1];
+    }
+    CM_HIP(hipEventRecord(ev_last, st));
     P.tick("fri_commit");
     tail_grind(fri.d_chan_, cfg.pow_bits, (unsigned long long*)d_nonce.p, st);
     P.tick("pow");
@@ -139,25 +151,29 @@ struct DeviceTail {
       a.tab = d_tab.u32(); a.nq_pad = nq_pad; a.hdr = hdr; a.h_positions = h_pos;
       tail_tables(a, st);
     }
+    CM_HIP(hipEventRecord(ev_tables, st));
     tail_gather(d_desc.as<TailDesc>(), d_off.u32(), d_tab.u32(), nq_pad, n_small, (uint32_t)desc.size(), nq, h_out, st);
     P.tick("decommit");
     enqueued = true;
   }
 
-  // after the stream is synchronised and FriPhase::commit_finish has replayed the commit phase
+  // behind ev_tables: the header and the positions are in pinned memory
   bool nonce_found() const { return hdr[0] == TAIL_OK; }
   uint64_t nonce() const { return (uint64_t)hdr[1] | ((uint64_t)hdr[2] << 32); }
 
-  // `queries`: drawn by the HOST channel after mix_u64(nonce) — must equal what the device drew
-  void finish(Prover& P, FriPhase& fri, const Queries& queries, ProofData& pf, const std::function<void(const char*)>& mark = nullptr) {
+  // `queries`: drawn by the HOST channel after mix_u64(nonce) — must equal what the device drew.  Host tables -> where every piece
+  // of the witness stream starts (while k_tail_gather is still writing it).
+  void plan(const Queries& queries) {
     CM_CHECK(hdr[3] == queries.positions.size() && memcmp(h_pos, queries.positions.data(), 4 * queries.positions.size()) == 0,
              "decommit: device query positions diverged from the host channel");
     TailTables tt;
     tt.build(queries.positions, L0, qmask);
-    if (mark) mark("tail finish: host tables");
-    std::vector<size_t> off(desc.size() + 1, 0);
+    off.assign(desc.size() + 1, 0);
     for (size_t d = 0; d < desc.size(); d++) off[d + 1] = off[d] + tt.count(desc[d].kind, desc[d].k) * TailTables::words_per_item(desc[d]);
     CM_CHECK(off.back() == hdr[4] && off.back() <= out_bound, "decommit: device witness size differs from the host's table walk");
+  }
+  // after the stream is synchronised: the witnesses into the proof object
+  void copy(Prover& P, FriPhase& fri, ProofData& pf) {
     pf.decommitments.resize(4);
     pf.queried_values.resize(4);
     pf.fri_inner.resize(fri.inner.size());
@@ -183,7 +199,6 @@ struct DeviceTail {
         case T_INNER_HASH: hashes(pf.fri_inner[sp.index].decommitment.hash_witness, w, words); break;
       }
     }
-    if (mark) mark("tail finish: witnesses copied");
     for (size_t i = 0; i < fri.inner.size(); i++) pf.fri_inner[i].commitment = fri.inner[i]->root;
     for (int t = 0; t < 4; t++) pf.commitments.push_back(P.trees[t].root);
   }
