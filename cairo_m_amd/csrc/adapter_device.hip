@@ -38,6 +38,17 @@ constexpr uint32_t INFO_KEY_LO = 8, INFO_KEY_HI = 19;
 __device__ __forceinline__ uint32_t info_comp(uint32_t info) { return info >> 14; }
 __device__ __forceinline__ uint32_t info_ne(uint32_t info) { return (info >> 4) & 15u; }
 __device__ __forceinline__ uint32_t info_na(uint32_t info) { return info & 15u; }
+// the memory at segment start: the locals (address i) and the heap (index i = address MAX_ADDRESS - i), runner/src/vm/mod.rs:205-221
+struct InitMem {
+  const uint32_t* lo; uint32_t n_lo;
+  const uint32_t* hi; uint32_t n_hi;
+  __device__ __forceinline__ const uint32_t* cell(uint32_t addr) const {
+    if (addr < n_lo) return lo + 4 * (size_t)addr;
+    const uint32_t h = host::MAX_ADDRESS - addr;   // (addr > MAX_ADDRESS wraps to a huge index: no cell)
+    if (h < n_hi) return hi + 4 * (size_t)h;
+    return nullptr;
+  }
+};
 __global__ void k_step_counts(const uint32_t* __restrict__ trace, uint32_t n_steps, const uint32_t* __restrict__ init_mem,
                               uint32_t n_init, OpTable tab, uint32_t* __restrict__ info, unsigned long long* __restrict__ cnt,
                               uint32_t* __restrict__ err) {
@@ -79,7 +90,7 @@ __global__ void k_entry_keys(const uint32_t* __restrict__ trace, uint32_t n_step
 // RC20_LIMIT clocks from their predecessor are rare: only they write cu_count[e] (zeroed by the caller) and their position.
 __global__ void k_prev_links(const uint32_t* __restrict__ sorted_addr, const uint32_t* __restrict__ sorted_e, uint32_t n_mem,
                              const uint32_t* __restrict__ mem, const uint32_t* __restrict__ entry_clock,
-                             const uint32_t* __restrict__ init_mem, uint32_t n_init, uint2* __restrict__ link,
+                             InitMem init, uint2* __restrict__ link,
                              uint32_t* __restrict__ cu_count, uint32_t* __restrict__ cu_pos, uint32_t* __restrict__ head_flag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
   const bool live = i < n_mem;
@@ -96,7 +107,8 @@ __global__ void k_prev_links(const uint32_t* __restrict__ sorted_addr, const uin
   head_flag[i] = head ? 1u : 0u;
   if (head) {
     pclk = 0;
-    pv0 = addr < n_init ? init_mem[4 * (size_t)addr] : v0;
+    const uint32_t* ic = init.cell(addr);
+    pv0 = ic ? ic[0] : v0;
   }
   const uint32_t delta = clk - pclk;
   const uint32_t steps = delta > air::RC20_LIMIT ? delta / air::RC20_LIMIT : 0u;
@@ -108,15 +120,14 @@ __global__ void k_prev_links(const uint32_t* __restrict__ sorted_addr, const uin
 __global__ void k_clock_updates(const uint32_t* __restrict__ mem, uint32_t n_mem, const uint32_t* __restrict__ cu_count,
                                 const uint32_t* __restrict__ cu_off, const uint32_t* __restrict__ cu_pos, const uint2* __restrict__ link,
                                 const uint32_t* __restrict__ sorted_addr, const uint32_t* __restrict__ sorted_e,
-                                const uint32_t* __restrict__ init_mem, uint32_t n_init, cm_clock_update* __restrict__ out) {
+                                InitMem init, cm_clock_update* __restrict__ out) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_mem) return;
   uint32_t n = cu_count[e];
   if (!n) return;
   uint32_t addr = mem[5 * (size_t)e];
-  const uint32_t* iv;
-  if (addr < n_init) iv = init_mem + 4 * (size_t)addr;
-  else {
+  const uint32_t* iv = init.cell(addr);
+  if (!iv) {
     uint32_t lo = 0, hi = cu_pos[e];          // first position whose address is `addr`
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (sorted_addr[mid] < addr) lo = mid + 1; else hi = mid; }
     iv = mem + 5 * (size_t)sorted_e[lo] + 1;
@@ -292,10 +303,14 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
   CM_CHECK(seg.n_memory_trace < (1ull << 32) && seg.n_trace < (1ull << 32), "adapter: segment too large");
   CM_CHECK(seg.n_memory_trace >= 1, "adapter: empty memory trace");
   // ---- upload the runner output ----
-  DevBuf d_trace(seg.n_trace * 8), d_mem((size_t)n_mem * 20 + 4), d_init((size_t)n_init * 16 + 4), d_err(8);
+  const uint32_t n_heap = (uint32_t)seg.n_initial_heap;
+  CM_CHECK(seg.n_initial_memory + seg.n_initial_heap <= (uint64_t)host::MAX_ADDRESS + 1, "adapter: locals and heap overlap");
+  DevBuf d_trace(seg.n_trace * 8), d_mem((size_t)n_mem * 20 + 4), d_init((size_t)n_init * 16 + 4), d_heap((size_t)n_heap * 16 + 4), d_err(8);
   CM_HIP(hipMemcpyAsync(d_trace.p, seg.trace, seg.n_trace * 8, hipMemcpyHostToDevice, st));
   if (n_mem) CM_HIP(hipMemcpyAsync(d_mem.p, seg.memory_trace, (size_t)n_mem * 20, hipMemcpyHostToDevice, st));
   if (n_init) CM_HIP(hipMemcpyAsync(d_init.p, seg.initial_memory, (size_t)n_init * 16, hipMemcpyHostToDevice, st));
+  if (n_heap) CM_HIP(hipMemcpyAsync(d_heap.p, seg.initial_heap, (size_t)n_heap * 16, hipMemcpyHostToDevice, st));
+  const InitMem init{d_init.u32(), n_init, d_heap.u32(), n_heap};
   OpTable tab;
   memset(&tab, 0, sizeof(tab));
   for (uint32_t op = 0; op < 64; op++) {
@@ -341,8 +356,8 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
   DevBuf d_link((size_t)n_mem * 8 + 8), d_cuc((size_t)n_mem * 4 + 4), d_cupos((size_t)n_mem * 4 + 4), d_head((size_t)n_mem * 4 + 4),
       d_cuoff((size_t)n_mem * 4 + 4), d_hrank((size_t)n_mem * 4 + 4);
   CM_HIP(hipMemsetAsync(d_cuc.p, 0, (size_t)n_mem * 4, st));
-  hipLaunchKernelGGL(k_prev_links, grid1(n_mem), dim3(256), 0, st, d_saddr.u32(), d_se.u32(), n_mem, d_mem.u32(), d_eclk.u32(), d_init.u32(),
-                     n_init, d_link.as<uint2>(), d_cuc.u32(), d_cupos.u32(), d_head.u32());
+  hipLaunchKernelGGL(k_prev_links, grid1(n_mem), dim3(256), 0, st, d_saddr.u32(), d_se.u32(), n_mem, d_mem.u32(), d_eclk.u32(), init,
+                     d_link.as<uint2>(), d_cuc.u32(), d_cupos.u32(), d_head.u32());
   with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_cuc.u32(), d_cuoff.u32(), (int)n_mem, st)); });
   with_temp([&](void* t, size_t& b) { CM_HIP(hipcub::DeviceScan::ExclusiveSum(t, b, d_head.u32(), d_hrank.u32(), (int)n_mem, st)); });
   // ---- 4. steps bucketed per opcode component, opcode variants grouped inside (stable 11-bit sort) ----
@@ -373,7 +388,7 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
   DevBuf d_cu((size_t)n_cu * sizeof(cm_clock_update) + 4);
   if (n_cu)
     hipLaunchKernelGGL(k_clock_updates, grid1(n_mem), dim3(256), 0, st, d_mem.u32(), n_mem, d_cuc.u32(), d_cuoff.u32(), d_cupos.u32(),
-                       d_link.as<uint2>(), d_saddr.u32(), d_se.u32(), d_init.u32(), n_init, d_cu.as<cm_clock_update>());
+                       d_link.as<uint2>(), d_saddr.u32(), d_se.u32(), init, d_cu.as<cm_clock_update>());
   uint64_t counts[CM_N_OPCODE_COMPONENTS] = {0};
   {
     uint32_t prev_end = 0;  // ends[c] = one past the last step of component c in sorted order (0 if absent)
@@ -408,6 +423,12 @@ DeviceInput* adapt_segment_device(const cm_runner_segment& seg) {
                       seg.initial_memory[4 * (size_t)a + 3]}, 0u, 0u};
     initial_memory[a] = s;
     final_memory[a] = s;
+  }
+  for (uint32_t i = 0; i < n_heap; i++) {
+    const uint32_t* w = seg.initial_heap + 4 * (size_t)i;
+    host::MemState s{{w[0], w[1], w[2], w[3]}, 0u, 0u};
+    initial_memory[host::MAX_ADDRESS - i] = s;
+    final_memory[host::MAX_ADDRESS - i] = s;
   }
   auto val = [&](uint32_t e) { const uint32_t* w = seg.memory_trace + 5 * (size_t)e + 1; return host::Cell{w[0], w[1], w[2], w[3]}; };
   for (const CellRec& c : cells) {

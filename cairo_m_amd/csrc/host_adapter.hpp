@@ -101,23 +101,51 @@ struct MemEntry { uint32_t addr; Cell value; };
 struct Segment {
   std::vector<std::array<uint32_t, 2>> trace;  // (pc, fp) per step + the final state
   std::vector<MemEntry> memory_trace;
-  std::vector<Cell> initial_memory;            // dense: address i -> cell (locals; heap unused)
+  std::vector<Cell> initial_memory;            // dense: address i -> cell (the locals: program, frames)
+  std::vector<Cell> initial_heap;              // dense from the top: index i -> cell at MAX_ADDRESS - i (runner/src/vm/mod.rs:205-221)
 };
+constexpr uint32_t MAX_ADDRESS = (1u << 28) - 1;   // crates/common/src/lib.rs MAX_ADDRESS: the heap grows downwards from here
 
 // ---- minimal VM (semantics: crates/runner/src/vm/instructions/{store,jnz,jump,call}.rs; access-log
 // order: instruction word(s) first, then operands src0, src1, dst; ret reads fp-1 then fp-2) ----------
 struct VM {
-  std::vector<Cell> mem;
+  // Memory of crates/runner/src/memory/mod.rs:48-62: `mem` = the locals (address i), `heap` = cells from the top (index i =
+  // address MAX_ADDRESS - i).  A read never grows either vector (an untouched cell reads as zero, :186-200); a write beyond both
+  // grows the NEARER one (:262-283) — which cells exist matters for the initial memory of a continuation segment.
+  std::vector<Cell> mem, heap;
   std::vector<MemEntry> log;
   uint32_t pc = 0, fp = 0, final_pc = 0;
-  void ensure(uint32_t a) { if (a >= mem.size()) mem.resize((size_t)a + 1, Cell{0, 0, 0, 0}); }
-  uint32_t rd(uint32_t a) { ensure(a); log.push_back({a, mem[a]}); return mem[a][0]; }
-  void wr(uint32_t a, uint32_t v) { ensure(a); mem[a] = Cell{v, 0, 0, 0}; log.push_back({a, mem[a]}); }
+  void ensure(uint32_t a) { if (a >= mem.size()) mem.resize((size_t)a + 1, Cell{0, 0, 0, 0}); }   // (frame set-up only)
+  static void check_address(uint32_t a) {
+    if (a > MAX_ADDRESS) throw std::runtime_error("vm: address " + std::to_string(a) + " is beyond MAX_ADDRESS");
+  }
+  Cell get(uint32_t a) const {
+    check_address(a);
+    if (a < mem.size()) return mem[a];
+    const size_t h = (size_t)MAX_ADDRESS - a;
+    if (h < heap.size()) return heap[h];
+    return Cell{0, 0, 0, 0};
+  }
+  void put(uint32_t a, const Cell& c) {
+    check_address(a);
+    const size_t h = (size_t)MAX_ADDRESS - a;
+    if (a < mem.size()) { mem[a] = c; return; }
+    if (h < heap.size()) { heap[h] = c; return; }
+    if ((size_t)a - mem.size() < h - heap.size()) { mem.resize((size_t)a + 1, Cell{0, 0, 0, 0}); mem[a] = c; }
+    else { heap.resize(h + 1, Cell{0, 0, 0, 0}); heap[h] = c; }
+  }
+  uint32_t rd(uint32_t a) {
+    const Cell c = get(a);
+    if (c[1] | c[2] | c[3]) throw std::runtime_error("vm: the cell at " + std::to_string(a) + " is not a base-field value");
+    log.push_back({a, c});
+    return c[0];
+  }
+  void wr(uint32_t a, uint32_t v) { const Cell c{v, 0, 0, 0}; put(a, c); log.push_back({a, c}); }
   static uint32_t add(uint32_t a, uint32_t b) { return (cm::M31(a) + cm::M31(b)).v; }
   static uint32_t sub(uint32_t a, uint32_t b) { return (cm::M31(a) - cm::M31(b)).v; }
   static uint32_t mul(uint32_t a, uint32_t b) { return (cm::M31(a) * cm::M31(b)).v; }
   void step() {
-    ensure(pc);
+    if (pc >= mem.size()) throw std::runtime_error("vm: instruction fetch from an uninitialised cell at " + std::to_string(pc));
     Cell w0 = mem[pc];
     log.push_back({pc, w0});
     uint32_t op = w0[0];
@@ -126,7 +154,7 @@ struct VM {
     uint32_t in[6] = {w0[0], w0[1], w0[2], w0[3], 0, 0};
     uint32_t npc_inc = 1;
     if (oi.size_m31 > 4) {
-      ensure(pc + 1);
+      if ((size_t)pc + 1 >= mem.size()) throw std::runtime_error("vm: instruction fetch from an uninitialised cell at " + std::to_string(pc + 1));
       Cell w1 = mem[pc + 1];
       log.push_back({pc + 1, w1});
       in[4] = w1[0]; in[5] = w1[1];
@@ -226,7 +254,7 @@ inline std::vector<Segment> run_program(const std::vector<std::vector<uint32_t>>
   vm.mem[new_fp - 2] = Cell{new_fp, 0, 0, 0};
   vm.mem[new_fp - 1] = Cell{vm.final_pc, 0, 0, 0};
   std::vector<Segment> segs;
-  std::vector<Cell> initial = vm.mem;
+  std::vector<Cell> initial = vm.mem, initial_heap = vm.heap;
   for (;;) {
     Segment s;
     while (vm.pc != vm.final_pc && s.trace.size() < max_steps) {
@@ -236,10 +264,12 @@ inline std::vector<Segment> run_program(const std::vector<std::vector<uint32_t>>
     s.trace.push_back({vm.pc, vm.fp});
     s.memory_trace.swap(vm.log);
     s.initial_memory = initial;
+    s.initial_heap = initial_heap;
     bool done = vm.pc == vm.final_pc;
     segs.push_back(std::move(s));
     if (done) break;
     initial = vm.mem;
+    initial_heap = vm.heap;
   }
   return segs;
 }
@@ -400,6 +430,12 @@ inline ProverInputOwned import_segment(const Segment& seg, const uint32_t prog[2
     MemState s{seg.initial_memory[a], 0u, 0u};
     initial_memory[(uint32_t)a] = s;
     final_memory[(uint32_t)a] = s;
+  }
+  if (seg.initial_heap.size() > (size_t)MAX_ADDRESS + 1 - seg.initial_memory.size()) throw std::runtime_error("adapter: locals and heap overlap");
+  for (size_t i = 0; i < seg.initial_heap.size(); i++) {
+    MemState s{seg.initial_heap[i], 0u, 0u};
+    initial_memory[MAX_ADDRESS - (uint32_t)i] = s;
+    final_memory[MAX_ADDRESS - (uint32_t)i] = s;
   }
   using Arg = MemArg;
   auto push = [&](uint32_t address, const Cell& value, uint32_t clock) -> Arg { return mt.push(address, value, clock); };

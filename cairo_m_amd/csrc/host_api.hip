@@ -47,7 +47,7 @@ int32_t cm_synth_fibonacci(uint32_t n, uint64_t max_steps, uint32_t segment_inde
 }
 struct cm_host_segment {
   cm::host::Segment seg;
-  std::vector<uint32_t> trace, mem, init;
+  std::vector<uint32_t> trace, mem, init, heap;
   cm_runner_segment view;
 };
 static int32_t build_segment(const std::vector<std::vector<uint32_t>>& program, uint32_t entry_pc, const std::vector<uint32_t>& args,
@@ -63,7 +63,9 @@ static int32_t build_segment(const std::vector<std::vector<uint32_t>>& program, 
     for (auto& t : h->seg.trace) { h->trace.push_back(t[0]); h->trace.push_back(t[1]); }
     for (auto& e : h->seg.memory_trace) { h->mem.push_back(e.addr); for (int k = 0; k < 4; k++) h->mem.push_back(e.value[k]); }
     for (auto& c : h->seg.initial_memory) for (int k = 0; k < 4; k++) h->init.push_back(c[k]);
+    for (auto& c : h->seg.initial_heap) for (int k = 0; k < 4; k++) h->heap.push_back(c[k]);
     cm_runner_segment& v = h->view;
+    v.initial_heap = h->heap.data(); v.n_initial_heap = h->seg.initial_heap.size();
     v.trace = h->trace.data(); v.n_trace = h->seg.trace.size();
     v.memory_trace = h->mem.data(); v.n_memory_trace = h->seg.memory_trace.size();
     v.initial_memory = h->init.data(); v.n_initial_memory = h->seg.initial_memory.size();
@@ -135,8 +137,16 @@ int32_t cm_segment_from_artifacts(const uint8_t* trace, uint64_t trace_len, cons
   v.trace = h->trace.data(); v.n_trace = trace_len / 8;
   v.memory_trace = h->mem.data(); v.n_memory_trace = (mem_len - hdr) / 20;
   v.initial_memory = h->init.data(); v.n_initial_memory = n_initial_memory;
+  v.initial_heap = nullptr; v.n_initial_heap = 0;   // (cm_host_segment_set_initial_heap)
   for (int i = 0; i < 2; i++) { v.program_range[i] = ranges[i]; v.input_range[i] = ranges[2 + i]; v.output_range[i] = ranges[4 + i]; }
   *out = h;
+  return 0;
+}
+int32_t cm_host_segment_set_initial_heap(cm_host_segment* h, const uint32_t* initial_heap, uint64_t n_initial_heap) {
+  if (n_initial_heap && !initial_heap) return cm_set_last_error("cm_host_segment_set_initial_heap: null heap");
+  if (n_initial_heap + h->view.n_initial_memory > (uint64_t)cm::host::MAX_ADDRESS + 1) return cm_set_last_error("cm_host_segment_set_initial_heap: locals and heap overlap");
+  h->heap.assign(initial_heap, initial_heap + 4 * n_initial_heap);
+  h->view.initial_heap = h->heap.data(); h->view.n_initial_heap = n_initial_heap;
   return 0;
 }
 const cm_prover_input* cm_host_input_view(const cm_host_input* h) { return &h->view; }

@@ -438,7 +438,8 @@ def prover_input_arrays(view_ptr):
 class RunnerSegmentView(C.Structure):
     """cm_runner_segment (read-only mirror)."""
     _fields_ = [("trace", C.c_void_p), ("n_trace", C.c_uint64), ("memory_trace", C.c_void_p), ("n_memory_trace", C.c_uint64),
-                ("initial_memory", C.c_void_p), ("n_initial_memory", C.c_uint64), ("ranges", C.c_uint32 * 6)]
+                ("initial_memory", C.c_void_p), ("n_initial_memory", C.c_uint64), ("ranges", C.c_uint32 * 6),
+                ("initial_heap", C.c_void_p), ("n_initial_heap", C.c_uint64)]
 
 
 def runner_segment_arrays(view_ptr):
@@ -450,7 +451,8 @@ def runner_segment_arrays(view_ptr):
             return np.zeros((0, words), dtype=np.uint32)
         return np.ctypeslib.as_array(C.cast(ptr, _u32p), shape=(int(n), words)).copy()
     return {"trace": arr(v.trace, v.n_trace, 2), "memory_trace": arr(v.memory_trace, v.n_memory_trace, 5),
-            "initial_memory": arr(v.initial_memory, v.n_initial_memory, 4), "ranges": list(v.ranges)}
+            "initial_memory": arr(v.initial_memory, v.n_initial_memory, 4), "ranges": list(v.ranges),
+            "initial_heap": arr(v.initial_heap, v.n_initial_heap, 4)}   # index i = the cell at 2^28 - 1 - i
 
 
 class HostSegment:

@@ -25,8 +25,10 @@
 #include <stddef.h>
 #include <stdint.h>
 /* Revision of this header.  4: cm_comm.struct_size at offset 0 (breaking for cm_comm users).  5: cm_shard_plan* take the PCS
- * config and column-array capacities; cm_set_device_tail, cm_tail_list. */
-#define CM_ABI_REVISION 5
+ * config and column-array capacities; cm_set_device_tail, cm_tail_list.  6: cm_runner_segment grows by initial_heap /
+ * n_initial_heap at its END (a revision-5 caller must be recompiled: the library reads the two fields);
+ * cm_host_segment_set_initial_heap. */
+#define CM_ABI_REVISION 6
 
 #ifdef __cplusplus
 extern "C" {
@@ -397,6 +399,11 @@ typedef struct {
   const uint32_t* initial_memory;  /* 4 words per cell: addresses 0 .. n_initial_memory-1 at segment start */
   uint64_t n_initial_memory;
   uint32_t program_range[2], input_range[2], output_range[2];
+  /* (revision 6) the HEAP at segment start, 4 words per cell: index i = the cell at MAX_ADDRESS - i = 2^28 - 1 - i — the second
+   * half of the reference's Segment::initial_memory (crates/runner/src/vm/mod.rs:205-221: `heap[i]` maps to MAX_ADDRESS - i;
+   * the allocator of `new T[n]` grows it downwards).  Empty for a program's first segment; NULL / 0 when there is none. */
+  const uint32_t* initial_heap;
+  uint64_t n_initial_heap;
 } cm_runner_segment;
 int32_t cm_adapt_segment_device(const cm_runner_segment* seg, cm_device_input** out);
 /* streaming ingest from runner segments: see cm_prove_many_host */
@@ -421,6 +428,8 @@ int32_t cm_segment_serialize_memory_trace(const cm_runner_segment* s, int32_t wi
 int32_t cm_segment_from_artifacts(const uint8_t* trace, uint64_t trace_len, const uint8_t* mem, uint64_t mem_len,
                                   int32_t mem_has_header, const uint32_t* initial_memory, uint64_t n_initial_memory,
                                   const uint32_t ranges[6], cm_host_segment** out);
+/* (revision 6) the heap cells of a segment built from artifacts (copied; see cm_runner_segment.initial_heap) */
+int32_t cm_host_segment_set_initial_heap(cm_host_segment* h, const uint32_t* initial_heap, uint64_t n_initial_heap);
 int32_t cm_host_segment_free(cm_host_segment* h);
 /* ---- per-component AIR ops --------------------------------------------------------------------
  * What the reference does per component through Rust generics that name SimdBackend — and therefore cannot be

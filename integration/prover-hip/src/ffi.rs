@@ -137,6 +137,9 @@ pub struct cm_runner_segment {
     pub program_range: [u32; 2],
     pub input_range: [u32; 2],
     pub output_range: [u32; 2],
+    /// (revision 6) heap cells at segment start: index i = the cell at MAX_ADDRESS - i (runner/src/vm/mod.rs:205-221)
+    pub initial_heap: *const u32,
+    pub n_initial_heap: u64,
 }
 /// Collectives of the sharded prover (cm_prove_sharded): two blocking calls over two device staging buffers
 #[repr(C)]
@@ -241,6 +244,7 @@ unsafe extern "C" {
     pub fn cm_host_segment_view(h: *const cm_host_segment) -> *const cm_runner_segment;
     pub fn cm_segment_serialize_trace(s: *const cm_runner_segment, out: *mut u8, cap: u64, len: *mut u64) -> i32;
     pub fn cm_segment_serialize_memory_trace(s: *const cm_runner_segment, with_header: i32, out: *mut u8, cap: u64, len: *mut u64) -> i32;
+    pub fn cm_host_segment_set_initial_heap(h: *mut cm_host_segment, initial_heap: *const u32, n_initial_heap: u64) -> i32;
     pub fn cm_segment_from_artifacts(trace: *const u8, trace_len: u64, mem: *const u8, mem_len: u64, mem_has_header: i32, initial_memory: *const u32, n_initial_memory: u64, ranges: *const u32, out: *mut *mut cm_host_segment) -> i32;
     pub fn cm_host_segment_free(h: *mut cm_host_segment) -> i32;
     pub fn cm_component_info(component: i32, n_trace_cols: *mut u32, n_interaction_cols: *mut u32, n_constraints: *mut u32) -> i32;

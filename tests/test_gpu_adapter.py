@@ -125,6 +125,31 @@ def test_wide_addresses(backend):
     hi.free(); hs.free()
 
 
+def test_heap_segments(backend, oracle):
+    """The compiler's `new felt[3]` program (tests/casm_fixtures.py heap_program): cells at the top of the 2^28-cell address space.
+    Whole: device adapter == host adapter, proof == the oracle's.  Cut every 8 steps: segments 2 and 3 start with a heap
+    (cm_runner_segment.initial_heap, ABI revision 6) whose cells the device kernels must find for previous values and which belong
+    to the boundary memory whether the segment touches them or not."""
+    from tests.casm_fixtures import heap_program
+    prog, entry, nret, _ = heap_program()
+    hi = vm_run(prog, entry_pc=entry, n_returns=nret)
+    hs = vm_segment(prog, entry_pc=entry, n_returns=nret)
+    _check(backend, hi, hs)
+    p = backend.prove(hi)
+    want, _ = oracle.prove(hi.view)
+    assert np.array_equal(p.words(), want)
+    p.free(); hi.free(); hs.free()
+    from cairo_m_amd.lib import runner_segment_arrays
+    n_heap = []
+    for s in range(4):
+        hi = vm_run(prog, entry_pc=entry, n_returns=nret, max_steps=8, segment=s)
+        hs = vm_segment(prog, entry_pc=entry, n_returns=nret, max_steps=8, segment=s)
+        n_heap.append(runner_segment_arrays(hs.view)["initial_heap"].shape[0])
+        _check(backend, hi, hs)
+        hi.free(); hs.free()
+    assert n_heap[0] == 0 and n_heap[3] == 3, n_heap
+
+
 def test_runner_artifact_files_to_proof(backend, oracle, tmp_path):
     """SURVEY 8 f-3 end to end: the runner's on-disk artifacts — binary trace ((fp, pc) LE u32 pairs, execution.rs:28-66),
     binary memory trace (u32 program_length header + (address, 4 value words) records, io.rs:38-80) and the compiled
