@@ -3,6 +3,7 @@
 // DEVICE arrays of device pointers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <sched.h>
 #include <vector>
@@ -55,7 +56,8 @@ void eval_at_point_batch(const uint32_t* const* d_coeffs, uint32_t ncols, uint32
 
 // every (log size, point) sampling group of a proof in three launches; d_out receives 4 * ncols words per job
 struct EapJob { uint32_t log_n, ncols; const uint32_t* const* d_coeffs; QM31 px, py; uint32_t* d_out;
-                bool has_shift = false; uint32_t shift_x = 0, shift_y = 0; };
+                bool has_shift = false; uint32_t shift_x = 0, shift_y = 0;
+                uint32_t* h_out = nullptr; };   // optional mirror of d_out in PINNED HOST memory, written by the same kernel (no copy command)
 // d_oods_t != null: every job samples at the OODS point derived ON THE DEVICE from the felt at d_oods_t (4 words; the draw of
 // CirclePoint::get_random_point), plus the job's M31 shift (has_shift: the previous-row mask point) — px / py are ignored
 void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st, const uint32_t* d_oods_t = nullptr);
@@ -174,6 +176,9 @@ void stage_forget_stream(hipStream_t st);
 // The prover's main stream of the calling host thread (created on first use, non-blocking): concurrent proofs
 // from different host threads run on different streams and overlap on the GPU.
 hipStream_t thread_main_stream();
+// measurement switches (cm_set_tuning): initial values from the environment
+struct Tuning { std::atomic<int> oods_poll, oods_host_write, stage_copy_kernel, stage_lazy_events; };
+Tuning& tuning();
 // side stream i of the calling host thread (the streams Fork hands out), with NO ordering against anything: the caller orders it
 // with events (Prover::commit_enqueue runs the transforms of a commitment there, next to the Merkle launches on the main stream)
 hipStream_t thread_side_stream(int i);

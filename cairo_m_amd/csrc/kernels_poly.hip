@@ -289,6 +289,7 @@ struct EapJobDev {
   uint32_t log_n, ncols;
   const uint32_t* const* coeffs;
   uint32_t* out;                 // 4 * ncols words
+  uint32_t* out_host;            // the same values into pinned host memory (or null)
   uint32_t low_off, high_off;    // word offsets of the two tables in the scratch buffer
   uint32_t partial_off;          // word offset of partial[ncols][ngroups][4]
   uint32_t block_begin;          // first block of this job in k_eval_partial_multi
@@ -408,7 +409,10 @@ __global__ void __launch_bounds__(256) k_reduce_partials_multi(const EapJobDev* 
   QM31 acc;
   for (uint32_t i = threadIdx.x; i < jb.ngroups; i += blockDim.x) acc += QM31::from_u32(p + 4 * i);
   acc = block_reduce_qm31(acc);
-  if (threadIdx.x == 0) acc.to_u32(jb.out + 4 * col);
+  if (threadIdx.x == 0) {
+    acc.to_u32(jb.out + 4 * col);
+    if (jb.out_host) *reinterpret_cast<uint4*>(jb.out_host + 4 * col) = make_uint4(acc.a.a.v, acc.a.b.v, acc.b.a.v, acc.b.b.v);
+  }
 }
 
 // ================================================================= host wrappers
@@ -627,7 +631,7 @@ void eval_at_point_multi(const std::vector<EapJob>& jobs, hipStream_t st, const 
     memset(&d, 0, sizeof(d));
     const uint32_t low = j.log_n < EAP2_LOW_BITS ? j.log_n : EAP2_LOW_BITS, high = j.log_n - low;
     const uint32_t ngroups = ((1u << high) + EAP2_GROUP - 1) / EAP2_GROUP;
-    d.log_n = j.log_n; d.ncols = j.ncols; d.coeffs = j.d_coeffs; d.out = j.d_out; d.ngroups = ngroups;
+    d.log_n = j.log_n; d.ncols = j.ncols; d.coeffs = j.d_coeffs; d.out = j.d_out; d.out_host = j.h_out; d.ngroups = ngroups;
     d.low_off = (uint32_t)words; words += (size_t)4 << low;
     d.high_off = (uint32_t)words; words += (size_t)4 << high;
     d.partial_off = (uint32_t)words; words += (size_t)4 * j.ncols * ngroups;

@@ -80,7 +80,7 @@ struct Stage {
   // One event per stream with copies out of the ring since the last wrap (main stream + Fork side streams + caller streams
   // of the per-op C ABI), re-recorded behind every copy.  The wrap waits on the EVENTS, never on the stream handles: a caller
   // may have destroyed its cm_stream_t in the meantime (hipStreamDestroy lets queued work finish; a recorded event stays valid).
-  struct User { hipStream_t st; hipEvent_t ev; };
+  struct User { hipStream_t st; hipEvent_t ev; bool dirty = false; };   // dirty: copies behind the last record of `ev` (lazy form)
   std::vector<User> users;
   std::vector<hipEvent_t> spare;
   void ensure() {
@@ -93,7 +93,10 @@ Stage& stage() {   // ring wrap syncs only the owner's stream
     s = new Stage();
     Stage* own = s;
     at_thread_exit([own] {
-      for (const Stage::User& u : own->users) { (void)hipEventSynchronize(u.ev); (void)hipEventDestroy(u.ev); }
+      for (const Stage::User& u : own->users) {
+        if (u.dirty) (void)hipStreamSynchronize(u.st);   // (the thread's main stream: alive, or already drained by its own exit hook)
+        (void)hipEventSynchronize(u.ev); (void)hipEventDestroy(u.ev);
+      }
       for (hipEvent_t e : own->spare) (void)hipEventDestroy(e);
       if (own->base) (void)hipHostFree(own->base);
       delete own;
@@ -121,7 +124,20 @@ void* pool_get(size_t bytes) { return pool().get(bytes); }
 void pool_put(void* p) { pool().put(p); }
 void pool_trim() { pool().trim(); }
 
+// The copy out of the ring as a KERNEL that reads the pinned words over PCIe: a hipMemcpyAsync of more than a few KB goes through
+// the SDMA engine, and a copy-engine command between two kernels of a compute stream costs ~10 us on either side of its 7 us
+// (four of them sat on the critical path of a proof: profiles/r05p_gaps.txt).  A/B: CM_STAGE_COPY_KERNEL=0.
+__global__ void __launch_bounds__(256) k_stage_copy(uint4* __restrict__ dst, const uint4* __restrict__ src, uint32_t n16,
+                                                    uint8_t* dst_tail, const uint8_t* src_tail, uint32_t n_tail) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
 void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  const bool copy_kernel = tuning().stage_copy_kernel.load(std::memory_order_relaxed) != 0;
+  // the thread's own main stream outlives every copy enqueued on it: its event is only recorded when the ring wraps (an event
+  // record per upload is a barrier packet per upload, ~20 per proof).  A/B: CM_STAGE_LAZY_EVENTS=0.
+  const bool lazy_events = tuning().stage_lazy_events.load(std::memory_order_relaxed) != 0;
+  if (!bytes) return;
   Stage& s = stage();
   std::lock_guard<std::mutex> lk(s.mu);
   s.ensure();
@@ -137,7 +153,10 @@ void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
   }
   if (s.off + need > s.size) {
     // wrap: every copy still reading the ring must have executed, on whichever stream it was enqueued
-    for (const Stage::User& u : s.users) { CM_HIP(hipEventSynchronize(u.ev)); s.spare.push_back(u.ev); }
+    for (const Stage::User& u : s.users) {
+      if (u.dirty) CM_HIP(hipEventRecord(u.ev, u.st));
+      CM_HIP(hipEventSynchronize(u.ev)); s.spare.push_back(u.ev);
+    }
     s.users.clear();
     s.off = 0;
   }
@@ -150,9 +169,30 @@ void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
     it = s.users.end() - 1;
   }
   memcpy(s.base + s.off, src, bytes);
-  CM_HIP(hipMemcpyAsync(dst, s.base + s.off, bytes, hipMemcpyHostToDevice, st));
-  CM_HIP(hipEventRecord(it->ev, st));
+  if (copy_kernel && ((uintptr_t)dst & 15) == 0) {
+    const uint32_t n16 = (uint32_t)(bytes / 16), n_tail = (uint32_t)(bytes % 16);
+    const uint32_t blocks = std::min<uint32_t>(std::max<uint32_t>((n16 + 255) / 256, 1u), 64u);
+    hipLaunchKernelGGL(k_stage_copy, dim3(blocks), dim3(256), 0, st, (uint4*)dst, (const uint4*)(s.base + s.off), n16,
+                       (uint8_t*)dst + (size_t)n16 * 16, s.base + s.off + (size_t)n16 * 16, n_tail);
+    CM_HIP(hipGetLastError());
+  } else {
+    CM_HIP(hipMemcpyAsync(dst, s.base + s.off, bytes, hipMemcpyHostToDevice, st));
+  }
+  if (lazy_events && st == thread_main_stream()) it->dirty = true;
+  else { CM_HIP(hipEventRecord(it->ev, st)); it->dirty = false; }
   s.off += need;
+}
+Tuning& tuning() {
+  static Tuning* t = [] {
+    auto env1 = [](const char* n) { const char* e = getenv(n); return (e && atoi(e) == 0) ? 0 : 1; };
+    Tuning* x = new Tuning();
+    x->oods_poll.store(env1("CM_OODS_POLL"));
+    x->oods_host_write.store(env1("CM_OODS_HOST_WRITE"));
+    x->stage_copy_kernel.store(env1("CM_STAGE_COPY_KERNEL"));
+    x->stage_lazy_events.store(env1("CM_STAGE_LAZY_EVENTS"));
+    return x;
+  }();
+  return *t;
 }
 void stage_forget_stream(hipStream_t st) {
   // cm_stream_destroy on the owning thread: the handle value may be recycled for a new stream, whose copies must get their own
@@ -161,6 +201,7 @@ void stage_forget_stream(hipStream_t st) {
   std::lock_guard<std::mutex> lk(s.mu);
   for (size_t i = 0; i < s.users.size(); i++)
     if (s.users[i].st == st) {
+      if (s.users[i].dirty) (void)hipStreamSynchronize(st);
       (void)hipEventSynchronize(s.users[i].ev);
       s.spare.push_back(s.users[i].ev);
       s.users.erase(s.users.begin() + i);

@@ -377,6 +377,8 @@ struct SegmentProver {
   struct OJob { uint32_t log; bool prev; CPoint<QM31> pt; std::vector<ORef> refs; size_t off = 0, out_off = 0; int chunk = 0; };
   std::vector<OJob> ojobs;                    // sampling jobs, built (and their pointer table uploaded) by oods_prepare()
   size_t n_oods_out = 0;
+  bool oods_poll = false;                    // the host watches the landing words of the sampled values instead of waiting for an event
+  static void cpu_relax() { __builtin_ia32_pause(); }
   size_t n_oods_out0 = 0, n_flat0 = 0;       // sampled values / flat samples of chunk 0 (the part hashed while chunk 1 is evaluated)
   struct QRef { int t; uint32_t c; };
   struct QEntry { uint32_t col; uint32_t sidx; };   // column of the group, index of its sampled value in d_oods_out
@@ -1057,6 +1059,7 @@ struct SegmentProver {
     // start without the host having seen root 3 (it used to cost the host replay + the launches: ~60 us of idle GPU).  The host
     // replays the same steps when root 3 arrives and checks the drawn felt.
     static const bool dev_oods = getenv("CM_HOST_OODS") == nullptr;
+    oods_poll = dev_oods && tuning().oods_poll.load(std::memory_order_relaxed) != 0;
     static thread_local hipEvent_t ev_root3 = nullptr, ev_chunk0 = nullptr;
     bool chunk0_event = false;
     if (dev_oods) P.tick("composition_commit");
@@ -1079,17 +1082,29 @@ struct SegmentProver {
         }
         ej[j.chunk].push_back(e);
       }
-      // chunk 0, its values to the host, chunk 1, its values (one pinned landing buffer, two copies)
+      // chunk 0, its values to the host, chunk 1, its values (one pinned landing buffer)
       uint8_t* land = (uint8_t*)stage_landing(n_oods_out * 16, st);
       oods_w = (const uint32_t*)land;
+      // Polling form (default; A/B: CM_OODS_POLL=0 = copy commands + event / stream synchronisation): the reduction kernel writes
+      // every sampled value into the landing buffer itself, next to its copy in HBM — the 12.5 KB copy of chunk 0 went through the
+      // SDMA engine and cost 27 us between the two chunks' kernels — and the host does not wait for an event: it fills the landing
+      // words with a value no M31 word takes and watches them change.
+      const bool host_write = oods_poll && tuning().oods_host_write.load(std::memory_order_relaxed) != 0;
+      if (oods_poll) memset(land, 0xFF, n_oods_out * 16);
+      if (host_write)
+        for (int c = 0; c < 2; c++)
+          for (auto& e : ej[c]) e.h_out = (uint32_t*)land + (e.d_out - d_oods_out.u32());
       eval_at_point_multi(ej[0], st, d_step3.u32());
-      if (n_oods_out0) CM_HIP(hipMemcpyAsync(land, d_oods_out.p, n_oods_out0 * 16, hipMemcpyDeviceToHost, st));
+      if (n_oods_out0 && !host_write) CM_HIP(hipMemcpyAsync(land, d_oods_out.p, n_oods_out0 * 16, hipMemcpyDeviceToHost, st));
       if (!ej[1].empty()) {
-        if (!ev_chunk0) { CM_HIP(hipEventCreateWithFlags(&ev_chunk0, hipEventDisableTiming)); thread_event_owned(ev_chunk0); }
-        CM_HIP(hipEventRecord(ev_chunk0, st));
+        if (!oods_poll) {
+          if (!ev_chunk0) { CM_HIP(hipEventCreateWithFlags(&ev_chunk0, hipEventDisableTiming)); thread_event_owned(ev_chunk0); }
+          CM_HIP(hipEventRecord(ev_chunk0, st));
+        }
         chunk0_event = true;
         eval_at_point_multi(ej[1], st, d_step3.u32());
-        CM_HIP(hipMemcpyAsync(land + n_oods_out0 * 16, d_oods_out.as<uint8_t>() + n_oods_out0 * 16, (n_oods_out - n_oods_out0) * 16, hipMemcpyDeviceToHost, st));
+        if (!host_write)
+          CM_HIP(hipMemcpyAsync(land + n_oods_out0 * 16, d_oods_out.as<uint8_t>() + n_oods_out0 * 16, (n_oods_out - n_oods_out0) * 16, hipMemcpyDeviceToHost, st));
       }
     }
     // ONE round trip for two roots: root 3 is waited for; root 2 and the random coefficient of the device-side step are
@@ -1247,14 +1262,27 @@ struct SegmentProver {
         ch.mix_felts_update(fm, flat.data(), flat.size());
         n_mixed += flat.size();
       };
+      // all words of [w0, w1) have arrived from the device (every word the copy writes is < 2^31); gives up after ~2 ms of
+      // spinning and lets the caller synchronise instead
+      auto landed = [&](size_t q0, size_t q1) {
+        const volatile uint32_t* v = w;
+        for (int spin = 0; spin < 200000; spin++) {
+          size_t i = 4 * q1;
+          while (i > 4 * q0 && v[i - 1] != 0xFFFFFFFFu) i--;
+          if (i == 4 * q0) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
+          cpu_relax();
+        }
+        return false;
+      };
       if (chunk0_event) {
-        CM_HIP(hipEventSynchronize(ev_chunk0));
+        if (!oods_poll) CM_HIP(hipEventSynchronize(ev_chunk0));
+        else if (!landed(0, n_oods_out0)) CM_HIP(hipStreamSynchronize(st));
         ht.mark("oods: chunk 0 landed");
         fill(0);
         mix_upto(n_flat0);
         ht.mark("oods: chunk 0 filled + mixed");
       }
-      CM_HIP(hipStreamSynchronize(st));
+      if (!(oods_poll && landed(chunk0_event ? n_oods_out0 : 0, n_out))) CM_HIP(hipStreamSynchronize(st));
       ht.mark("oods: waited for gpu");
       if (!chunk0_event) fill(0);
       fill(1);
@@ -1962,6 +1990,17 @@ int32_t cm_kprof_enable(int32_t on) {
 // time only one kernel class (name as reported by cm_kprof_report); NULL / "" = all classes
 int32_t cm_set_preprocessed_cache(int32_t on) {
   cm::g_pp_cache.store(on ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
+int32_t cm_set_tuning(const char* key, int32_t value) {
+  if (!key) return cm_set_last_error("cm_set_tuning: null key");
+  cm::Tuning& t = cm::tuning();
+  const std::string k(key);
+  if (k == "oods_poll") t.oods_poll.store(value ? 1 : 0);
+  else if (k == "oods_host_write") t.oods_host_write.store(value ? 1 : 0);
+  else if (k == "stage_copy_kernel") t.stage_copy_kernel.store(value ? 1 : 0);
+  else if (k == "stage_lazy_events") t.stage_lazy_events.store(value ? 1 : 0);
+  else return cm_set_last_error("cm_set_tuning: unknown key");
   return 0;
 }
 int32_t cm_set_device_tail(int32_t on) {

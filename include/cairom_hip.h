@@ -368,6 +368,16 @@ int32_t cm_set_twiddle_cache(int32_t on);
  * replays the transcript steps afterwards and refuses the proof on a mismatch (cairo_m_amd/csrc/tail_device.hpp);
  * 0 = the host drives each step (round trip per step, symbolic decommitment walk on the host).  Proof bytes are identical. */
 int32_t cm_set_device_tail(int32_t on);
+/* (revision 6) Measurement switches of host / device hand-overs, flipped inside one process so that two forms can be timed
+ * alternately on the same box (tools/ab_switch.py); every form produces the same proof bytes.  key:
+ *   "oods_poll"         1 (default; env CM_OODS_POLL) = the sampled values are written to pinned host memory by the kernel that
+ *                       reduces them and the host watches the words arrive; 0 = copy commands + event / stream synchronisation
+ *   "stage_copy_kernel" 1 (default; env CM_STAGE_COPY_KERNEL) = small host -> device uploads are a kernel reading the pinned
+ *                       staging ring; 0 = hipMemcpyAsync (the SDMA engine above a few KB)
+ *   "stage_lazy_events" 1 (default; env CM_STAGE_LAZY_EVENTS) = the staging ring's event of the thread's main stream is only
+ *                       recorded when the ring wraps; 0 = behind every upload
+ * status 1 for an unknown key. */
+int32_t cm_set_tuning(const char* key, int32_t value);
 /* The node lists the device-side tail gathers by (host code, no GPU: the mirror the prover checks the device against; the CPU
  * tests compare it with a restatement of MerkleProver::decommit).  positions: the sorted, de-duplicated query positions on the
  * domain of 2^log_domain points; qmask: bit l = the first FRI tree carries columns of 2^l rows; list: 0 = U[k] (queried nodes

@@ -231,6 +231,7 @@ unsafe extern "C" {
     pub fn cm_set_preprocessed_cache(on: i32) -> i32;
     pub fn cm_set_twiddle_cache(on: i32) -> i32;
     pub fn cm_set_device_tail(on: i32) -> i32;
+    pub fn cm_set_tuning(key: *const c_char, value: i32) -> i32;
     pub fn cm_tail_list(positions: *const u32, n_positions: u32, log_domain: u32, qmask: u32, list: u32, k: u32, out: *mut u32, cap: u32, n_out: *mut u32) -> i32;
     pub fn cm_proof_from_words(words: *const u32, n_words: u64, out: *mut *mut cm_proof) -> i32;
     pub fn cm_proof_words(p: *const cm_proof, words_out: *mut *const u32, n_out: *mut u64) -> i32;

@@ -1,0 +1,46 @@
+# development tool: two or more forms of a cm_set_tuning switch timed ALTERNATELY inside one process (boxes differ by +-4 %, runs of
+# one process by +-2 %; alternating blocks of lone proofs on one warm process removes both):
+#   python tools/ab_switch.py [--reps 12] [--block 8] oods_poll stage_copy_kernel stage_lazy_events
+# prints, per key, the median ms per proof with the switch on and off (all other switches at their defaults) and the paired difference.
+import argparse, os, statistics, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import ctypes as C
+import torch
+from cairo_m_amd.lib import Backend, synth_fibonacci
+
+ap = argparse.ArgumentParser()
+ap.add_argument("keys", nargs="+")
+ap.add_argument("--reps", type=int, default=12)
+ap.add_argument("--block", type=int, default=8)
+ap.add_argument("--fib-n", type=int, default=419000)
+a = ap.parse_args()
+be = Backend(0)
+dev = be.upload_input(synth_fibonacci(a.fib_n))
+
+
+def block():
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(a.block):
+        be.prove_device(dev).free()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / a.block * 1e3
+
+
+def setk(key, v):
+    assert be.L.cm_set_tuning(key.encode(), C.c_int32(v)) == 0, key
+
+
+for _ in range(2):
+    block()
+for key in a.keys:
+    on, off = [], []
+    for r in range(a.reps):
+        order = (1, 0) if r % 2 == 0 else (0, 1)
+        for v in order:
+            setk(key, v)
+            block()                      # one untimed block after every flip
+            (on if v else off).append(block())
+    setk(key, 1)
+    d = [x - y for x, y in zip(on, off)]
+    print(f"{key:20s} on {statistics.median(on):.3f} ms  off {statistics.median(off):.3f} ms  paired on - off: median {statistics.median(d):+.3f}"
+          f"  mean {statistics.mean(d):+.3f}  ({sum(1 for x in d if x < 0)} of {len(d)} pairs faster on)")
