@@ -162,7 +162,7 @@ int32_t cm_stream_destroy(cm_stream_t s) {
 }
 int32_t cm_set_cpu_affinity(int32_t mode) {
   return guard([&] {
-    CM_CHECK(mode == 0 || mode == 1, "cm_set_cpu_affinity: mode must be 0 (never) or 1 (scoped to the proving calls)");
+    CM_CHECK(mode >= 0 && mode <= 2, "cm_set_cpu_affinity: mode must be 0 (never), 1 (scoped to the proving calls) or 2 (sticky)");
     set_cpu_affinity_mode(mode);
   });
 }

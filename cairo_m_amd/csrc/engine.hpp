@@ -177,7 +177,7 @@ void stage_forget_stream(hipStream_t st);
 // from different host threads run on different streams and overlap on the GPU.
 hipStream_t thread_main_stream();
 // measurement switches (cm_set_tuning): initial values from the environment
-struct Tuning { std::atomic<int> oods_poll, oods_host_write, stage_copy_kernel, stage_lazy_events; };
+struct Tuning { std::atomic<int> oods_poll, oods_host_write, stage_copy_kernel, stage_lazy_events, defer_teardown; };
 Tuning& tuning();
 // side stream i of the calling host thread (the streams Fork hands out), with NO ordering against anything: the caller orders it
 // with events (Prover::commit_enqueue runs the transforms of a commitment there, next to the Merkle launches on the main stream)

@@ -190,6 +190,7 @@ Tuning& tuning() {
     x->oods_host_write.store(env1("CM_OODS_HOST_WRITE"));
     x->stage_copy_kernel.store(env1("CM_STAGE_COPY_KERNEL"));
     x->stage_lazy_events.store(env1("CM_STAGE_LAZY_EVENTS"));
+    x->defer_teardown.store(env1("CM_DEFER_TEARDOWN"));
     return x;
   }();
   return *t;
@@ -455,7 +456,7 @@ int affinity_mode() {
   int m = g_affinity_mode.load(std::memory_order_relaxed);
   if (m < 0) {
     const char* e = getenv("CM_CPU_AFFINITY");
-    m = (getenv("CM_NO_CPU_AFFINITY") != nullptr) ? 0 : (e ? (atoi(e) != 0) : 1);
+    m = (getenv("CM_NO_CPU_AFFINITY") != nullptr) ? 0 : (e ? (atoi(e) == 2 ? 2 : atoi(e) != 0) : 1);
     g_affinity_mode.store(m);
   }
   return m;
@@ -507,13 +508,22 @@ bool narrow_to_device(cpu_set_t* saved) {
   return sched_setaffinity(0, sizeof(both), &both) == 0;   // tid 0 = the calling thread
 }
 }  // namespace
-void set_cpu_affinity_mode(int mode) { g_affinity_mode.store(mode ? 1 : 0); }
+void set_cpu_affinity_mode(int mode) { g_affinity_mode.store(mode == 2 ? 2 : (mode ? 1 : 0)); }
 int cpu_affinity_mode() { return affinity_mode(); }
-AffinityScope::AffinityScope() { active = affinity_mode() == 1 && narrow_to_device(&saved); }
+AffinityScope::AffinityScope() {
+  const int m = affinity_mode();
+  if (m == 2) {   // STICKY: narrowed once per thread, never restored (three syscalls per proof cost 30-50 us on the pool's hosts)
+    static thread_local bool done = false;
+    if (!done) { cpu_set_t dropped; (void)narrow_to_device(&dropped); done = true; }
+    active = false;
+    return;
+  }
+  active = m == 1 && narrow_to_device(&saved);
+}
 AffinityScope::~AffinityScope() { if (active) (void)sched_setaffinity(0, sizeof(saved), &saved); }
 void bind_worker_thread_cpus() {
   cpu_set_t saved;
-  if (affinity_mode() == 1) (void)narrow_to_device(&saved);
+  if (affinity_mode() >= 1) (void)narrow_to_device(&saved);
 }
 hipStream_t thread_main_stream() {
   static thread_local hipStream_t s = nullptr;

@@ -349,7 +349,10 @@ struct SegmentProver {
   std::unique_ptr<ProofData> out;
   ProofData& pf;
   HostTrace ht;
+  struct DtorMark { HostTrace* ht; const char* what; ~DtorMark() { ht->mark(what); } };   // (CM_HOST_MARKS: where the teardown goes)
+  DtorMark dm_p{&ht, "~ everything else (P: trees, events)"};
   Prover P;
+  DtorMark dm_after_p{&ht, "~ twiddles .. step buffers"};
   hipStream_t st;
   Channel& ch;
   uint32_t clog[air::N_COMPONENTS];          // log2 rows of every component
@@ -368,11 +371,14 @@ struct SegmentProver {
   DevBuf d_step2;                            // device-side transcript step after tree 2: {channel[16], coefficient[4], root[8]}
   DevBuf d_ctab;                             // composition: every small table of the constraints phase, ONE upload
   CPoint<QM31> oods;
+  DtorMark dm_q{&ht, "~ oods buffers, quotients"};
   DevBuf d_oods_table, d_oods_out, d_qblob;  // sampling pointer table, sampled values, DEEP-quotient plan
   size_t o_qjobs = 0, n_qjobs = 0;
   std::vector<uint32_t> q_logs;
   std::vector<ColumnSet> quotients;
+  DtorMark dm_fri{&ht, "~ fri"};
   FriPhase fri;
+  DtorMark dm_rest{&ht, "~ ojobs, qg, affinity"};
   struct ORef { int t; uint32_t c; bool prev; };
   struct OJob { uint32_t log; bool prev; CPoint<QM31> pt; std::vector<ORef> refs; size_t off = 0, out_off = 0; int chunk = 0; };
   std::vector<OJob> ojobs;                    // sampling jobs, built (and their pointer table uploaded) by oods_prepare()
@@ -408,7 +414,9 @@ struct SegmentProver {
     decommit();
 
     kprof_close_run();   // a run of timed launches still open on this thread
+    ht.mark("finish: entered");
     P.finish();
+    ht.mark("finish: phase events read");
     fork_join_check();
     pf.phase_ms = P.phase_ms;
     pf.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - P.t0).count();
@@ -422,8 +430,23 @@ struct SegmentProver {
     } else if (tl_pp_cache.valid) {
       tl_pp_cache = PreprocessedCache();  // switched off: give the buffers back to the pool
     }
+    // Teardown that can wait: the FRI phase alone owns ~500 pool blocks (20 layers x (4 columns + a tree of ~20 layers)) and
+    // giving them back took 80-100 us with the GPU idle between two proofs.  They are parked here and released by this thread's
+    // NEXT proof while it waits for tree 1 (or when the thread ends); the next FRI phase finds them back in the pool.
+    if (defer_teardown()) {
+      std::unique_ptr<Parked>& g = parked();
+      g.reset(new Parked());
+      g->fri = std::move(fri);
+      g->qg = std::move(qg);
+      g->ojobs = std::move(ojobs);
+      g->quotients = std::move(quotients);
+    }
+    ht.mark("finish: done");
     return out.release();
   }
+  struct Parked { FriPhase fri; std::vector<QGroup> qg; std::vector<OJob> ojobs; std::vector<ColumnSet> quotients; };
+  static std::unique_ptr<Parked>& parked() { static thread_local std::unique_ptr<Parked> g; return g; }
+  static bool defer_teardown() { return tuning().defer_teardown.load(std::memory_order_relaxed) != 0; }
 
   // component sizes, twiddles (side stream), transcript setup (prover.rs:33-66)
   void setup() {
@@ -621,6 +644,8 @@ struct SegmentProver {
                          rel + 4 * air::N_RELATIONS, d_step1.u32(), st);
       CM_HIP(hipMemcpyAsync(pinned_words() + PIN_STEP1, d_step1.p, 16 * 4, hipMemcpyDeviceToHost, st));
       ht.mark("trace_commit: enqueued");
+      parked().reset();   // the previous proof's parked teardown: the host is about to wait ~0.9 ms anyway
+      ht.mark("trace_commit: previous proof's teardown");
       P.pace(&P.trees[1].merkle);
       ht.mark("trace_commit: paced (tree 1 at its top)");
     }
@@ -1421,7 +1446,25 @@ struct SegmentProver {
     if (!ticked) P.tick("decommit");
   }
 };
-ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) { return SegmentProver(din, cfg).run(); }
+ProofData* prove(const DeviceInput& din, const cm_pcs_config& cfg) {
+  static const bool marks = getenv("CM_HOST_MARKS") != nullptr;
+  static thread_local std::chrono::steady_clock::time_point last_return;
+  static thread_local bool have_last = false;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  if (marks && have_last) fprintf(stderr, "[host] %-40s %8.1f us\n", "(between two proofs: caller)", std::chrono::duration<double, std::micro>(now() - last_return).count());
+  const auto t0 = now();
+  ProofData* r;
+  std::chrono::steady_clock::time_point t1;
+  {
+    SegmentProver sp(din, cfg);
+    if (marks) fprintf(stderr, "[host] %-40s %8.1f us\n", "(prover object constructed)", std::chrono::duration<double, std::micro>(now() - t0).count());
+    r = sp.run();
+    t1 = now();
+  }
+  if (marks) fprintf(stderr, "[host] %-40s %8.1f us\n", "(prover object destroyed)", std::chrono::duration<double, std::micro>(now() - t1).count());
+  last_return = now(); have_last = true;
+  return r;
+}
 
 #include "prover_sharded.inc"
 
@@ -1998,6 +2041,7 @@ int32_t cm_set_tuning(const char* key, int32_t value) {
   const std::string k(key);
   if (k == "oods_poll") t.oods_poll.store(value ? 1 : 0);
   else if (k == "oods_host_write") t.oods_host_write.store(value ? 1 : 0);
+  else if (k == "defer_teardown") t.defer_teardown.store(value ? 1 : 0);
   else if (k == "stage_copy_kernel") t.stage_copy_kernel.store(value ? 1 : 0);
   else if (k == "stage_lazy_events") t.stage_lazy_events.store(value ? 1 : 0);
   else return cm_set_last_error("cm_set_tuning: unknown key");

@@ -56,6 +56,9 @@ int32_t cm_stream_sync(cm_stream_t s);
  *          already had) and the caller's own mask is restored before the call returns, so nothing leaks into the
  *          host application, into threads it creates later or into child processes.  The library's own
  *          cm_prove_many worker threads stay on the GPU's node.
+ *   mode 2 (env CM_CPU_AFFINITY=2): STICKY — a thread that calls cm_prove* is narrowed the same way ONCE and stays there: a
+ *          dedicated proving thread saves the three affinity system calls of every proof (30-50 us on the hosts this was
+ *          measured on; bench.py's worker threads use it and say so in their line).
  *   mode 0 (env CM_CPU_AFFINITY=0 or CM_NO_CPU_AFFINITY=1): the library never calls sched_setaffinity.
  * cm_get_cpu_affinity returns the mode in force. */
 int32_t cm_set_cpu_affinity(int32_t mode);
@@ -372,6 +375,10 @@ int32_t cm_set_device_tail(int32_t on);
  * alternately on the same box (tools/ab_switch.py); every form produces the same proof bytes.  key:
  *   "oods_poll"         1 (default; env CM_OODS_POLL) = the sampled values are written to pinned host memory by the kernel that
  *                       reduces them and the host watches the words arrive; 0 = copy commands + event / stream synchronisation
+ *   "oods_host_write"   (with oods_poll) 1 (default) = the reducing kernel writes the pinned words; 0 = copy commands, watched
+ *   "defer_teardown"    1 (default; env CM_DEFER_TEARDOWN) = the pool blocks of a proof's FRI phase / quotient plan are given back
+ *                       by the calling thread's NEXT proof while it waits for tree 1 (or when the thread ends); 0 = before cm_prove*
+ *                       returns
  *   "stage_copy_kernel" 1 (default; env CM_STAGE_COPY_KERNEL) = small host -> device uploads are a kernel reading the pinned
  *                       staging ring; 0 = hipMemcpyAsync (the SDMA engine above a few KB)
  *   "stage_lazy_events" 1 (default; env CM_STAGE_LAZY_EVENTS) = the staging ring's event of the thread's main stream is only

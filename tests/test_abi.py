@@ -31,3 +31,21 @@ def test_no_cpu_fallback_without_gpu():
     from cairo_m_amd import Backend, CmError
     with pytest.raises(CmError):
         Backend(0)
+
+
+def test_process_wide_switches_reject_what_they_do_not_know():
+    """cm_set_cpu_affinity: 0 never / 1 scoped (default) / 2 sticky; cm_set_tuning: the measurement switches by name (host code:
+    no GPU needed to set them)"""
+    from cairo_m_amd.lib import load_library
+    L = load_library()
+    before = L.cm_get_cpu_affinity()
+    try:
+        for mode in (0, 2, 1):
+            assert L.cm_set_cpu_affinity(C.c_int32(mode)) == 0 and L.cm_get_cpu_affinity() == mode
+        assert L.cm_set_cpu_affinity(C.c_int32(3)) != 0 and L.cm_get_cpu_affinity() == 1
+    finally:
+        L.cm_set_cpu_affinity(C.c_int32(before))
+    for key in (b"oods_poll", b"oods_host_write", b"stage_copy_kernel", b"stage_lazy_events", b"defer_teardown"):
+        assert L.cm_set_tuning(key, C.c_int32(0)) == 0 and L.cm_set_tuning(key, C.c_int32(1)) == 0
+    assert L.cm_set_tuning(b"no_such_switch", C.c_int32(1)) != 0
+    assert L.cm_set_tuning(None, C.c_int32(1)) != 0

@@ -13,20 +13,31 @@ ap.add_argument("keys", nargs="+")
 ap.add_argument("--reps", type=int, default=12)
 ap.add_argument("--block", type=int, default=8)
 ap.add_argument("--fib-n", type=int, default=419000)
+ap.add_argument("--phases", action="store_true", help="also the mean GPU phase times per form")
 a = ap.parse_args()
 be = Backend(0)
 dev = be.upload_input(synth_fibonacci(a.fib_n))
 
 
-def block():
+PH = {}
+
+
+def block(tag=None):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(a.block):
-        be.prove_device(dev).free()
+        p = be.prove_device(dev)
+        if tag is not None:   # GPU-side phase times (HIP events on the main stream), summed per variant
+            for k, v in p.stats()["phase_ms"].items():
+                PH.setdefault(tag, {}).setdefault(k, []).append(v)
+        p.free()
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / a.block * 1e3
 
 
 def setk(key, v):
+    if key == "cpu_affinity_sticky":   # cm_set_cpu_affinity: 2 = sticky, 1 = scoped (the default)
+        assert be.L.cm_set_cpu_affinity(C.c_int32(2 if v else 1)) == 0
+        return
     assert be.L.cm_set_tuning(key.encode(), C.c_int32(v)) == 0, key
 
 
@@ -39,8 +50,12 @@ for key in a.keys:
         for v in order:
             setk(key, v)
             block()                      # one untimed block after every flip
-            (on if v else off).append(block())
+            (on if v else off).append(block((key, v)))
     setk(key, 1)
     d = [x - y for x, y in zip(on, off)]
     print(f"{key:20s} on {statistics.median(on):.3f} ms  off {statistics.median(off):.3f} ms  paired on - off: median {statistics.median(d):+.3f}"
           f"  mean {statistics.mean(d):+.3f}  ({sum(1 for x in d if x < 0)} of {len(d)} pairs faster on)")
+    if a.phases:
+        for k in PH[(key, 1)]:
+            m1, m0 = statistics.mean(PH[(key, 1)][k]), statistics.mean(PH[(key, 0)][k])
+            print(f"    {k:22s} on {m1:7.3f}  off {m0:7.3f}  {m1 - m0:+.3f}")
