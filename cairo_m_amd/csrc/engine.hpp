@@ -176,9 +176,14 @@ void stage_forget_stream(hipStream_t st);
 // The prover's main stream of the calling host thread (created on first use, non-blocking): concurrent proofs
 // from different host threads run on different streams and overlap on the GPU.
 hipStream_t thread_main_stream();
-// measurement switches (cm_set_tuning): initial values from the environment
-struct Tuning { std::atomic<int> oods_poll, oods_host_write, stage_copy_kernel, stage_lazy_events, defer_teardown; };
-Tuning& tuning();
+// measurement switches (cm_set_tuning; include/cairom_hip.h lists them): initial values from the environment, flipped at run time
+// so that two forms can be timed alternately inside one process (tools/ab_switch.py)
+enum TuneKey { T_OODS_POLL, T_OODS_HOST_WRITE, T_STAGE_COPY_KERNEL, T_STAGE_LAZY_EVENTS, T_DEFER_TEARDOWN, T_FLAG_JOIN, T_FLAG_FORK,
+               T_COMMIT_PREP_EARLY, T_TRACE_HIST_FUSE, T_FRI_TOP_FUSE, T_LOGUP_DEFER, T_OODS_SPLIT, T_COUNT };
+struct TuneEntry { const char* key; const char* env; int dflt; };
+extern const TuneEntry TUNE_TABLE[T_COUNT];
+std::atomic<int>* tune_values();
+inline int tune(TuneKey k) { return tune_values()[k].load(std::memory_order_relaxed); }
 // side stream i of the calling host thread (the streams Fork hands out), with NO ordering against anything: the caller orders it
 // with events (Prover::commit_enqueue runs the transforms of a commitment there, next to the Merkle launches on the main stream)
 hipStream_t thread_side_stream(int i);

@@ -32,7 +32,10 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
   // every layer above the single-launch tail is allocated up front so that the column tables of all their
   // Merkle trees (and of the first-layer tree) travel in ONE host->device copy
   std::vector<std::unique_ptr<InnerLayer>> pre;
-  static const bool top_fuse = getenv("CM_FRI_TOP_FUSE") && atoi(getenv("CM_FRI_TOP_FUSE")) != 0;   // measured: no gain (profiles/r05f_ab_fri_top_fuse.txt) — the small layers are bound by the dependent-compression chain, not by launches; off
+  // Separate processes could not tell the two forms apart (profiles/r05f_ab_fri_top_fuse.txt: the small layers are bound by the
+  // dependent-compression chain, not by launches); alternating blocks inside one process can: -0.07 ms per proof, 13 of 16 pairs
+  // (profiles/r05_ab_switches_in_process.txt).  On.
+  const bool top_fuse = tune(T_FRI_TOP_FUSE) != 0;
   {
     UploadBatch ub;
     std::vector<const uint32_t*> cols;

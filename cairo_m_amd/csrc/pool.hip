@@ -133,10 +133,10 @@ __global__ void __launch_bounds__(256) k_stage_copy(uint4* __restrict__ dst, con
   if (blockIdx.x == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
-  const bool copy_kernel = tuning().stage_copy_kernel.load(std::memory_order_relaxed) != 0;
+  const bool copy_kernel = tune(T_STAGE_COPY_KERNEL) != 0;
   // the thread's own main stream outlives every copy enqueued on it: its event is only recorded when the ring wraps (an event
   // record per upload is a barrier packet per upload, ~20 per proof).  A/B: CM_STAGE_LAZY_EVENTS=0.
-  const bool lazy_events = tuning().stage_lazy_events.load(std::memory_order_relaxed) != 0;
+  const bool lazy_events = tune(T_STAGE_LAZY_EVENTS) != 0;
   if (!bytes) return;
   Stage& s = stage();
   std::lock_guard<std::mutex> lk(s.mu);
@@ -182,18 +182,22 @@ void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
   else { CM_HIP(hipEventRecord(it->ev, st)); it->dirty = false; }
   s.off += need;
 }
-Tuning& tuning() {
-  static Tuning* t = [] {
-    auto env1 = [](const char* n) { const char* e = getenv(n); return (e && atoi(e) == 0) ? 0 : 1; };
-    Tuning* x = new Tuning();
-    x->oods_poll.store(env1("CM_OODS_POLL"));
-    x->oods_host_write.store(env1("CM_OODS_HOST_WRITE"));
-    x->stage_copy_kernel.store(env1("CM_STAGE_COPY_KERNEL"));
-    x->stage_lazy_events.store(env1("CM_STAGE_LAZY_EVENTS"));
-    x->defer_teardown.store(env1("CM_DEFER_TEARDOWN"));
+const TuneEntry TUNE_TABLE[T_COUNT] = {
+    {"oods_poll", "CM_OODS_POLL", 1},           {"oods_host_write", "CM_OODS_HOST_WRITE", 1}, {"stage_copy_kernel", "CM_STAGE_COPY_KERNEL", 1},
+    {"stage_lazy_events", "CM_STAGE_LAZY_EVENTS", 1}, {"defer_teardown", "CM_DEFER_TEARDOWN", 1}, {"flag_join", "CM_FLAG_JOIN", 1},
+    {"flag_fork", "CM_FLAG_FORK", 1},           {"commit_prep_early", "CM_COMMIT_PREP_EARLY", 1}, {"trace_hist_fuse", "CM_TRACE_HIST_FUSE", 1},
+    {"fri_top_fuse", "CM_FRI_TOP_FUSE", 1},     {"logup_defer", "CM_LOGUP_DEFER", 1},         {"oods_split", "CM_OODS_SPLIT", 780},
+};
+std::atomic<int>* tune_values() {
+  static std::atomic<int>* v = [] {
+    std::atomic<int>* x = new std::atomic<int>[T_COUNT];
+    for (int k = 0; k < T_COUNT; k++) {
+      const char* e = getenv(TUNE_TABLE[k].env);
+      x[k].store(e ? atoi(e) : TUNE_TABLE[k].dflt);
+    }
     return x;
   }();
-  return *t;
+  return v;
 }
 void stage_forget_stream(hipStream_t st) {
   // cm_stream_destroy on the owning thread: the handle value may be recycled for a new stream, whose copies must get their own
@@ -404,7 +408,7 @@ static bool flag_sync_usable() {
   return ok;
 }
 static bool flag_fork_on() {
-  static const bool on = !(getenv("CM_FLAG_FORK") && atoi(getenv("CM_FLAG_FORK")) == 0) && flag_sync_usable();
+  const bool on = tune(T_FLAG_FORK) != 0 && flag_sync_usable();
   return on;
 }
 Fork::Fork(hipStream_t main_stream) : main(main_stream) {
@@ -539,7 +543,7 @@ void Fork::join() {
   if (joined) return;
   joined = true;
   SideStreams& ss = side();
-  static const bool flag_join = !(getenv("CM_FLAG_JOIN") && atoi(getenv("CM_FLAG_JOIN")) == 0) && flag_sync_usable();
+  const bool flag_join = tune(T_FLAG_JOIN) != 0 && flag_sync_usable();
   if (flag_join && used) {
     const uint32_t epoch = ++ss.epoch;
     for (int i = 0; i < N; i++)

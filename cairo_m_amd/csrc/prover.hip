@@ -446,7 +446,7 @@ struct SegmentProver {
   }
   struct Parked { FriPhase fri; std::vector<QGroup> qg; std::vector<OJob> ojobs; std::vector<ColumnSet> quotients; };
   static std::unique_ptr<Parked>& parked() { static thread_local std::unique_ptr<Parked> g; return g; }
-  static bool defer_teardown() { return tuning().defer_teardown.load(std::memory_order_relaxed) != 0; }
+  static bool defer_teardown() { return tune(T_DEFER_TEARDOWN) != 0; }
 
   // component sizes, twiddles (side stream), transcript setup (prover.rs:33-66)
   void setup() {
@@ -562,7 +562,7 @@ struct SegmentProver {
         if (clog[c] <= SMALL_COMPONENT_MAX_LOG && !no_small_batch()) continue;
         hipStream_t sc = fk.stream(spos == 0 ? Fork::main_or(0) : spos % fork_width(Fork::N - 2));   // by_size: the first one is the largest
         spos++;
-        static const bool fuse_th = !(getenv("CM_TRACE_HIST_FUSE") && atoi(getenv("CM_TRACE_HIST_FUSE")) == 0);   // A/B
+        const bool fuse_th = tune(T_TRACE_HIST_FUSE) != 0;   // A/B
         if (fuse_th) launch_opcode_trace_hist(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), h, sc);
         else {
           launch_opcode_trace(c, din.bundles[c].p, (uint32_t)in.n_bundles[c], din.data_accesses.p, clog[c], tr_evals.dev(tr0[c]), sc);
@@ -661,7 +661,7 @@ struct SegmentProver {
     // The LogUp tail (claimed sums, the running-sum columns' prefix scans: ~0.15 ms of short memory-bound kernels) runs on a side
     // stream while the tree-2 transforms of every OTHER column start; the running-sum columns go last in their size group.
     // CM_LOGUP_DEFER=0: the tail on the main stream in front of the tree (the round-3 order).
-    static const bool defer_tail = !(getenv("CM_LOGUP_DEFER") && atoi(getenv("CM_LOGUP_DEFER")) == 0);
+    const bool defer_tail = tune(T_LOGUP_DEFER) != 0;
     std::vector<DevBuf> tail_scratch;   // alive until the host has seen the sums
     Prover::DeferredCols late;
     Prover::CommitPrep tree2_prep;
@@ -714,7 +714,7 @@ struct SegmentProver {
       // while the LogUp kernels just launched execute — it used to sit between the LogUp tail and the first transform with the
       // GPU idle (50 us in the round-5 timeline).  Its one host->device copy lands on the main stream behind the region's
       // largest kernel.  CM_COMMIT_PREP_EARLY=0: prepared at the launch (A/B).
-      static const bool prep_early = !(getenv("CM_COMMIT_PREP_EARLY") && atoi(getenv("CM_COMMIT_PREP_EARLY")) == 0);
+      const bool prep_early = tune(T_COMMIT_PREP_EARLY) != 0;
       if (defer_tail) {
         late.late.assign(it_evals.ptrs.size(), 0);
         for (int c = 0; c < air::N_COMPONENTS; c++)
@@ -1026,7 +1026,7 @@ struct SegmentProver {
       // Two chunks in the transcript's flat order (tree, column, mask): the sampled values of chunk 0 come back first and the
       // host hashes them (channel.mix_felts, ~0.1 ms of sequential Blake2s over ~30 KB) while the GPU evaluates chunk 1 — the
       // split makes the two take about as long (CM_OODS_SPLIT: per mille of the samples in chunk 0; 1000 = one chunk)
-      static const uint32_t split_pm = getenv("CM_OODS_SPLIT") ? (uint32_t)atoi(getenv("CM_OODS_SPLIT")) : OODS_SPLIT_DEFAULT;
+      const uint32_t split_pm = (uint32_t)tune(T_OODS_SPLIT);
       std::vector<std::vector<char>> has_prev(4);
       size_t total = 0;
       for (int t = 0; t < 4; t++) { has_prev[t].assign(P.trees[t].coeffs.size(), 0); total += P.trees[t].coeffs.size(); }
@@ -1084,7 +1084,7 @@ struct SegmentProver {
     // start without the host having seen root 3 (it used to cost the host replay + the launches: ~60 us of idle GPU).  The host
     // replays the same steps when root 3 arrives and checks the drawn felt.
     static const bool dev_oods = getenv("CM_HOST_OODS") == nullptr;
-    oods_poll = dev_oods && tuning().oods_poll.load(std::memory_order_relaxed) != 0;
+    oods_poll = dev_oods && tune(T_OODS_POLL) != 0;
     static thread_local hipEvent_t ev_root3 = nullptr, ev_chunk0 = nullptr;
     bool chunk0_event = false;
     if (dev_oods) P.tick("composition_commit");
@@ -1114,7 +1114,7 @@ struct SegmentProver {
       // every sampled value into the landing buffer itself, next to its copy in HBM — the 12.5 KB copy of chunk 0 went through the
       // SDMA engine and cost 27 us between the two chunks' kernels — and the host does not wait for an event: it fills the landing
       // words with a value no M31 word takes and watches them change.
-      const bool host_write = oods_poll && tuning().oods_host_write.load(std::memory_order_relaxed) != 0;
+      const bool host_write = oods_poll && tune(T_OODS_HOST_WRITE) != 0;
       if (oods_poll) memset(land, 0xFF, n_oods_out * 16);
       if (host_write)
         for (int c = 0; c < 2; c++)
@@ -2037,15 +2037,14 @@ int32_t cm_set_preprocessed_cache(int32_t on) {
 }
 int32_t cm_set_tuning(const char* key, int32_t value) {
   if (!key) return cm_set_last_error("cm_set_tuning: null key");
-  cm::Tuning& t = cm::tuning();
-  const std::string k(key);
-  if (k == "oods_poll") t.oods_poll.store(value ? 1 : 0);
-  else if (k == "oods_host_write") t.oods_host_write.store(value ? 1 : 0);
-  else if (k == "defer_teardown") t.defer_teardown.store(value ? 1 : 0);
-  else if (k == "stage_copy_kernel") t.stage_copy_kernel.store(value ? 1 : 0);
-  else if (k == "stage_lazy_events") t.stage_lazy_events.store(value ? 1 : 0);
-  else return cm_set_last_error("cm_set_tuning: unknown key");
-  return 0;
+  for (int k = 0; k < cm::T_COUNT; k++)
+    if (strcmp(cm::TUNE_TABLE[k].key, key) == 0) {
+      if (k == cm::T_OODS_SPLIT) { if (value < 0 || value > 1000) return cm_set_last_error("cm_set_tuning: oods_split is per mille, 0..1000"); }
+      else value = value ? 1 : 0;
+      cm::tune_values()[k].store(value);
+      return 0;
+    }
+  return cm_set_last_error("cm_set_tuning: unknown key");
 }
 int32_t cm_set_device_tail(int32_t on) {
   cm::g_device_tail.store(on ? 1 : 0);

@@ -371,18 +371,22 @@ int32_t cm_set_twiddle_cache(int32_t on);
  * replays the transcript steps afterwards and refuses the proof on a mismatch (cairo_m_amd/csrc/tail_device.hpp);
  * 0 = the host drives each step (round trip per step, symbolic decommitment walk on the host).  Proof bytes are identical. */
 int32_t cm_set_device_tail(int32_t on);
-/* (revision 6) Measurement switches of host / device hand-overs, flipped inside one process so that two forms can be timed
- * alternately on the same box (tools/ab_switch.py); every form produces the same proof bytes.  key:
- *   "oods_poll"         1 (default; env CM_OODS_POLL) = the sampled values are written to pinned host memory by the kernel that
- *                       reduces them and the host watches the words arrive; 0 = copy commands + event / stream synchronisation
- *   "oods_host_write"   (with oods_poll) 1 (default) = the reducing kernel writes the pinned words; 0 = copy commands, watched
- *   "defer_teardown"    1 (default; env CM_DEFER_TEARDOWN) = the pool blocks of a proof's FRI phase / quotient plan are given back
- *                       by the calling thread's NEXT proof while it waits for tree 1 (or when the thread ends); 0 = before cm_prove*
- *                       returns
- *   "stage_copy_kernel" 1 (default; env CM_STAGE_COPY_KERNEL) = small host -> device uploads are a kernel reading the pinned
- *                       staging ring; 0 = hipMemcpyAsync (the SDMA engine above a few KB)
- *   "stage_lazy_events" 1 (default; env CM_STAGE_LAZY_EVENTS) = the staging ring's event of the thread's main stream is only
- *                       recorded when the ring wraps; 0 = behind every upload
+/* (revision 6) Measurement switches, flipped inside one process so that two forms can be timed alternately on the same box
+ * (tools/ab_switch.py: paired blocks of lone proofs); every form produces the same proof bytes.  Each has an environment
+ * variable of the same name in capitals behind CM_ for its initial value.  key (default):
+ *   "oods_poll" (1)          the sampled values are watched arriving in pinned host memory; 0 = event / stream synchronisation
+ *   "oods_host_write" (1)    (with oods_poll) the kernel that reduces them writes the pinned words; 0 = copy commands, watched
+ *   "oods_split" (780)       per mille of the sampled values evaluated, copied and hashed first (1000 = one chunk)
+ *   "stage_copy_kernel" (1)  small host -> device uploads are a kernel reading the pinned staging ring; 0 = hipMemcpyAsync (the SDMA
+ *                            engine above a few KB)
+ *   "stage_lazy_events" (1)  the staging ring's event of the thread's main stream is recorded when the ring wraps; 0 = per upload
+ *   "defer_teardown" (1)     the pool blocks of a proof's FRI phase / quotient plan are given back by the calling thread's NEXT
+ *                            proof while it waits for tree 1 (or when the thread ends); 0 = before cm_prove* returns
+ *   "flag_join" / "flag_fork" (1)  fork regions joined / forked by flag words polled by one-wave kernels; 0 = HIP events
+ *   "commit_prep_early" (1)  the interaction tree's launch plan is prepared under the LogUp kernels; 0 = behind them
+ *   "trace_hist_fuse" (1)    trace cells and lookup histogram of a large opcode component in one launch; 0 = two
+ *   "logup_defer" (1)        the LogUp tail (claimed sums, prefix scans) on a side stream next to the first transforms; 0 = in front
+ *   "fri_top_fuse" (1)       fold + transcript step inside the tree-top launch of the FRI layers <= 2^16; 0 = three launches
  * status 1 for an unknown key. */
 int32_t cm_set_tuning(const char* key, int32_t value);
 /* The node lists the device-side tail gathers by (host code, no GPU: the mirror the prover checks the device against; the CPU

@@ -45,7 +45,11 @@ def test_process_wide_switches_reject_what_they_do_not_know():
         assert L.cm_set_cpu_affinity(C.c_int32(3)) != 0 and L.cm_get_cpu_affinity() == 1
     finally:
         L.cm_set_cpu_affinity(C.c_int32(before))
-    for key in (b"oods_poll", b"oods_host_write", b"stage_copy_kernel", b"stage_lazy_events", b"defer_teardown"):
+    for key in (b"oods_poll", b"oods_host_write", b"stage_copy_kernel", b"stage_lazy_events", b"defer_teardown", b"flag_join", b"flag_fork",
+                b"commit_prep_early", b"trace_hist_fuse", b"logup_defer"):
         assert L.cm_set_tuning(key, C.c_int32(0)) == 0 and L.cm_set_tuning(key, C.c_int32(1)) == 0
+    assert L.cm_set_tuning(b"fri_top_fuse", C.c_int32(1)) == 0 and L.cm_set_tuning(b"fri_top_fuse", C.c_int32(0)) == 0
+    assert L.cm_set_tuning(b"oods_split", C.c_int32(650)) == 0 and L.cm_set_tuning(b"oods_split", C.c_int32(780)) == 0
+    assert L.cm_set_tuning(b"oods_split", C.c_int32(1001)) != 0
     assert L.cm_set_tuning(b"no_such_switch", C.c_int32(1)) != 0
     assert L.cm_set_tuning(None, C.c_int32(1)) != 0

@@ -1,6 +1,7 @@
 # development tool: two or more forms of a cm_set_tuning switch timed ALTERNATELY inside one process (boxes differ by +-4 %, runs of
 # one process by +-2 %; alternating blocks of lone proofs on one warm process removes both):
-#   python tools/ab_switch.py [--reps 12] [--block 8] oods_poll stage_copy_kernel stage_lazy_events
+#   python tools/ab_switch.py [--reps 12] [--block 8] oods_poll stage_copy_kernel oods_split=650,780
+# (key alone: 1 against 0; key=a,b: value a against value b)
 # prints, per key, the median ms per proof with the switch on and off (all other switches at their defaults) and the paired difference.
 import argparse, os, statistics, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -20,6 +21,7 @@ dev = be.upload_input(synth_fibonacci(a.fib_n))
 
 
 PH = {}
+DEFAULTS = [("oods_split", 780)]   # every other switch defaults to 1
 
 
 def block(tag=None):
@@ -43,17 +45,19 @@ def setk(key, v):
 
 for _ in range(2):
     block()
-for key in a.keys:
+for spec in a.keys:
+    key, _, vals = spec.partition("=")
+    von, voff = (int(x) for x in vals.split(",")) if vals else (1, 0)
     on, off = [], []
     for r in range(a.reps):
         order = (1, 0) if r % 2 == 0 else (0, 1)
         for v in order:
-            setk(key, v)
+            setk(key, von if v else voff)
             block()                      # one untimed block after every flip
             (on if v else off).append(block((key, v)))
-    setk(key, 1)
+    setk(key, {e[0]: e[1] for e in DEFAULTS}.get(key, 1))
     d = [x - y for x, y in zip(on, off)]
-    print(f"{key:20s} on {statistics.median(on):.3f} ms  off {statistics.median(off):.3f} ms  paired on - off: median {statistics.median(d):+.3f}"
+    print(f"{spec:24s} on {statistics.median(on):.3f} ms  off {statistics.median(off):.3f} ms  paired on - off: median {statistics.median(d):+.3f}"
           f"  mean {statistics.mean(d):+.3f}  ({sum(1 for x in d if x < 0)} of {len(d)} pairs faster on)")
     if a.phases:
         for k in PH[(key, 1)]:
