@@ -1371,6 +1371,16 @@ struct SegmentProver {
     if (dev_tail) tail.enqueue(P, fri, quotients, q_logs);
     check_composition_at_oods(pf, tr0, it0, clog, hrel, powers, coff, oods);   // host-only, overlapped with the kernels enqueued above
     ht.mark("fri: enqueued, oods check done");
+    // The host now waits ~2 ms for the FRI layers: give back what nothing enqueued later can need — the trace-domain evaluations,
+    // the coefficient columns of the four trees, the small per-phase tables — instead of doing it between two proofs with the GPU
+    // idle.  (Pool blocks are reused in stream order on this thread's stream: releasing them under running kernels is safe.)
+    if (defer_teardown()) {
+      tr_evals = ColumnSet();
+      if (!pp_cache_enabled()) pp_evals = ColumnSet();
+      for (int t = pp_cache_enabled() ? 1 : 0; t < 4; t++) P.trees[t].coeffs = ColumnSet();
+      drel = DevBuf(); d_powers = DevBuf(); d_step1 = DevBuf(); d_step2 = DevBuf(); d_ctab = DevBuf(); d_oods_table = DevBuf(); d_qblob = DevBuf();
+      ht.mark("fri: early teardown");
+    }
     if (dev_tail) {
       CM_HIP(hipEventSynchronize(tail.ev_last));        // challenges, roots and the last layer are in pinned memory ...
       ht.mark("tail: last layer landed");
