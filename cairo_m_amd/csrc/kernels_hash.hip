@@ -152,8 +152,8 @@ void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* con
                   uint32_t* d_out, hipStream_t st) {
   uint32_t n = 1u << log_size;
   // algorithmic bytes: column values once + 64 B of child hashes in, 32 B out per node
-  KProfScope kp("k_merkle_layer", (4.0 * ncols + (d_prev ? 64.0 : 0.0) + 32.0) * (double)n, st,
-                /* Blake2s compressions */ (double)n * ((d_prev ? 1.0 : 0.0) + (double)((ncols + 15) / 16)));
+  KProfExt kp("k_merkle_layer", (4.0 * ncols + (d_prev ? 64.0 : 0.0) + 32.0) * (double)n, st,
+              /* Blake2s compressions */ (double)n * ((d_prev ? 1.0 : 0.0) + (double)((ncols + 15) / 16)));
   // narrow layers (no columns or one SecureColumn): a wave walks several 64-node chunks with the next chunk's loads in flight
   // (k_merkle_narrow).  Chunks per wave: as many as still leave >= 2 waves per wave slot of the chip (256 CUs x 32 slots).
   // A/B: CM_MERKLE_NPW=0 restores k_merkle_layer for these layers, 1 / 2 / 4 / 8 force a chunk count.
@@ -163,7 +163,7 @@ void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* con
     while (npw > 1 && (n % (256u * npw)) != 0) npw >>= 1;
     const dim3 grid(n / (256u * npw));
     const bool rfc = framing().hash_node_rfc;
-#define CM_NARROW(R, P, C) hipLaunchKernelGGL((k_merkle_narrow<R, P, C>), grid, dim3(256), 0, st, d_prev, d_cols, d_out, npw)
+#define CM_NARROW(R, P, C) CM_KPROF_LAUNCH(kp, (k_merkle_narrow<R, P, C>), grid, dim3(256), 0, st, d_prev, d_cols, d_out, npw)
     if (d_prev && ncols) { if (rfc) CM_NARROW(true, true, 4); else CM_NARROW(false, true, 4); }
     else if (d_prev) { if (rfc) CM_NARROW(true, true, 0); else CM_NARROW(false, true, 0); }
     else { if (rfc) CM_NARROW(true, false, 4); else CM_NARROW(false, false, 4); }
@@ -171,8 +171,8 @@ void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* con
     CM_HIP(hipGetLastError());
     return;
   }
-  if (framing().hash_node_rfc) hipLaunchKernelGGL(k_merkle_layer<true>, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
-  else hipLaunchKernelGGL(k_merkle_layer<false>, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
+  if (framing().hash_node_rfc) CM_KPROF_LAUNCH(kp, k_merkle_layer<true>, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
+  else CM_KPROF_LAUNCH(kp, k_merkle_layer<false>, dim3((n + 255) / 256), dim3(256), 0, st, log_size, d_prev, d_cols, ncols, d_out);
   CM_HIP(hipGetLastError());
 }
 void merkle_layer_quad(uint32_t log_size, const uint32_t* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
