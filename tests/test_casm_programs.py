@@ -84,3 +84,15 @@ def test_heap_cells_at_the_top_of_the_address_space(oracle):
         assert rc == 0, (s, err)
         inp.free()
     assert seen_untouched_heap_cell
+
+
+def test_values_the_reference_states_itself():
+    """Two mdtest programs carry their result in the reference's own markdown (`//! expected: V`, mdtest/README.md:56:
+    01-basics/08-type-casts.md:46, 05-edge-cases/01-error-handling.md:25) — the only expected values in the tree that neither the
+    fixture script's evaluator nor this repository computed.  The VM must return them."""
+    stated = [f for f in FIXTURES if f.get("reference_expected") is not None]
+    assert len(stated) >= 2
+    for fx in stated:
+        inp, got = run_case(fx, fx["cases"][0])
+        inp.free()
+        assert got == [fx["reference_expected"]], (fx["name"], got)

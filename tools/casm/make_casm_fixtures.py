@@ -145,8 +145,22 @@ def call_frame_words(vals, program_length):
     return data + slots
 
 
+def stated_expectations():
+    """{entry function name: value} for the mdtest programs whose markdown states the result itself (`//! expected: V` in
+    /root/reference/mdtest/**/*.md, mdtest/README.md:56): the only expected values in the tree that nobody here computed"""
+    out = {}
+    for md in glob.glob("/root/reference/mdtest/*/*.md"):
+        for block in re.findall(r"```cairo-m\n(.*?)```", open(md).read(), re.S):
+            m = re.search(r"^//! expected: (\d+)\s*$", block, re.M)
+            f = re.search(r"^fn (\w+)\(", block, re.M)
+            if m and f:
+                out[f.group(1)] = int(m.group(1))
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    stated = stated_expectations()
     for old in glob.glob(os.path.join(OUT, "*.json")):
         os.remove(old)
     made, skipped = [], []
@@ -191,7 +205,13 @@ def main():
             why_not = "U32StoreEq* (opcodes 24 / 30): the reference's AIR cannot balance its own LogUp sum on a live row"
         elif twice is not None:
             why_not = f"instruction {twice} reads and writes one frame cell in the same step: clock - prev_clock - 1 = -1 is not in range_check_20"
+        ref_expected = None
+        if entry in stated and not params:
+            ref_expected = stated[entry]
+            if cases[0]["expected"] != [ref_expected % P31]:
+                raise SystemExit(f"{name}: the evaluator says {cases[0]['expected']}, the reference's markdown says {ref_expected}")
         fx = {"name": name, "snapshot": os.path.relpath(path, "/root/reference"), "entry": entry, "entry_pc": labels[entry],
+              "reference_expected": ref_expected,
               "n_returns": len(cases[0]["expected"]), "instructions": ins, "data": data, "cases": cases, "opcodes": opcodes,
               "provable": why_not is None, "unprovable_reason": why_not,
               "made_by": "tools/casm/make_casm_fixtures.py (listing parsed from the snapshot; expected values from tools/casm/cm_eval.py on the snapshot's source)"}
