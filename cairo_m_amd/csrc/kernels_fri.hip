@@ -490,7 +490,7 @@ void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st) {
   uint32_t n = a.n_rows ? a.n_rows : (1u << a.log_size);
   KProfScope kp("k_quotients", (4.0 * n_cols + 16.0) * (double)n, st);
   // two rows per thread with one shared denominator inversion (A/B: CM_QUOT_ROWS=1 restores the one-row kernel)
-  static const int rows = getenv("CM_QUOT_ROWS") ? atoi(getenv("CM_QUOT_ROWS")) : 2;
+  const int rows = tune(T_QUOT_ROWS);
   if (a.log_size >= 14 && rows == 2 && a.entry_cols && a.n_batches >= 1 && a.n_batches <= 2 && n % 512 == 0)
     hipLaunchKernelGGL(k_quotients_rows<2>, dim3(n / 512), dim3(256), 0, st, a);
   else if (a.log_size >= 14 && rows == 4 && a.entry_cols && a.n_batches >= 1 && a.n_batches <= 2 && n % 1024 == 0)
@@ -539,7 +539,7 @@ void fold_line_and_circle(uint32_t* const out[4], const uint32_t* const src[4], 
 // four coordinate words); true if the launch was made (the layer must be large enough for the wave-per-chunk walk)
 bool fold_line_leaf(uint32_t* const out[4], const uint32_t* const src[4], const uint32_t* const* circle, uint32_t log_n,
                     const Twiddles& tw, hipStream_t st, const uint32_t* d_alpha, const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes) {
-  static const bool on = !(getenv("CM_FRI_FOLD_LEAF") && atoi(getenv("CM_FRI_FOLD_LEAF")) == 0);   // A/B: 0 = fold, then the leaf launch
+  const bool on = tune(T_FRI_FOLD_LEAF) != 0;   // A/B: 0 = fold, then the leaf launch
   if (!on || log_n < 15 || log_n + 1 > tw.R) return false;
   const uint32_t n = 1u << (log_n - 1);
   uint32_t npw = std::min(8u, std::max(1u, n >> 20));
@@ -560,7 +560,7 @@ bool fold_line_leaf(uint32_t* const out[4], const uint32_t* const src[4], const 
 // fold_circle_into_line of ONE group of quotient columns (2^log_n circle evaluations) into a blank layer + its leaf hashes
 bool fold_circle_leaf(uint32_t* const out[4], const uint32_t* const circle[4], uint32_t log_n, const Twiddles& tw, hipStream_t st,
                       const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes) {
-  static const bool on = !(getenv("CM_FRI_FOLD_LEAF") && atoi(getenv("CM_FRI_FOLD_LEAF")) == 0);
+  const bool on = tune(T_FRI_FOLD_LEAF) != 0;
   if (!on || log_n < 15 || log_n > tw.R) return false;
   const uint32_t n = 1u << (log_n - 1);
   uint32_t npw = std::min(8u, std::max(1u, n >> 20));

@@ -157,7 +157,7 @@ void merkle_layer(uint32_t log_size, const uint32_t* d_prev, const uint32_t* con
   // narrow layers (no columns or one SecureColumn): a wave walks several 64-node chunks with the next chunk's loads in flight
   // (k_merkle_narrow).  Chunks per wave: as many as still leave >= 2 waves per wave slot of the chip (256 CUs x 32 slots).
   // A/B: CM_MERKLE_NPW=0 restores k_merkle_layer for these layers, 1 / 2 / 4 / 8 force a chunk count.
-  static const int npw_env = getenv("CM_MERKLE_NPW") ? atoi(getenv("CM_MERKLE_NPW")) : -1;
+  const int npw_env = tune(T_MERKLE_NPW);
   if (npw_env != 0 && (ncols == 0 || ncols == 4) && (d_prev || ncols) && log_size >= 14) {
     uint32_t npw = npw_env > 0 ? (uint32_t)npw_env : std::min(8u, std::max(1u, n >> 20));
     while (npw > 1 && (n % (256u * npw)) != 0) npw >>= 1;

@@ -539,7 +539,7 @@ bool fft_fused_serves(uint32_t W);
 void launch_fft_fused_rb(const FftPassArgs& inv, const FftPassArgs& fwd, uint32_t ntiles, uint32_t ncols, hipStream_t st);
 void interpolate_extend(const uint32_t* const* d_src, uint32_t* const* d_coeffs, uint32_t* const* d_lde, uint32_t ncols, uint32_t n,
                         const Twiddles& tw, hipStream_t st) {
-  static const bool fused_on = !(getenv("CM_FFT_FUSED") && atoi(getenv("CM_FFT_FUSED")) == 0);
+  const bool fused_on = tune(T_FFT_FUSED) != 0;
   CM_CHECK(n >= 1 && n + 1 <= tw.R, "interpolate_extend: log size exceeds twiddle table");
   if (ncols == 0) return;
   const uint32_t W = n > FFT_CONTIG_LOG ? n - FFT_CONTIG_LOG : 0;

@@ -188,17 +188,22 @@ void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
   s.off += need;
 }
 const TuneEntry TUNE_TABLE[T_COUNT] = {
-    {"oods_poll", "CM_OODS_POLL", 1},           {"oods_host_write", "CM_OODS_HOST_WRITE", 1}, {"stage_copy_kernel", "CM_STAGE_COPY_KERNEL", 1},
-    {"stage_lazy_events", "CM_STAGE_LAZY_EVENTS", 1}, {"defer_teardown", "CM_DEFER_TEARDOWN", 1}, {"flag_join", "CM_FLAG_JOIN", 1},
-    {"flag_fork", "CM_FLAG_FORK", 1},           {"commit_prep_early", "CM_COMMIT_PREP_EARLY", 1}, {"trace_hist_fuse", "CM_TRACE_HIST_FUSE", 1},
-    {"fri_top_fuse", "CM_FRI_TOP_FUSE", 1},     {"logup_defer", "CM_LOGUP_DEFER", 1},         {"oods_split", "CM_OODS_SPLIT", 780},
+    {"oods_poll", "CM_OODS_POLL", 1, 0, 1},           {"oods_host_write", "CM_OODS_HOST_WRITE", 1, 0, 1}, {"stage_copy_kernel", "CM_STAGE_COPY_KERNEL", 1, 0, 1},
+    {"stage_lazy_events", "CM_STAGE_LAZY_EVENTS", 1, 0, 1}, {"defer_teardown", "CM_DEFER_TEARDOWN", 1, 0, 1}, {"flag_join", "CM_FLAG_JOIN", 1, 0, 1},
+    {"flag_fork", "CM_FLAG_FORK", 1, 0, 1},           {"commit_prep_early", "CM_COMMIT_PREP_EARLY", 1, 0, 1}, {"trace_hist_fuse", "CM_TRACE_HIST_FUSE", 1, 0, 1},
+    {"fri_top_fuse", "CM_FRI_TOP_FUSE", 1, 0, 1},     {"logup_defer", "CM_LOGUP_DEFER", 1, 0, 1},         {"oods_split", "CM_OODS_SPLIT", 780, 0, 1000},
+    {"fork_main", "CM_FORK_MAIN", 1, 0, 1},           {"merkle_npw", "CM_MERKLE_NPW", -1, -1, 8},         {"fork_width", "CM_FORK_WIDTH", 0, 0, 8},
+    {"pp_side", "CM_PP_SIDE", 1, 0, 1},               {"tree0_prio", "CM_TREE0_PRIO", -1, -1, 1},         {"tree1_first", "CM_TREE1_FIRST", 1, 0, 1},
+    {"logup_width", "CM_LOGUP_WIDTH", 4, 1, 7},       {"quot_rows", "CM_QUOT_ROWS", 2, 1, 4},             {"fri_fold_leaf", "CM_FRI_FOLD_LEAF", 1, 0, 1},
+    {"fft_fused", "CM_FFT_FUSED", 1, 0, 1},           {"commit_pipe", "CM_COMMIT_PIPE", 1, 0, 1},         {"fft_chunk_mb", "CM_FFT_CHUNK_MB", 0, 0, 4096},
+    {"pace", "CM_PACE", -1, -1, 1},                   {"pace_early", "CM_PACE_EARLY", 1, 0, 1},
 };
 std::atomic<int>* tune_values() {
   static std::atomic<int>* v = [] {
     std::atomic<int>* x = new std::atomic<int>[T_COUNT];
     for (int k = 0; k < T_COUNT; k++) {
       const char* e = getenv(TUNE_TABLE[k].env);
-      x[k].store(e ? atoi(e) : TUNE_TABLE[k].dflt);
+      x[k].store(e ? std::min(std::max(atoi(e), TUNE_TABLE[k].lo), TUNE_TABLE[k].hi) : TUNE_TABLE[k].dflt);
     }
     return x;
   }();
@@ -425,8 +430,7 @@ Fork::Fork(hipStream_t main_stream) : main(main_stream) {
   } else CM_HIP(hipEventRecord(ss.fork_ev, main));
 }
 int Fork::main_or(int side_index) {
-  static const bool on = !(getenv("CM_FORK_MAIN") && atoi(getenv("CM_FORK_MAIN")) == 0);
-  return on ? MAIN : side_index;
+  return tune(T_FORK_MAIN) != 0 ? MAIN : side_index;
 }
 hipStream_t Fork::stream(int i) {
   if (i == MAIN) return main;

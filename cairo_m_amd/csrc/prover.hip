@@ -324,7 +324,7 @@ static void zero_ranges(void* const p[3], const size_t bytes[3], hipStream_t st)
 }
 // side streams a fork region spreads its large launches over (A/B: CM_FORK_WIDTH; the join costs one barrier packet per used stream)
 static int fork_width(int dflt) {
-  static const int w = getenv("CM_FORK_WIDTH") ? atoi(getenv("CM_FORK_WIDTH")) : 0;
+  const int w = tune(T_FORK_WIDTH);
   return w > 0 && w < dflt ? w : dflt;
 }
 // =========================================================================================================
@@ -499,8 +499,8 @@ struct SegmentProver {
       pp_evals.alloc(logs, st);
       // The constant columns are generated on the side stream that builds the twiddles and later commits tree 0 (the same HIP
       // stream: ordered behind one, in front of the other): nothing before the LogUp phase reads them on the main stream, which
-      // starts trace generation ~150 us earlier this way.  CM_PP_MAIN=1: on the main stream (A/B).
-      static const bool pp_side = getenv("CM_PP_MAIN") == nullptr;
+      // starts trace generation ~150 us earlier this way.  cm_set_tuning("pp_side", 0) / CM_PP_SIDE=0: on the main stream (A/B).
+      const bool pp_side = tune(T_PP_SIDE) != 0;
       hipStream_t pps = st;
       if (pp_side) {
         if (!tw_fork) tw_fork.reset(new Fork(st));   // (twiddle cache on: nothing else is on that stream yet)
@@ -594,7 +594,7 @@ struct SegmentProver {
       // of the highest priority class has hardware queues of its own.  CM_TREE0_PRIO=0: the side stream (A/B), 1: lowest class.
       // A lone proof only: with several proofs in flight (cm_prove_many) the other proofs' kernels fill the queues anyway, and
       // four high-priority chains cutting into them cost 0.5-1 ms per proof (9.6 -> 10.1-10.8 with four in flight).
-      static const int t0_prio = getenv("CM_TREE0_PRIO") ? atoi(getenv("CM_TREE0_PRIO")) : -1;
+      const int t0_prio = tune(T_TREE0_PRIO);
       if (t0_prio != 0 && g_proofs_in_flight.load(std::memory_order_relaxed) <= 1) {
         tree0_stream = thread_priority_stream(t0_prio);
         hipEvent_t e = Prover::pipe_event();
@@ -608,7 +608,7 @@ struct SegmentProver {
     P.tick("trace_gen");
     // tree 1 first: its large transforms start as soon as the trace exists and keep the GPU busy while the host issues tree 0's
     // chain of small launches (enqueued first, that chain delayed the first tree-1 kernel by the host time of ~30 launches)
-    static const bool tree1_first = getenv("CM_TREE0_FIRST") == nullptr;   // A/B switch
+    const bool tree1_first = tune(T_TREE1_FIRST) != 0;   // A/B switch
     if (build_tree0 && !tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, tree0_stream);
     P.trees[1].merkle.pace_ev = Prover::pace_event(1);
     P.commit_enqueue(P.trees[1], &tr_evals, false, st, true, false, P.pipe_stream());
@@ -696,7 +696,7 @@ struct SegmentProver {
       // each even when its event has long fired (tools/join_lab.hip: 15 us for three, 42-49 us for seven).  The ~15 LogUp kernels
       // lose nothing on five streams (interaction_gen + interaction_commit 2.66 -> 2.61 ms, profiles/r04n_ab_logup_width.txt); the
       // constraint and quotient regions do (1.0 -> 1.3 ms with four) and keep all eight.  CM_LOGUP_WIDTH: side streams used here.
-      static const int lw = getenv("CM_LOGUP_WIDTH") ? std::max(1, std::min(atoi(getenv("CM_LOGUP_WIDTH")), Fork::N - 1)) : 4;
+      const int lw = std::max(1, std::min(tune(T_LOGUP_WIDTH), Fork::N - 1));
       launch_logup_small(d_small.as<SmallLogupJob>(), (uint32_t)small_jobs.size(), small_max_log, (const uint32_t* const*)pp_evals.dev(),
                          drel.as<DevRelations>(), fk.stream(lw));   // first: latency-bound, hidden under the large kernels
       int spos = 0;
@@ -2049,8 +2049,7 @@ int32_t cm_set_tuning(const char* key, int32_t value) {
   if (!key) return cm_set_last_error("cm_set_tuning: null key");
   for (int k = 0; k < cm::T_COUNT; k++)
     if (strcmp(cm::TUNE_TABLE[k].key, key) == 0) {
-      if (k == cm::T_OODS_SPLIT) { if (value < 0 || value > 1000) return cm_set_last_error("cm_set_tuning: oods_split is per mille, 0..1000"); }
-      else value = value ? 1 : 0;
+      if (value < cm::TUNE_TABLE[k].lo || value > cm::TUNE_TABLE[k].hi) return cm_set_last_error("cm_set_tuning: value out of the key's range");
       cm::tune_values()[k].store(value);
       return 0;
     }

@@ -180,7 +180,7 @@ struct Prover {
   // `defer->late` must be final; `defer->ready` may still be null (it is read by commit_launch)
   CommitPrep commit_prepare(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true,
                             bool evals_in_place = false, hipStream_t s_tr = nullptr, const DeferredCols* defer = nullptr) {
-    static const bool pipe_on = !(getenv("CM_COMMIT_PIPE") && atoi(getenv("CM_COMMIT_PIPE")) == 0);
+    const bool pipe_on = tune(T_COMMIT_PIPE) != 0;
     if (!pipe_on || !with_merkle || s_tr == s) s_tr = nullptr;
     CommitPrep cp;
     cp.t = &t; cp.from_coeffs = from_coeffs; cp.with_merkle = with_merkle; cp.evals_in_place = evals_in_place; cp.s = s; cp.defer = defer;
@@ -297,7 +297,7 @@ struct Prover {
       // of columns whose working set (evaluations + coefficients + LDE) fits the 256 MiB L3, so every sweep after the first
       // reads what the previous one just wrote from the on-die cache instead of HBM.  CM_FFT_CHUNK_MB: working-set budget
       // (0 = whole group per sweep, the round-2 order).
-      static const uint32_t chunk_mb = getenv("CM_FFT_CHUNK_MB") ? (uint32_t)atoi(getenv("CM_FFT_CHUNK_MB")) : FFT_CHUNK_MB_DEFAULT;
+      const uint32_t chunk_mb = (uint32_t)tune(T_FFT_CHUNK_MB);
       uint32_t per = g.n;
       if (chunk_mb) {
         const uint64_t col_bytes = ((uint64_t)4 << g.log) * (from_coeffs ? 1 : 2) + ((uint64_t)4 << (g.log + cfg.log_blowup_factor));
@@ -366,8 +366,8 @@ struct Prover {
   // the next phase then sit blocked for ~0.2 ms instead of milliseconds, and the host's wake-up + launch latency (~50 us of idle
   // GPU per site with the full drain) hides behind the tree top.  CM_PACE_EARLY=0: the full drain.
   void pace(MerkleTree* tree = nullptr) {
-    static const int mode = getenv("CM_PACE") ? atoi(getenv("CM_PACE")) : -1;   // 0 = always run ahead, 1 = always drain (A/B)
-    static const bool early = !(getenv("CM_PACE_EARLY") && atoi(getenv("CM_PACE_EARLY")) == 0);
+    const int mode = tune(T_PACE);   // 0 = always run ahead, 1 = always drain (A/B)
+    const bool early = tune(T_PACE_EARLY) != 0;
     const bool drain = mode == 1 || (mode != 0 && g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);
     if (!drain) return;
     if (early && tree && tree->pace_ev && tree->pace_recorded) CM_HIP(hipEventSynchronize(tree->pace_ev));

@@ -387,7 +387,11 @@ int32_t cm_set_device_tail(int32_t on);
  *   "trace_hist_fuse" (1)    trace cells and lookup histogram of a large opcode component in one launch; 0 = two
  *   "logup_defer" (1)        the LogUp tail (claimed sums, prefix scans) on a side stream next to the first transforms; 0 = in front
  *   "fri_top_fuse" (1)       fold + transcript step inside the tree-top launch of the FRI layers <= 2^16; 0 = three launches
- * status 1 for an unknown key. */
+ * and the policy choices of earlier rounds, numeric where the environment variable was: "fork_main" (1), "merkle_npw" (-1 = by
+ * layer size, 0 = k_merkle_layer, 1..8 chunks per wave), "fork_width" (0 = all side streams), "pp_side" (1), "tree0_prio" (-1 high
+ * priority stream, 0 fork side stream, 1 low), "tree1_first" (1), "logup_width" (4), "quot_rows" (2), "fri_fold_leaf" (1),
+ * "fft_fused" (1), "commit_pipe" (1), "fft_chunk_mb" (0 = off), "pace" (-1 = by load), "pace_early" (1).
+ * status 1 for an unknown key or a value outside the key's range. */
 int32_t cm_set_tuning(const char* key, int32_t value);
 /* The node lists the device-side tail gathers by (host code, no GPU: the mirror the prover checks the device against; the CPU
  * tests compare it with a restatement of MerkleProver::decommit).  positions: the sorted, de-duplicated query positions on the

@@ -21,7 +21,8 @@ dev = be.upload_input(synth_fibonacci(a.fib_n))
 
 
 PH = {}
-DEFAULTS = [("oods_split", 780)]   # every other switch defaults to 1
+DEFAULTS = [("oods_split", 780), ("merkle_npw", -1), ("fork_width", 0), ("tree0_prio", -1), ("logup_width", 4), ("quot_rows", 2),
+            ("fft_chunk_mb", 0), ("pace", -1)]   # every other switch defaults to 1
 
 
 def block(tag=None):
