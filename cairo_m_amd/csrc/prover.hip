@@ -329,7 +329,7 @@ static int fork_width(int dflt) {
 }
 // =========================================================================================================
 // CM_HOST_TRACE=1: host-side time between marks on stderr (where the GPU sits idle waiting for the host)
-constexpr uint32_t OODS_SPLIT_DEFAULT = 780;   // per mille of the sampled values in the chunk evaluated (and hashed) first; A/B: CM_OODS_SPLIT
+// (the split of the sampled values, per mille in the chunk evaluated and hashed first: tuning key "oods_split", 780)
 struct HostTrace {
   bool on = getenv("CM_HOST_TRACE") != nullptr || getenv("CM_HOST_MARKS") != nullptr;   // MARKS: no synchronising ticks
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
