@@ -92,6 +92,9 @@ def test_values_the_reference_states_itself():
     fixture script's evaluator nor this repository computed.  The VM must return them."""
     stated = [f for f in FIXTURES if f.get("reference_expected") is not None]
     assert len(stated) >= 2
+    # 33 more have their expected values pinned by the Rust equivalent the reference's authors wrote next to the program (the
+    # fixture script evaluates it with tools/casm/rust_eval.py and stops on a disagreement with the source evaluator)
+    assert sum(1 for f in FIXTURES if (f.get("rust_equivalent_cases") or 0) >= 1) >= 30
     for fx in stated:
         inp, got = run_case(fx, fx["cases"][0])
         inp.free()

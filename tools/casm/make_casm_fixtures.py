@@ -10,6 +10,9 @@ generated for it (insta snapshot of crates/compiler/codegen/tests/mdtest_snapsho
   * evaluates the SOURCE with tools/casm/cm_eval.py — on fixed argument sets when the entry function takes parameters — to get
     the value the entry function returns, independently of the listing,
 and writes {instructions, entry_pc, cases: [{args, expected}], n_returns, opcodes, provable} — data only, no source text.
+Where the reference's mdtest markdown pairs the program with a RUST EQUIVALENT written by its authors (39 of them; the reference's
+runner compiles both and compares the outputs), tools/casm/rust_eval.py evaluates that Rust block on the same arguments and the
+script stops on any disagreement with cm_eval: `rust_equivalent_cases` = the number of argument sets that agreed.
 `data` = the memory cells the listing places behind the instructions (constant arrays, the heap cursor).  A snapshot is left out
 when it holds no listing (expected compile errors) or the evaluator does not cover its source, nothing else is filtered: in
 particular NOT on what this repository's VM returns.  `provable` is false when the program executes U32StoreEqFpFp /
@@ -25,6 +28,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from cm_eval import Fault, Interp, Ref, Unsupported, to_words  # noqa: E402
+import rust_eval  # noqa: E402
 
 SNAPS = "/root/reference/crates/compiler/codegen/tests/snapshots"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "casm")
@@ -145,6 +149,54 @@ def call_frame_words(vals, program_length):
     return data + slots
 
 
+def norm_source(src):
+    import textwrap
+    return "\n".join(l.rstrip() for l in textwrap.dedent(src).strip().splitlines())
+
+
+def value_ints(v):
+    """the integers of a cm_eval value in order (not ABI limbs): what the reference's runner turns into M31 values to compare"""
+    if v is None:
+        return []
+    t = v[0]
+    if t in ("felt", "u32"):
+        return [v[1]]
+    if t == "bool":
+        return [1 if v[1] else 0]
+    if t == "tuple":
+        return [x for it in v[1] for x in value_ints(it)]
+    if t == "struct":
+        return [x for it in v[2].values() for x in value_ints(it)]
+    raise Unsupported(f"{t} in a compared value")
+
+
+def rust_equivalent_agrees(cm_source, rs_source, entry, params, sets):
+    """-> number of argument sets on which the reference authors' Rust statement of the program (tools/casm/rust_eval.py) and
+    cm_eval give the same values as M31 (crates/runner/tests/common/mod.rs:150-165); raises SystemExit on a disagreement"""
+    ri = rust_eval.Interp(rs_source)
+    if entry not in ri.fns:
+        raise rust_eval.Unsupported(f"the Rust block has no fn {entry}")
+    n = 0
+    for vals in sets:
+        try:
+            cv = Interp(cm_source).call(entry, list(vals))
+        except Fault:
+            continue
+        rargs = []
+        for v, (_, pt) in zip(vals, ri.fns[entry][0]):
+            rargs.append(v[1] if v[0] == "bool" else [rust_eval.Int(x[1], pt[1]) for x in v[1].items] if v[0] == "array"
+                         else rust_eval.Int(v[1], pt))
+        try:
+            rv = rust_eval.Interp(rs_source).call(entry, rargs)
+        except rust_eval.Fault:
+            continue
+        a, b = [x % P31 for x in value_ints(cv)], [x % P31 for x in rust_eval.flat_ints(rv)]
+        if a != b:
+            raise SystemExit(f"{entry}{[(v[0], v[1]) for v in vals]}: cm_eval says {a}, the reference's Rust equivalent says {b}")
+        n += 1
+    return n
+
+
 def stated_expectations():
     """{entry function name: value} for the mdtest programs whose markdown states the result itself (`//! expected: V` in
     /root/reference/mdtest/**/*.md, mdtest/README.md:56): the only expected values in the tree that nobody here computed"""
@@ -161,6 +213,8 @@ def stated_expectations():
 def main():
     os.makedirs(OUT, exist_ok=True)
     stated = stated_expectations()
+    rust_of = {norm_source(c): r for _, c, r in rust_eval.mdtest_pairs()}
+    n_rust = 0
     for old in glob.glob(os.path.join(OUT, "*.json")):
         os.remove(old)
     made, skipped = [], []
@@ -205,13 +259,21 @@ def main():
             why_not = "U32StoreEq* (opcodes 24 / 30): the reference's AIR cannot balance its own LogUp sum on a live row"
         elif twice is not None:
             why_not = f"instruction {twice} reads and writes one frame cell in the same step: clock - prev_clock - 1 = -1 is not in range_check_20"
+        rust_cases = None
+        rs = rust_of.get(norm_source(source))
+        if rs is not None:
+            try:
+                rust_cases = rust_equivalent_agrees(source, rs, entry, params, arg_sets(params))
+                n_rust += 1
+            except rust_eval.Unsupported as e:
+                print(f"  rust equivalent of {name} outside the Rust evaluator's subset: {e}")
         ref_expected = None
         if entry in stated and not params:
             ref_expected = stated[entry]
             if cases[0]["expected"] != [ref_expected % P31]:
                 raise SystemExit(f"{name}: the evaluator says {cases[0]['expected']}, the reference's markdown says {ref_expected}")
         fx = {"name": name, "snapshot": os.path.relpath(path, "/root/reference"), "entry": entry, "entry_pc": labels[entry],
-              "reference_expected": ref_expected,
+              "reference_expected": ref_expected, "rust_equivalent_cases": rust_cases,
               "n_returns": len(cases[0]["expected"]), "instructions": ins, "data": data, "cases": cases, "opcodes": opcodes,
               "provable": why_not is None, "unprovable_reason": why_not,
               "made_by": "tools/casm/make_casm_fixtures.py (listing parsed from the snapshot; expected values from tools/casm/cm_eval.py on the snapshot's source)"}
@@ -219,7 +281,7 @@ def main():
             json.dump(fx, f, separators=(",", ":"))
             f.write("\n")
         made.append(name)
-    print(f"{len(made)} fixtures, {len(skipped)} snapshots left out")
+    print(f"{len(made)} fixtures, {len(skipped)} snapshots left out; {n_rust} checked against the reference's Rust equivalents")
     for n, why in skipped:
         print(f"  left out  {n}: {why}")
 
