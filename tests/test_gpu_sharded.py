@@ -140,8 +140,9 @@ def test_sharded_all_opcode_proof_equals_single_gpu_proof(backend, oracle, tmp_p
 def test_in_library_rccl_comm_world_1(backend, oracle, tmp_path, fib_n):
     """The library's own stream-ordered RCCL communicator (cm_rccl_comm_create: ncclAllGather / grouped ncclSend + ncclRecv on
     the prover's stream, no host synchronisation): the test box has ONE GPU and RCCL refuses two ranks on one device, so this
-    runs the whole sharded path — every pack, collective and unpack — through librccl with world = 1 and requires the proof to
-    equal the single-GPU one.  (Multi-rank bit-exactness is covered over gloo above; multi-rank RCCL needs a multi-GPU node.)"""
+    runs the sharded path with world = 1 — the device collectives a lone rank still issues (sub-root, histogram, coefficient
+    and sampled-value all-gathers go through ncclAllGather; the row exchange and the host-word gathers are short-cut for a rank
+    that owns everything) — and requires the proof to equal the single-GPU one.  (Multi-rank bit-exactness is covered over gloo above; multi-rank RCCL needs a multi-GPU node.)"""
     inp = synth_fibonacci(fib_n)
     p = backend.prove(inp)
     want = p.words().copy()
