@@ -7,6 +7,9 @@
 // Twiddles are computed from the group law (no shared tables with the product) and memoised per
 // (domain log size, layer) so that the many columns of one proof do not redo the same point walk.
 #pragma once
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <map>
 #include <memory>
 #include <mutex>
@@ -48,30 +51,58 @@ inline const std::vector<M31>& layer_twiddles(uint32_t n, uint32_t layer, bool i
   auto it = cache.find(key);
   if (it != cache.end()) return *it->second;
   std::unique_ptr<std::vector<M31>> t(new std::vector<M31>(compute_layer_twiddles(n, layer)));
-  if (inverse) for (auto& x : *t) x = x.inverse();
+  if (inverse) {
+    // Montgomery's trick: one field inversion per table instead of one per entry (the tables of one proof hold ~2^23 entries;
+    // per-entry inversions were 1.5 s of the first proof of a process, single-threaded under this mutex)
+    std::vector<M31>& v = *t;
+    bool any_zero = false;
+    for (auto& x : v) any_zero |= x.v == 0;
+    if (any_zero || v.size() < 2) { for (auto& x : v) x = x.inverse(); }
+    else {
+      std::vector<M31> pre(v.size());
+      M31 acc = M31(1);
+      for (size_t i = 0; i < v.size(); i++) { pre[i] = acc; acc = acc * v[i]; }
+      M31 inv = acc.inverse();
+      for (size_t i = v.size(); i-- > 0;) { const M31 x = v[i]; v[i] = inv * pre[i]; inv = inv * x; }
+    }
+  }
   return *(cache[key] = std::move(t));
 }
 
+// threads inside ONE transform: only outside a parallel region (the callers loop over columns in parallel when there are many)
+inline bool fft_inner_parallel(size_t N) {
+#ifdef _OPENMP
+  return N >= ((size_t)1 << 15) && !omp_in_parallel() && omp_get_max_threads() > 1;
+#else
+  (void)N;
+  return false;
+#endif
+}
 // values: bit-reversed evaluations on CanonicCoset(n).circle_domain(); returns coefficients.
 inline std::vector<M31> interpolate(std::vector<M31> values) {
   size_t N = values.size();
   uint32_t n = 0;
   while (((size_t)1 << n) < N) n++;
   assert(n >= 1);
+  // a lone large column (composition, preprocessed and FRI trees: 4-10 columns) is transformed by all threads, butterfly pairs of a
+  // layer split among them; inside a loop over many columns (the callers' own parallel regions) the layers stay sequential
+  const bool par = fft_inner_parallel(N);
+  M31* const v = values.data();
   for (uint32_t layer = 0; layer < n; layer++) {
-    const std::vector<M31>& tw = layer_twiddles(n, layer, true);
-    size_t stride = (size_t)1 << layer;
-    for (size_t h = 0; h < (N >> (layer + 1)); h++) {
-      for (size_t l = 0; l < stride; l++) {
-        size_t i0 = (h << (layer + 1)) + l, i1 = i0 + stride;
-        M31 a = values[i0], b = values[i1];
-        values[i0] = a + b;
-        values[i1] = (a - b) * tw[h];
-      }
+    const M31* const tw = layer_twiddles(n, layer, true).data();
+    const size_t stride = (size_t)1 << layer;
+#pragma omp parallel for schedule(static) if (par)
+    for (size_t p = 0; p < N / 2; p++) {
+      const size_t h = p >> layer, l = p & (stride - 1);
+      const size_t i0 = (h << (layer + 1)) + l, i1 = i0 + stride;
+      M31 a = v[i0], b = v[i1];
+      v[i0] = a + b;
+      v[i1] = (a - b) * tw[h];
     }
   }
-  M31 inv = M31((uint32_t)N).inverse();
-  for (auto& v : values) v = v * inv;
+  const M31 inv = M31((uint32_t)N).inverse();
+#pragma omp parallel for schedule(static) if (par)
+  for (size_t i = 0; i < N; i++) v[i] = v[i] * inv;
   return values;
 }
 
@@ -80,16 +111,18 @@ inline std::vector<M31> evaluate(const std::vector<M31>& coeffs, uint32_t n) {
   size_t N = (size_t)1 << n;
   std::vector<M31> values(N);
   for (size_t i = 0; i < coeffs.size(); i++) values[i] = coeffs[i];
+  const bool par = fft_inner_parallel(N);
+  M31* const v = values.data();
   for (int layer = (int)n - 1; layer >= 0; layer--) {
-    const std::vector<M31>& tw = layer_twiddles(n, (uint32_t)layer);
-    size_t stride = (size_t)1 << layer;
-    for (size_t h = 0; h < (N >> (layer + 1)); h++) {
-      for (size_t l = 0; l < stride; l++) {
-        size_t i0 = (h << (layer + 1)) + l, i1 = i0 + stride;
-        M31 a = values[i0], b = values[i1] * tw[h];
-        values[i0] = a + b;
-        values[i1] = a - b;
-      }
+    const M31* const tw = layer_twiddles(n, (uint32_t)layer).data();
+    const size_t stride = (size_t)1 << layer;
+#pragma omp parallel for schedule(static) if (par)
+    for (size_t p = 0; p < N / 2; p++) {
+      const size_t h = p >> layer, l = p & (stride - 1);
+      const size_t i0 = (h << (layer + 1)) + l, i1 = i0 + stride;
+      M31 a = v[i0], b = v[i1] * tw[h];
+      v[i0] = a + b;
+      v[i1] = a - b;
     }
   }
   return values;

@@ -25,6 +25,16 @@ struct CommitmentTree {
   MerkleProver merkle;
 };
 
+// a loop over columns runs in parallel when the LARGE columns alone can keep the threads busy
+inline bool columns_in_parallel(const std::vector<Col>& cols) {
+  size_t large = 0;
+  for (auto& c : cols) large += c.size() >= ((size_t)1 << 15) ? 1 : 0;
+#ifdef _OPENMP
+  return large == 0 || large >= 2 * (size_t)omp_get_max_threads();
+#else
+  return false;
+#endif
+}
 struct PcsProver {
   PcsConfig cfg;
   std::vector<CommitmentTree> trees;
@@ -33,7 +43,9 @@ struct PcsProver {
     t.polys = std::move(polys);
     t.evals.resize(t.polys.size());
     t.poly_logs.resize(t.polys.size());
-#pragma omp parallel for schedule(dynamic)
+    // few columns (preprocessed, composition): one after the other, every transform on all threads (offt.hpp); many: one per thread
+    const bool outer = columns_in_parallel(t.polys);
+#pragma omp parallel for schedule(dynamic) if (outer)
     for (size_t i = 0; i < t.polys.size(); i++) {
       t.poly_logs[i] = ilog2(t.polys[i].size());
       t.evals[i] = evaluate(t.polys[i], t.poly_logs[i] + cfg.log_blowup);
@@ -46,7 +58,8 @@ struct PcsProver {
   }
   void commit_evals(std::vector<Col>&& evals, Channel& ch) {  // TreeBuilder::extend_evals + commit
     std::vector<Col> polys(evals.size());
-#pragma omp parallel for schedule(dynamic)
+    const bool outer = columns_in_parallel(evals);
+#pragma omp parallel for schedule(dynamic) if (outer)
     for (size_t i = 0; i < evals.size(); i++) polys[i] = interpolate(std::move(evals[i]));
     commit_polys(std::move(polys), ch);
   }
