@@ -7,6 +7,7 @@
 // Twiddles are computed from the group law (no shared tables with the product) and memoised per
 // (domain log size, layer) so that the many columns of one proof do not redo the same point walk.
 #pragma once
+#include <algorithm>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -78,6 +79,14 @@ inline bool fft_inner_parallel(size_t N) {
   return false;
 #endif
 }
+// a layer of 2^20 butterflies is ~0.3 ms of work for 16 threads: larger teams spend longer forming than computing
+inline int fft_inner_threads() {
+#ifdef _OPENMP
+  return std::min(omp_get_max_threads(), 16);
+#else
+  return 1;
+#endif
+}
 // values: bit-reversed evaluations on CanonicCoset(n).circle_domain(); returns coefficients.
 inline std::vector<M31> interpolate(std::vector<M31> values) {
   size_t N = values.size();
@@ -91,7 +100,7 @@ inline std::vector<M31> interpolate(std::vector<M31> values) {
   for (uint32_t layer = 0; layer < n; layer++) {
     const M31* const tw = layer_twiddles(n, layer, true).data();
     const size_t stride = (size_t)1 << layer;
-#pragma omp parallel for schedule(static) if (par)
+#pragma omp parallel for schedule(static) if (par) num_threads(fft_inner_threads())
     for (size_t p = 0; p < N / 2; p++) {
       const size_t h = p >> layer, l = p & (stride - 1);
       const size_t i0 = (h << (layer + 1)) + l, i1 = i0 + stride;
@@ -101,7 +110,7 @@ inline std::vector<M31> interpolate(std::vector<M31> values) {
     }
   }
   const M31 inv = M31((uint32_t)N).inverse();
-#pragma omp parallel for schedule(static) if (par)
+#pragma omp parallel for schedule(static) if (par) num_threads(fft_inner_threads())
   for (size_t i = 0; i < N; i++) v[i] = v[i] * inv;
   return values;
 }
@@ -116,7 +125,7 @@ inline std::vector<M31> evaluate(const std::vector<M31>& coeffs, uint32_t n) {
   for (int layer = (int)n - 1; layer >= 0; layer--) {
     const M31* const tw = layer_twiddles(n, (uint32_t)layer).data();
     const size_t stride = (size_t)1 << layer;
-#pragma omp parallel for schedule(static) if (par)
+#pragma omp parallel for schedule(static) if (par) num_threads(fft_inner_threads())
     for (size_t p = 0; p < N / 2; p++) {
       const size_t h = p >> layer, l = p & (stride - 1);
       const size_t i0 = (h << (layer + 1)) + l, i1 = i0 + stride;
