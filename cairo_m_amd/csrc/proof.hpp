@@ -28,6 +28,34 @@ struct FriLayerProofData {
   MerkleDecommitment decommitment;
   Hash32 commitment;
 };
+// The sampled values of one column: one or two in every AIR of this prover (mask [0] or [-1, 0]).  A std::vector per column
+// meant ~1 600 heap blocks per proof, allocated during OODS sampling and freed in cm_proof_free — between two lone proofs, with
+// the GPU idle.  Two values inline; more (a foreign proof the verifier is asked about) spill into a vector.
+struct SampleVec {
+  QM31 in_[2];
+  uint32_t n_ = 0;
+  std::vector<QM31> more_;   // holds every value once there are more than two
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  const QM31* data() const { return more_.empty() ? in_ : more_.data(); }
+  QM31* data() { return more_.empty() ? in_ : more_.data(); }
+  void push_back(const QM31& v) {
+    if (more_.empty() && n_ < 2) { in_[n_++] = v; return; }
+    if (more_.empty()) more_.assign(in_, in_ + n_);
+    more_.push_back(v);
+    n_++;
+  }
+  QM31& operator[](size_t i) { return data()[i]; }
+  const QM31& operator[](size_t i) const { return data()[i]; }
+  QM31* begin() { return data(); }
+  QM31* end() { return data() + n_; }
+  const QM31* begin() const { return data(); }
+  const QM31* end() const { return data() + n_; }
+  QM31& front() { return data()[0]; }
+  QM31& back() { return data()[n_ - 1]; }
+  const QM31& front() const { return data()[0]; }
+  const QM31& back() const { return data()[n_ - 1]; }
+};
 struct ProofData {
   cm_pcs_config config;
   std::vector<uint32_t> claim_log_sizes;
@@ -35,7 +63,7 @@ struct ProofData {
   PublicData public_data;
   uint64_t interaction_pow = 0;
   std::vector<Hash32> commitments;
-  std::vector<std::vector<std::vector<QM31>>> sampled_values;
+  std::vector<std::vector<SampleVec>> sampled_values;   // [tree][column] -> values in mask order
   std::vector<MerkleDecommitment> decommitments;
   std::vector<std::vector<uint32_t>> queried_values;
   uint64_t proof_of_work = 0;
