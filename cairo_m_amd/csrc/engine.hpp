@@ -182,7 +182,7 @@ enum TuneKey { T_OODS_POLL, T_OODS_HOST_WRITE, T_STAGE_COPY_KERNEL, T_STAGE_LAZY
                T_COMMIT_PREP_EARLY, T_TRACE_HIST_FUSE, T_FRI_TOP_FUSE, T_LOGUP_DEFER, T_OODS_SPLIT,
                // policy choices of rounds 2-4 (numeric where the old environment variable was)
                T_FORK_MAIN, T_MERKLE_NPW, T_FORK_WIDTH, T_PP_SIDE, T_TREE0_PRIO, T_TREE1_FIRST, T_LOGUP_WIDTH, T_QUOT_ROWS, T_FRI_FOLD_LEAF,
-               T_FFT_FUSED, T_COMMIT_PIPE, T_FFT_CHUNK_MB, T_PACE, T_PACE_EARLY, T_COUNT };
+               T_FFT_FUSED, T_COMMIT_PIPE, T_FFT_CHUNK_MB, T_PACE, T_PACE_EARLY, T_TAIL_FLAGS, T_COUNT };
 struct TuneEntry { const char* key; const char* env; int dflt, lo, hi; };
 extern const TuneEntry TUNE_TABLE[T_COUNT];
 std::atomic<int>* tune_values();

@@ -196,7 +196,7 @@ const TuneEntry TUNE_TABLE[T_COUNT] = {
     {"pp_side", "CM_PP_SIDE", 1, 0, 1},               {"tree0_prio", "CM_TREE0_PRIO", -1, -1, 1},         {"tree1_first", "CM_TREE1_FIRST", 1, 0, 1},
     {"logup_width", "CM_LOGUP_WIDTH", 4, 1, 7},       {"quot_rows", "CM_QUOT_ROWS", 2, 1, 4},             {"fri_fold_leaf", "CM_FRI_FOLD_LEAF", 1, 0, 1},
     {"fft_fused", "CM_FFT_FUSED", 1, 0, 1},           {"commit_pipe", "CM_COMMIT_PIPE", 1, 0, 1},         {"fft_chunk_mb", "CM_FFT_CHUNK_MB", 0, 0, 4096},
-    {"pace", "CM_PACE", -1, -1, 1},                   {"pace_early", "CM_PACE_EARLY", 1, 0, 1},
+    {"pace", "CM_PACE", -1, -1, 1},                   {"pace_early", "CM_PACE_EARLY", 1, 0, 1},           {"tail_flags", "CM_TAIL_FLAGS", 1, 0, 1},
 };
 std::atomic<int>* tune_values() {
   static std::atomic<int>* v = [] {

@@ -1382,11 +1382,11 @@ struct SegmentProver {
       ht.mark("fri: early teardown");
     }
     if (dev_tail) {
-      CM_HIP(hipEventSynchronize(tail.ev_last));        // challenges, roots and the last layer are in pinned memory ...
+      tail.wait_last(st);                                // challenges, roots and the last layer are in pinned memory ...
       ht.mark("tail: last layer landed");
       fri.commit_finish(P, cfg, pf, true);               // ... replayed while the proof of work and the tables run
       ht.mark("tail: commit phase replayed");
-      CM_HIP(hipEventSynchronize(tail.ev_tables));
+      tail.wait_tables(st);
       if (tail.nonce_found()) {
         pf.proof_of_work = tail.nonce();
         ch.mix_u64(pf.proof_of_work);

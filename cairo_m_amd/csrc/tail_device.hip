@@ -69,6 +69,11 @@ __global__ void __launch_bounds__(256) k_tail_last(TailLastArgs a) {
     a.chan[8] = 0;
     a.hdr[6] = s_bad;
   }
+  // "the pinned words of this kernel have been written": the host watches this word instead of an event behind the launch (an event
+  // record is a barrier packet in front of the proof of work)
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(a.hdr + TAIL_HDR_LAST_DONE, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- K2: proof of work ---------------------------------------------------------------------------------------------------
@@ -257,6 +262,9 @@ __global__ void __launch_bounds__(1024) k_tail_tables(TailTablesArgs a) {
     a.hdr[3] = ns;
     a.hdr[4] = carry;
   }
+  __threadfence_system();   // header, positions: visible to the host before the word it watches
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(a.hdr + TAIL_HDR_TABLES_DONE, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- K4: the gathers ------------------------------------------------------------------------------------------------------

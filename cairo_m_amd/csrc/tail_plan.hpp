@@ -137,7 +137,8 @@ struct DeviceTail {
         if (!e) { CM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); thread_event_owned(e); }
       ev_last = evs[0]; ev_tables = evs[1];
     }
-    CM_HIP(hipEventRecord(ev_last, st));
+    flags = tune(T_TAIL_FLAGS) != 0;   // the host watches two header words instead of two events (A/B: cm_set_tuning("tail_flags", 0))
+    if (!flags) CM_HIP(hipEventRecord(ev_last, st));
     P.tick("fri_commit");
     tail_grind(fri.d_chan_, cfg.pow_bits, (unsigned long long*)d_nonce.p, st);
     P.tick("pow");
@@ -151,13 +152,30 @@ struct DeviceTail {
       a.tab = d_tab.u32(); a.nq_pad = nq_pad; a.hdr = hdr; a.h_positions = h_pos;
       tail_tables(a, st);
     }
-    CM_HIP(hipEventRecord(ev_tables, st));
+    if (!flags) CM_HIP(hipEventRecord(ev_tables, st));
     tail_gather(d_desc.as<TailDesc>(), d_off.u32(), d_tab.u32(), nq_pad, n_small, (uint32_t)desc.size(), nq, h_out, st);
     P.tick("decommit");
     enqueued = true;
   }
 
-  // behind ev_tables: the header and the positions are in pinned memory
+  bool flags = true;
+  // the host's two waits: a header word the kernel sets behind its pinned writes, or (flags off / the word does not come within
+  // ~2 ms of spinning) the event / the stream
+  void wait_word(uint32_t word, hipEvent_t ev, hipStream_t st) const {
+    if (flags) {
+      const volatile uint32_t* w = hdr + word;
+      for (int spin = 0; spin < 200000; spin++) {
+        if (*w == 1u) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+        __builtin_ia32_pause();
+      }
+      CM_HIP(hipStreamSynchronize(st));
+      return;
+    }
+    CM_HIP(hipEventSynchronize(ev));
+  }
+  void wait_last(hipStream_t st) const { wait_word(TAIL_HDR_LAST_DONE, ev_last, st); }
+  void wait_tables(hipStream_t st) const { wait_word(TAIL_HDR_TABLES_DONE, ev_tables, st); }
+  // behind the tables: the header and the positions are in pinned memory
   bool nonce_found() const { return hdr[0] == TAIL_OK; }
   uint64_t nonce() const { return (uint64_t)hdr[1] | ((uint64_t)hdr[2] << 32); }
 

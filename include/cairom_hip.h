@@ -382,6 +382,8 @@ int32_t cm_set_device_tail(int32_t on);
  *   "stage_lazy_events" (1)  the staging ring's event of the thread's main stream is recorded when the ring wraps; 0 = per upload
  *   "defer_teardown" (1)     the pool blocks of a proof's FRI phase / quotient plan are given back by the calling thread's NEXT
  *                            proof while it waits for tree 1 (or when the thread ends); 0 = before cm_prove* returns
+ *   "tail_flags" (1)         the host follows the device-side tail by two header words the kernels set behind their pinned writes;
+ *                            0 = two events recorded between the tail's launches
  *   "flag_join" / "flag_fork" (1)  fork regions joined / forked by flag words polled by one-wave kernels; 0 = HIP events
  *   "commit_prep_early" (1)  the interaction tree's launch plan is prepared under the LogUp kernels; 0 = behind them
  *   "trace_hist_fuse" (1)    trace cells and lookup histogram of a large opcode component in one launch; 0 = two
