@@ -127,3 +127,30 @@ def test_log_blowup_factor_above_one(oracle, cfg):
         bad[pos] ^= 1
         assert (_verify(L, bad, cfg)[0] == 0) == (oracle.verify(bad, cfg)[0] == 0)
     inp.free()
+
+
+def test_a_column_with_more_sampled_values_than_its_mask_is_rejected(oracle):
+    """The proof object keeps a column's sampled values in an inline pair (proof.hpp SampleVec: every AIR here samples one or two
+    points per column) that spills into a vector for anything longer: a foreign word stream with THREE values in a column must
+    parse (the spill path) and be refused as a structure error — by both verifiers."""
+    L = load_library()
+    inp = synth_fibonacci(7)
+    words, _ = oracle.prove(inp.view)
+    inp.free()
+    w = [int(x) for x in words]
+    i = 5                                  # magic, four config words
+    nc = w[i]; i += 1 + nc + 4 * nc        # claim: log sizes, claimed sums
+    i += 7                                 # public registers / clock / roots
+    for _ in range(3):                     # program, input, output entries (7 words each)
+        c = w[i]; i += 1 + 7 * c
+    i += 2                                 # interaction proof of work
+    nt = w[i]; i += 1 + 8 * nt             # commitments
+    assert nt == 4
+    ncol = w[i]; i += 1                    # tree 0: columns
+    assert 1 <= ncol < 64
+    ns = w[i]
+    assert ns in (1, 2)                    # the first preprocessed column's samples
+    bad = w[:i] + [3] + w[i + 1:i + 1 + 4 * ns] + [0, 0, 0, 0] * (3 - ns) + w[i + 1 + 4 * ns:]
+    rc, err = _verify(L, np.array(bad, dtype=np.uint32))
+    assert rc != 0 and "InvalidStructure" in err, (rc, err)
+    assert oracle.verify(np.array(bad, dtype=np.uint32))[0] != 0
