@@ -151,6 +151,11 @@ void at_thread_exit(std::function<void()> f);
 void* pool_get(size_t bytes);
 void pool_put(void* p);
 void pool_trim();
+// Buffers a finished proof keeps OUTSIDE the pool for a while (the deferred teardown of prover.hip) register one release function per
+// host thread here; pool_trim(), cm_shutdown(), the pool's out-of-memory retry and prove_sharded() run it first, so that "hand
+// everything back" means everything and a parked FRI phase can never be the reason an allocation fails.
+void set_thread_parked_release(std::function<void()> f);
+void release_thread_parked();
 void stage_upload(void* dst, const void* src, size_t bytes, hipStream_t st);
 
 // The HIP device cm_init() selected (one device per process: one process per GPU).  hipSetDevice is per host
@@ -182,7 +187,9 @@ enum TuneKey { T_OODS_POLL, T_OODS_HOST_WRITE, T_STAGE_COPY_KERNEL, T_STAGE_LAZY
                T_COMMIT_PREP_EARLY, T_TRACE_HIST_FUSE, T_FRI_TOP_FUSE, T_LOGUP_DEFER, T_OODS_SPLIT,
                // policy choices of rounds 2-4 (numeric where the old environment variable was)
                T_FORK_MAIN, T_MERKLE_NPW, T_FORK_WIDTH, T_PP_SIDE, T_TREE0_PRIO, T_TREE1_FIRST, T_LOGUP_WIDTH, T_QUOT_ROWS, T_FRI_FOLD_LEAF,
-               T_FFT_FUSED, T_COMMIT_PIPE, T_FFT_CHUNK_MB, T_PACE, T_PACE_EARLY, T_TAIL_FLAGS, T_COUNT };
+               T_FFT_FUSED, T_COMMIT_PIPE, T_FFT_CHUNK_MB, T_PACE, T_PACE_EARLY, T_TAIL_FLAGS,
+               // test hook: > 0 caps the device tail's proof-of-work search at 2^(value-1) nonces so that the host fallback runs
+               T_TAIL_GRIND_CAP, T_COUNT };
 struct TuneEntry { const char* key; const char* env; int dflt, lo, hi; };
 extern const TuneEntry TUNE_TABLE[T_COUNT];
 std::atomic<int>* tune_values();

@@ -143,7 +143,10 @@ int32_t cm_segment_from_artifacts(const uint8_t* trace, uint64_t trace_len, cons
   return 0;
 }
 int32_t cm_host_segment_set_initial_heap(cm_host_segment* h, const uint32_t* initial_heap, uint64_t n_initial_heap) {
+  if (!h) return cm_set_last_error("cm_host_segment_set_initial_heap: null segment");
   if (n_initial_heap && !initial_heap) return cm_set_last_error("cm_host_segment_set_initial_heap: null heap");
+  // (bounded before any arithmetic on it: 4 * n and n + n_initial_memory must not wrap)
+  if (n_initial_heap > (uint64_t)cm::host::MAX_ADDRESS + 1) return cm_set_last_error("cm_host_segment_set_initial_heap: heap larger than the address space");
   if (n_initial_heap + h->view.n_initial_memory > (uint64_t)cm::host::MAX_ADDRESS + 1) return cm_set_last_error("cm_host_segment_set_initial_heap: locals and heap overlap");
   h->heap.assign(initial_heap, initial_heap + 4 * n_initial_heap);
   h->view.initial_heap = h->heap.data(); h->view.n_initial_heap = n_initial_heap;

@@ -43,7 +43,8 @@ struct Pool {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
-      trim();
+      release_thread_parked();   // a previous proof's deferred teardown (prover.hip) goes back to the pool first ...
+      trim();                    // ... and the pool back to the driver
       e = hipMalloc(&p, want);
     }
     if (e != hipSuccess) throw CmError(2, std::string("device allocation of ") + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
@@ -127,7 +128,10 @@ void at_thread_exit(std::function<void()> f) {
 }
 void* pool_get(size_t bytes) { return pool().get(bytes); }
 void pool_put(void* p) { pool().put(p); }
-void pool_trim() { pool().trim(); }
+namespace { std::function<void()>& parked_release_fn() { static thread_local std::function<void()> f; return f; } }
+void set_thread_parked_release(std::function<void()> f) { parked_release_fn() = std::move(f); }
+void release_thread_parked() { if (parked_release_fn()) parked_release_fn()(); }
+void pool_trim() { release_thread_parked(); pool().trim(); }
 
 // The copy out of the ring as a KERNEL that reads the pinned words over PCIe: a hipMemcpyAsync of more than a few KB goes through
 // the SDMA engine, and a copy-engine command between two kernels of a compute stream costs ~10 us on either side of its 7 us
@@ -197,6 +201,7 @@ const TuneEntry TUNE_TABLE[T_COUNT] = {
     {"logup_width", "CM_LOGUP_WIDTH", 4, 1, 7},       {"quot_rows", "CM_QUOT_ROWS", 2, 1, 4},             {"fri_fold_leaf", "CM_FRI_FOLD_LEAF", 1, 0, 1},
     {"fft_fused", "CM_FFT_FUSED", 1, 0, 1},           {"commit_pipe", "CM_COMMIT_PIPE", 1, 0, 1},         {"fft_chunk_mb", "CM_FFT_CHUNK_MB", 0, 0, 4096},
     {"pace", "CM_PACE", -1, -1, 1},                   {"pace_early", "CM_PACE_EARLY", 1, 0, 1},           {"tail_flags", "CM_TAIL_FLAGS", 1, 0, 1},
+    {"tail_grind_cap", "CM_TAIL_GRIND_CAP", 0, 0, 40},
 };
 std::atomic<int>* tune_values() {
   static std::atomic<int>* v = [] {
@@ -320,7 +325,14 @@ __global__ void k_join_collect(const uint32_t* flags, uint32_t mask, uint32_t ep
 struct SideStreams {
   hipStream_t s[Fork::N];
   hipEvent_t done[Fork::N], fork_ev;
-  uint32_t* flags = nullptr;       // device: one word per side stream
+  // device: one join word per side stream, then (own 64-byte line) the fork word.  All of it is allocated and zeroed here:
+  // a fork word holding a stale value >= the thread's fork epoch would release the side streams before the main stream
+  // reaches the fork point (round-5 advice: it used to sit one word past a N-word allocation)
+  static constexpr int FORK_SLOT = 16;                       // word index of the fork flag (Fork::N <= 16)
+  static constexpr size_t FLAG_WORDS = FORK_SLOT + 16;
+  static_assert(Fork::N <= FORK_SLOT, "join words and the fork word must not overlap");
+  uint32_t* flags = nullptr;
+  uint32_t* fork_flag() const { return flags + FORK_SLOT; }
   uint32_t* timed_out = nullptr;   // pinned
   uint32_t epoch = 0, fork_epoch = 0;
   unsigned long long limit_ticks = 0;
@@ -331,10 +343,10 @@ struct SideStreams {
     }
     CM_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
     const int mem = getenv("CM_FLAG_MEM") ? atoi(getenv("CM_FLAG_MEM")) : 0;   // development: 0 device, 1 fine-grained device, 2 pinned host
-    if (mem == 2) CM_HIP(hipHostMalloc((void**)&flags, (Fork::N + 1) * 4, hipHostMallocDefault));
-    else if (mem == 1) CM_HIP(hipExtMallocWithFlags((void**)&flags, (Fork::N + 1) * 4, hipDeviceMallocFinegrained));
-    else CM_HIP(hipMalloc((void**)&flags, Fork::N * 4));
-    CM_HIP(hipMemset(flags, 0, Fork::N * 4));
+    if (mem == 2) CM_HIP(hipHostMalloc((void**)&flags, FLAG_WORDS * 4, hipHostMallocDefault));
+    else if (mem == 1) CM_HIP(hipExtMallocWithFlags((void**)&flags, FLAG_WORDS * 4, hipDeviceMallocFinegrained));
+    else CM_HIP(hipMalloc((void**)&flags, FLAG_WORDS * 4));
+    CM_HIP(hipMemset(flags, 0, FLAG_WORDS * 4));
     CM_HIP(hipDeviceSynchronize());   // (hipMemset runs on the NULL stream, the library's streams are non-blocking)
     CM_HIP(hipHostMalloc((void**)&timed_out, 64, hipHostMallocDefault));
     memset(timed_out, 0, 64);
@@ -425,7 +437,7 @@ Fork::Fork(hipStream_t main_stream) : main(main_stream) {
   SideStreams& ss = side();
   if (flag_fork_on()) {
     fork_epoch = ++ss.fork_epoch;
-    hipLaunchKernelGGL(k_join_flag, dim3(1), dim3(1), 0, main, ss.flags + N, fork_epoch);
+    hipLaunchKernelGGL(k_join_flag, dim3(1), dim3(1), 0, main, ss.fork_flag(), fork_epoch);
     CM_HIP(hipGetLastError());
   } else CM_HIP(hipEventRecord(ss.fork_ev, main));
 }
@@ -438,7 +450,7 @@ hipStream_t Fork::stream(int i) {
   SideStreams& ss = side();
   if (!(used & (1u << i))) {
     if (flag_fork_on()) {
-      hipLaunchKernelGGL(k_join_collect, dim3(1), dim3(64), 0, ss.s[i], ss.flags + N, 1u, fork_epoch, ss.limit_ticks, ss.timed_out);
+      hipLaunchKernelGGL(k_join_collect, dim3(1), dim3(64), 0, ss.s[i], ss.fork_flag(), 1u, fork_epoch, ss.limit_ticks, ss.timed_out);
       CM_HIP(hipGetLastError());
     } else CM_HIP(hipStreamWaitEvent(ss.s[i], ss.fork_ev, 0));
     used |= 1u << i;

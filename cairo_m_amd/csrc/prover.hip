@@ -445,7 +445,15 @@ struct SegmentProver {
     return out.release();
   }
   struct Parked { FriPhase fri; std::vector<QGroup> qg; std::vector<OJob> ojobs; std::vector<ColumnSet> quotients; };
-  static std::unique_ptr<Parked>& parked() { static thread_local std::unique_ptr<Parked> g; return g; }
+  static std::unique_ptr<Parked>& parked() {
+    static thread_local std::unique_ptr<Parked> g;
+    static thread_local bool hooked = false;
+    if (!hooked) {   // cm_pool_trim / cm_shutdown / the pool's out-of-memory retry / prove_sharded release it too (pool.hip)
+      hooked = true;
+      set_thread_parked_release([] { parked().reset(); });
+    }
+    return g;
+  }
   static bool defer_teardown() { return tune(T_DEFER_TEARDOWN) != 0; }
 
   // component sizes, twiddles (side stream), transcript setup (prover.rs:33-66)
@@ -2063,6 +2071,9 @@ int32_t cm_tail_list(const uint32_t* positions, uint32_t n_positions, uint32_t l
                      uint32_t* out, uint32_t cap, uint32_t* n_out) {
   return pguard([&] {
     CM_CHECK(log_domain < cm::TAIL_MAX_SHIFTS && k <= log_domain && list <= 2, "cm_tail_list: bad arguments");
+    CM_CHECK((positions || n_positions == 0) && n_out && (out || cap == 0), "cm_tail_list: null argument");
+    for (uint32_t i = 0; i < n_positions; i++)   // TailTables::build assumes sorted, de-duplicated positions inside the domain
+      CM_CHECK((positions[i] >> log_domain) == 0 && (i == 0 || positions[i - 1] < positions[i]), "cm_tail_list: positions must be strictly increasing and below 2^log_domain");
     cm::TailTables tt;
     tt.build(std::vector<uint32_t>(positions, positions + n_positions), log_domain, qmask);
     const uint32_t* v = tt.list(list, k);

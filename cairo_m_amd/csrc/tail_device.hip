@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) k_tail_grind(const uint32_t* __restrict__
     else if (h[2]) tz = 64 + __ffs(h[2]) - 1;
     else if (h[3]) tz = 96 + __ffs(h[3]) - 1;
     else tz = 128;
-    if (tz >= bits) atomicMin(result, (unsigned long long)nonce);
+    if (tz >= bits && nonce < limit) atomicMin(result, (unsigned long long)nonce);   // (limit < span only under the test cap)
   }
 }
 
@@ -313,8 +313,9 @@ void tail_last_layer(const TailLastArgs& a, hipStream_t st) {
 }
 void tail_grind(const uint32_t* d_chan, uint32_t bits, unsigned long long* d_nonce, hipStream_t st) {
   CM_CHECK(bits <= TAIL_MAX_POW_BITS, "tail_grind: pow_bits");
-  const uint64_t limit = (uint64_t)1 << std::max(bits + 4, 8u);         // 16x the expected nonce: a miss has probability e^-16
-  const uint64_t span = std::min<uint64_t>(limit, (uint64_t)1 << 17);   // 512 blocks: two per CU
+  uint64_t limit = (uint64_t)1 << std::max(bits + 4, 8u);               // 16x the expected nonce: a miss has probability e^-16
+  if (const int cap = tune(T_TAIL_GRIND_CAP)) limit = std::min<uint64_t>(limit, (uint64_t)1 << (cap - 1));   // (tests force the fallback)
+  const uint64_t span = std::min<uint64_t>(std::max<uint64_t>(limit, 256), (uint64_t)1 << 17);   // 512 blocks: two per CU
   KProfScope kp("k_tail_grind", 0.0, st);
   if (framing().mix_u64_u32s) hipLaunchKernelGGL(k_tail_grind<true>, dim3((uint32_t)(span / 256)), dim3(256), 0, st, d_chan, bits, span, limit, d_nonce);
   else hipLaunchKernelGGL(k_tail_grind<false>, dim3((uint32_t)(span / 256)), dim3(256), 0, st, d_chan, bits, span, limit, d_nonce);

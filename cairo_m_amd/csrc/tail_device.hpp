@@ -43,7 +43,7 @@ enum TailKind : uint32_t {
 constexpr uint32_t TAIL_MAX_QUERIES = 1024, TAIL_MAX_SHIFTS = 32, TAIL_MAX_LAST = 64, TAIL_MAX_POW_BITS = 26;
 constexpr uint32_t TAIL_HDR_WORDS = 16;   // pinned header: {status, nonce lo, nonce hi, n_unique, total_words, pow miss, degree error}
 constexpr uint32_t TAIL_HDR_LAST_DONE = 7, TAIL_HDR_TABLES_DONE = 8;   // header words the host watches (1 = that kernel's pinned words are written)
-enum TailStatus : uint32_t { TAIL_OK = 0, TAIL_NO_NONCE = 1, TAIL_BAD_DEGREE = 2 };
+enum TailStatus : uint32_t { TAIL_OK = 0, TAIL_NO_NONCE = 1 };   // (a degree violation of the last layer is hdr[6], read by DeviceTail::wait_last)
 
 struct TailLastArgs {
   const uint32_t* d_ar;          // {alphas | roots} of the FRI commit phase

@@ -173,7 +173,11 @@ struct DeviceTail {
     }
     CM_HIP(hipEventSynchronize(ev));
   }
-  void wait_last(hipStream_t st) const { wait_word(TAIL_HDR_LAST_DONE, ev_last, st); }
+  void wait_last(hipStream_t st) const {
+    wait_word(TAIL_HDR_LAST_DONE, ev_last, st);
+    // k_tail_last found a non-zero coefficient above the degree bound of the last layer (the host replay checks it again)
+    CM_CHECK(hdr[6] == 0, "fri: the last layer's degree exceeds the bound (device tail)");
+  }
   void wait_tables(hipStream_t st) const { wait_word(TAIL_HDR_TABLES_DONE, ev_tables, st); }
   // behind the tables: the header and the positions are in pinned memory
   bool nonce_found() const { return hdr[0] == TAIL_OK; }

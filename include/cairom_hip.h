@@ -393,6 +393,8 @@ int32_t cm_set_device_tail(int32_t on);
  * layer size, 0 = k_merkle_layer, 1..8 chunks per wave), "fork_width" (0 = all side streams), "pp_side" (1), "tree0_prio" (-1 high
  * priority stream, 0 fork side stream, 1 low), "tree1_first" (1), "logup_width" (4), "quot_rows" (2), "fri_fold_leaf" (1),
  * "fft_fused" (1), "commit_pipe" (1), "fft_chunk_mb" (0 = off), "pace" (-1 = by load), "pace_early" (1).
+ * Test hook: "tail_grind_cap" (0 = off; v > 0 stops the device tail's proof-of-work search after 2^(v-1) nonces, so that the
+ * host-driven fallback behind a missed nonce — probability e^-16 in production — can be exercised; same proof bytes).
  * status 1 for an unknown key or a value outside the key's range.  Flip a switch only while no proof is running in the process: a
  * proof reads some of them more than once (a fork region decides at its fork AND at every side stream how it synchronises). */
 int32_t cm_set_tuning(const char* key, int32_t value);

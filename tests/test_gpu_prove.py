@@ -465,3 +465,56 @@ def test_device_tail_equals_host_walk(backend, oracle, cfg):
         backend.set_device_tail(True)
         for inp in inputs:
             inp.free()
+
+
+@pytest.mark.parametrize("cfg", [None, (10, 1, 2, 37), (18, 1, 1, 64)])
+def test_device_tail_missed_nonce_falls_back_to_the_host_search(backend, oracle, cfg):
+    """The device tail searches 16x the expected nonce range; behind a miss (probability e^-16) the prover discards the tail's
+    decommitment and continues with the host-driven proof of work and walk — after the early teardown has already released the
+    trace-domain evaluations and coefficient columns.  The test hook "tail_grind_cap" = 1 stops the device search after ONE nonce
+    so that this path runs: the words must equal the normal form's and the oracle's (round-5 advice: never exercised before)."""
+    import ctypes as C
+    inputs = [synth_fibonacci(7), synth_fibonacci(3000)]
+    L = backend.L
+    try:
+        for inp in inputs:
+            assert L.cm_set_tuning(b"tail_grind_cap", C.c_int32(0)) == 0
+            p_ok = backend.prove(inp, cfg=cfg)
+            assert L.cm_set_tuning(b"tail_grind_cap", C.c_int32(1)) == 0
+            p_fb = backend.prove(inp, cfg=cfg)
+            p_fb2 = backend.prove(inp, cfg=cfg)   # and once more: the fallback leaves the thread's parked buffers / pool usable
+            a, b, c = p_ok.words(), p_fb.words(), p_fb2.words()
+            assert a.size == b.size == c.size and np.array_equal(a, b) and np.array_equal(a, c)
+            want, _ = oracle.prove(inp.view, cfg=cfg) if cfg else oracle.prove(inp.view)
+            assert want.size == b.size and np.array_equal(b, want)
+            assert (p_fb.verify(cfg) if cfg else p_fb.verify())[0] == 0
+            for p in (p_ok, p_fb, p_fb2):
+                p.free()
+    finally:
+        L.cm_set_tuning(b"tail_grind_cap", C.c_int32(0))
+        for inp in inputs:
+            inp.free()
+
+
+def test_pool_trim_releases_parked_teardown(backend):
+    """cm_pool_trim hands back EVERYTHING the calling thread holds: the pool's cached blocks and the FRI phase / quotient columns a
+    finished proof parks for its successor (defer_teardown).  Free device memory after prove + trim returns to (within one
+    allocation granule of) what it was before the proof."""
+    import ctypes as C
+    L = backend.L
+    inp = synth_fibonacci(20000)
+    try:
+        backend.prove(inp).free()
+        assert L.cm_pool_trim() == 0
+        f0, t0 = C.c_uint64(0), C.c_uint64(0)
+        assert L.cm_device_mem_info(C.byref(f0), C.byref(t0)) == 0
+        backend.prove(inp).free()
+        f1 = C.c_uint64(0)
+        assert L.cm_device_mem_info(C.byref(f1), C.byref(t0)) == 0
+        assert f1.value < f0.value, "a finished proof keeps pool blocks cached"
+        assert L.cm_pool_trim() == 0
+        f2 = C.c_uint64(0)
+        assert L.cm_device_mem_info(C.byref(f2), C.byref(t0)) == 0
+        assert f2.value + (8 << 20) >= f0.value, (f0.value, f1.value, f2.value)
+    finally:
+        inp.free()

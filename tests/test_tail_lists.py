@@ -131,3 +131,22 @@ def test_first_fri_tree_walk_from_the_lists():
         for l in sizes:   # witness evaluations of the quotient columns of 2^l rows
             q = fold(S, L0 - l)
             assert tail_list(L, S, L0, qmask, 1, L0 - l) == [p for p in pairs(q) if p not in set(q)]
+
+
+def test_tail_list_refuses_bad_arguments():
+    """cm_tail_list checks what TailTables::build assumes: non-null pointers, positions strictly increasing and inside the domain."""
+    L = load_library()
+    out = np.zeros(64, dtype=np.uint32)
+    n = C.c_uint32(0)
+
+    def call(S, log_domain=6, out_p=out.ctypes.data_as(C.c_void_p), n_p=None, null_pos=False):
+        pos = np.ascontiguousarray(np.array(S, dtype=np.uint32))
+        return L.cm_tail_list(None if null_pos else pos.ctypes.data_as(C.c_void_p), C.c_uint32(len(S)), C.c_uint32(log_domain), C.c_uint32(0),
+                              C.c_uint32(1), C.c_uint32(1), out_p, C.c_uint32(64), C.byref(n) if n_p is None else n_p)
+    assert call([1, 5, 9]) == 0
+    assert call([5, 1, 9]) != 0          # not sorted
+    assert call([1, 5, 5]) != 0          # duplicate
+    assert call([1, 5, 64]) != 0         # outside 2^6
+    assert call([1, 5, 9], null_pos=True) != 0
+    assert call([1, 5, 9], out_p=None) != 0
+    assert call([1, 5, 9], n_p=C.c_void_p(0)) != 0
