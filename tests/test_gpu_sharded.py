@@ -178,3 +178,57 @@ def test_failing_rank_calls_the_communicator_abort(backend):
     backend.col_free(send)
     backend.col_free(recv)
     inp.free()
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("world,fib_n,comm", [(2, 50, "rccl"), (2, 419_000, "rccl"), (2, 419_000, "torch"), (4, 30_000, "rccl"),
+                                               (8, 419_000, "rccl")])
+def test_multi_gpu_rccl_proof_equals_single_gpu_proof(backend, oracle, tmp_path, world, fib_n, comm):
+    """Switches itself on where the box has `world` GPUs (the round's test boxes have one: skipped there).  One process per GPU
+    (LOCAL_RANK = device), backend nccl = RCCL over xGMI: the library's own stream-ordered communicator (cm_rccl_comm_create —
+    ncclAllGather and the grouped ncclSend / ncclRecv row exchange of comm_rccl.hip get real peers here for the first time) or the
+    torch.distributed callbacks, proving the metric config as ONE sharded proof.  Every rank's words must equal the single-GPU
+    proof's; --check-single makes each rank also compare against its own single-GPU proof.  This is the first thing to run on a
+    multi-GPU node, before `bench.py --gpus N`."""
+    if _gpus() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {_gpus()}")
+    inp = synth_fibonacci(fib_n)
+    p = backend.prove(inp)
+    want = p.words().copy()
+    p.free()
+    out = str(tmp_path / "proof")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "cairo_m_amd.sharded", "--fib-n", str(fib_n), "--dist-backend", "nccl",
+           "--comm", comm, "--steps", "1", "--check-single", "--json", "--out", out]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["world"] == world and line["bit_identical_to_single_gpu_proof"] is True, line
+    for k in range(world):
+        got = np.load(f"{out}.{k}.npy")
+        assert got.size == want.size and np.array_equal(got, want), f"rank {k} differs from the single-GPU proof"
+    assert oracle.verify(want)[0] == 0
+    inp.free()
+
+
+def test_bench_multi_gpu_replicas_line(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU, RCCL barrier + max over ranks):
+    runs only where the box has two GPUs; the line must report n_gpus = 2, weak scaling and about twice one GPU's cells per proof
+    batch (every rank proves its own segment replica)."""
+    if _gpus() < 2:
+        pytest.skip(f"needs 2 GPUs, this box has {_gpus()}")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline"]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
