@@ -68,8 +68,18 @@ def traced_idle():
         return None
     try:
         import re
-        m = re.match(r"span ([\d.]+) ms\s+busy ([\d.]+) ms\s+idle ([\d.]+) ms", open(f).readline())
-        return {"span_ms": float(m.group(1)), "busy_ms": float(m.group(2)), "idle_ms": float(m.group(3)), "source": os.path.relpath(f, ROOT)}
+        lines = open(f).read().splitlines()
+        m = re.match(r"span ([\d.]+) ms\s+busy ([\d.]+) ms\s+idle ([\d.]+) ms", lines[0])
+        out = {"span_ms": float(m.group(1)), "busy_ms": float(m.group(2)), "idle_ms": float(m.group(3)), "source": os.path.relpath(f, ROOT)}
+        # (round 6) the same timeline with the fork / join spin-wait kernels — and the staging copies — not counted as work
+        m2 = re.match(r"without the fork/join spin-wait kernels \((\d+) launches, ([\d.]+) ms summed\): busy ([\d.]+) ms\s+idle ([\d.]+) ms;"
+                      r"\s+without the staging copies too: busy ([\d.]+) ms\s+idle ([\d.]+) ms", lines[1]) if len(lines) > 1 else None
+        if m2:
+            out.update({"spin_wait_launches": int(m2.group(1)), "spin_wait_kernel_ms": float(m2.group(2)),
+                        "idle_ms_without_spin_wait_kernels": float(m2.group(4)), "idle_ms_without_spin_wait_and_staging": float(m2.group(6)),
+                        "note": "idle_ms counts every dispatch as busy, including the one-wave kernels that only poll a fork / join flag; "
+                                "the two other figures leave those (and the staging copies) out"})
+        return out
     except (OSError, AttributeError, ValueError):
         return None
 
@@ -83,6 +93,40 @@ def latest_profile(suffix):
         return None
     f = os.path.join(ROOT, "profiles", f"{tag}_{suffix}")
     return f if os.path.exists(f) else None
+
+
+def valu_model(ms_per_step):
+    """Whole-path VALU roofline (round 6): the time the SIMDs' vector ALU ports need AT LEAST for the instructions one proof issues.
+    Per kernel class: SQ_INSTS_VALU (wave-instructions per proof, PMC pass of the measurement set profiles/LATEST names) x the mean
+    issue cost of that class's instruction mix (profiles/<tag>_valu_mix.json: static ISA of the class's kernels in three buckets priced
+    by the single-opcode lab profiles/r03k_valu_lab.txt) / 1024 SIMDs.  floor_ms = sum over classes; frac = floor_ms / ms_per_step.
+    Everything is recomputable from the two committed files; nothing here is measured in this run except ms_per_step."""
+    fsq, fmix = latest_profile("pmc_sq.json"), latest_profile("valu_mix.json")
+    if not fsq or not fmix:
+        return None
+    try:
+        sq, mix = json.load(open(fsq))["classes"], json.load(open(fmix))
+    except (OSError, ValueError, KeyError):
+        return None
+    stages, total_ns, total_insts = [], 0.0, 0.0
+    for k, c in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0.0)):
+        n = c.get("SQ_INSTS_VALU", 0.0)
+        if not n or not k:
+            continue
+        m = mix["classes"].get(k)
+        ns = (m or {}).get("mean_ns_per_wave_instruction", mix["default_mean_ns_per_wave_instruction"])
+        t = n * ns / 1024.0
+        total_ns += t
+        total_insts += n
+        if n >= 2e6:
+            stages.append({"class": k, "valu_wave_insts": n, "mean_ns_per_wave_inst": ns, "mix": "own" if m else "default", "floor_ms": t * 1e-6,
+                           "valu_active_x_waves": c.get("valu_insts_per_wave_quadcycle"), "wait_frac": c.get("wait_frac")})
+    return {"unit": "ms per proof", "floor_ms": total_ns * 1e-6, "frac": total_ns * 1e-6 / ms_per_step, "valu_wave_insts_per_proof": total_insts,
+            "simds": 1024, "stages": stages, "sources": [os.path.relpath(fsq, ROOT), os.path.relpath(fmix, ROOT), "profiles/r03k_valu_lab.txt"],
+            "note": "lower bound of the proof time if every SIMD issued VALU instructions back to back at the lab's single-opcode rates and "
+                    "nothing else cost anything; `frac` is the share of the measured proof time that bound explains (the HBM fractions stay "
+                    "in `frac`, `stages`, `whole_path_model`).  The Blake2s and butterfly kernels cannot reach the single-opcode rates in a "
+                    "mixed stream (register-only compression loop: 0.84 of them, profiles/r03w_chain_lab.txt), so 1.0 is not attainable."}
 
 
 # SURVEY §8d: algorithmic bytes per committed trace cell of every stage (each stage streams its input once and writes its output
@@ -577,6 +621,7 @@ def main():
                         "whole_path_model": {"bytes_per_cell": MODEL_BYTES_PER_CELL,
                                              "achieved_GBs": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9,
                                              "frac": MODEL_BYTES_PER_CELL * cells / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "valu_model": valu_model(ms_per_step),
                         "whole_path_model_larger_sizes": big_legs or None,
                         "stages": stage_roofline(kprof_all, n_prof, cells),
                         "stages_note": "SURVEY §8d per-stage check: bytes per cell x committed cells / summed HIP-event intervals of the "

@@ -189,7 +189,9 @@ enum TuneKey { T_OODS_POLL, T_OODS_HOST_WRITE, T_STAGE_COPY_KERNEL, T_STAGE_LAZY
                T_FORK_MAIN, T_MERKLE_NPW, T_FORK_WIDTH, T_PP_SIDE, T_TREE0_PRIO, T_TREE1_FIRST, T_LOGUP_WIDTH, T_QUOT_ROWS, T_FRI_FOLD_LEAF,
                T_FFT_FUSED, T_COMMIT_PIPE, T_FFT_CHUNK_MB, T_PACE, T_PACE_EARLY, T_TAIL_FLAGS,
                // test hook: > 0 caps the device tail's proof-of-work search at 2^(value-1) nonces so that the host fallback runs
-               T_TAIL_GRIND_CAP, T_COUNT };
+               T_TAIL_GRIND_CAP,
+               // round 6: launch order inside the fork regions
+               T_CONS_WIDE_FIRST, T_LOGUP_SMALL_STREAM, T_CONS_PLAN, T_COUNT };
 struct TuneEntry { const char* key; const char* env; int dflt, lo, hi; };
 extern const TuneEntry TUNE_TABLE[T_COUNT];
 std::atomic<int>* tune_values();

@@ -234,9 +234,9 @@ __global__ void __launch_bounds__(1 << (TL - E)) k_fft_pass_rb(FftPassArgs a) {
 // changed nothing, profiles/r04*).  `inv` is the pass [12, n) of the inverse transform (in place on the coefficient columns),
 // `fwd` the pass [12, n) of the 2^(n+1) forward transform with dst = the extended columns (src unused).
 struct FftFusedArgs { FftPassArgs inv, fwd; };
-template <int W>
-__global__ void __launch_bounds__(1024) k_fft_fused_rb(FftFusedArgs a) {
-  constexpr int TL = 14, E = 4;
+template <int W, int E = 4>
+__global__ void __launch_bounds__(1 << (14 - E)) k_fft_fused_rb(FftFusedArgs a) {
+  constexpr int TL = 14;
   extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
   M31 v[1 << E], cf[1 << E];
   fft_pass_rb_body<true, W, TL, E, false>(a.inv, a.inv.src[blockIdx.y], a.inv.dst[blockIdx.y], blockIdx.x, v, tile);
@@ -249,12 +249,12 @@ __global__ void __launch_bounds__(1024) k_fft_fused_rb(FftFusedArgs a) {
   for (uint32_t e = 0; e < (1u << E); e++) v[e] = cf[e];
   fft_pass_rb_body<false, W, TL, E, true>(a.fwd, nullptr, lde, (1u << half_shift) | blockIdx.x, v, tile);
 }
-template <int W>
+template <int W, int E = 4>
 static void launch_fused_one(const FftFusedArgs& a, uint32_t ntiles, uint32_t ncols, hipStream_t st) {
   constexpr size_t lds = ((size_t)4 << 14) + ((size_t)4 << 9);
-  static const hipError_t once = hipFuncSetAttribute((const void*)k_fft_fused_rb<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const hipError_t once = hipFuncSetAttribute((const void*)k_fft_fused_rb<W, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)once;
-  hipLaunchKernelGGL((k_fft_fused_rb<W>), dim3(ntiles, ncols), dim3(1024), lds, st, a);
+  hipLaunchKernelGGL((k_fft_fused_rb<W, E>), dim3(ntiles, ncols), dim3(1u << (14 - E)), lds, st, a);
 }
 bool fft_fused_serves(uint32_t W) { return W >= 6 && W <= 9; }
 void launch_fft_fused_rb(const FftPassArgs& inv, const FftPassArgs& fwd, uint32_t ntiles, uint32_t ncols, hipStream_t st) {

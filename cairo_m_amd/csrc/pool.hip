@@ -202,6 +202,8 @@ const TuneEntry TUNE_TABLE[T_COUNT] = {
     {"fft_fused", "CM_FFT_FUSED", 1, 0, 1},           {"commit_pipe", "CM_COMMIT_PIPE", 1, 0, 1},         {"fft_chunk_mb", "CM_FFT_CHUNK_MB", 0, 0, 4096},
     {"pace", "CM_PACE", -1, -1, 1},                   {"pace_early", "CM_PACE_EARLY", 1, 0, 1},           {"tail_flags", "CM_TAIL_FLAGS", 1, 0, 1},
     {"tail_grind_cap", "CM_TAIL_GRIND_CAP", 0, 0, 40},
+    {"cons_wide_first", "CM_CONS_WIDE_FIRST", 1, 0, 1}, {"logup_small_stream", "CM_LOGUP_SMALL_STREAM", -1, -1, 7},
+    {"cons_plan", "CM_CONS_PLAN", 01237456, 0, 077777777},
 };
 std::atomic<int>* tune_values() {
   static std::atomic<int>* v = [] {

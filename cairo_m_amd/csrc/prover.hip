@@ -619,8 +619,14 @@ struct SegmentProver {
     const bool tree1_first = tune(T_TREE1_FIRST) != 0;   // A/B switch
     if (build_tree0 && !tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, tree0_stream);
     P.trees[1].merkle.pace_ev = Prover::pace_event(1);
-    P.commit_enqueue(P.trees[1], &tr_evals, false, st, true, false, P.pipe_stream());
+    {
+      Prover::CommitPrep cp1 = P.commit_prepare(P.trees[1], &tr_evals, false, st, true, false, P.pipe_stream());
+      ht.mark("trace_commit: tree 1 prepared");
+      P.commit_launch(cp1);
+      ht.mark("trace_commit: tree 1 launched");
+    }
     if (build_tree0 && tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, tree0_stream);
+    ht.mark("trace_commit: tree 0 enqueued");
     // Root 0 first (transcript order, prover.rs:70-82: root 0, claim, root 1): tree 0 has been running on its side stream next
     // to all of the above; its root is copied on THAT stream and waited for here, while the GPU is still busy with tree 1.
     if (build_tree0) {
@@ -633,6 +639,7 @@ struct SegmentProver {
       else CM_HIP(hipStreamWaitEvent(st, ev_root0, 0));   // what follows on the main stream reads tree 0's LDE
       tree0_guard.joined = true;
       CM_HIP(hipEventSynchronize(ev_root0));
+      ht.mark("trace_commit: root 0 arrived");
       memcpy(P.trees[0].root.data(), pinned_words() + PIN_ROOT0, 32);
       ch.mix_root(P.trees[0].root);
     }
@@ -705,8 +712,12 @@ struct SegmentProver {
       // lose nothing on five streams (interaction_gen + interaction_commit 2.66 -> 2.61 ms, profiles/r04n_ab_logup_width.txt); the
       // constraint and quotient regions do (1.0 -> 1.3 ms with four) and keep all eight.  CM_LOGUP_WIDTH: side streams used here.
       const int lw = std::max(1, std::min(tune(T_LOGUP_WIDTH), Fork::N - 1));
+      // (which side stream: the streams share a few hardware queues and a queue runs its packets in order — on the stream that
+      // shares the MAIN stream's queue this ~90 us latency-bound launch sat in front of the region's largest kernel, round-5
+      // timeline.  "logup_small_stream" >= 0 picks the stream, -1 = stream `lw`.)
+      const int lss = tune(T_LOGUP_SMALL_STREAM);
       launch_logup_small(d_small.as<SmallLogupJob>(), (uint32_t)small_jobs.size(), small_max_log, (const uint32_t* const*)pp_evals.dev(),
-                         drel.as<DevRelations>(), fk.stream(lw));   // first: latency-bound, hidden under the large kernels
+                         drel.as<DevRelations>(), fk.stream(lss >= 0 ? lss : lw));   // first: latency-bound, hidden under the large kernels
       int spos = 0;
       for (int pos = 0; pos < air::N_COMPONENTS; pos++) {   // large components first (see trace generation)
         const int c = by_size_all[pos];
@@ -952,30 +963,41 @@ struct SegmentProver {
       P.pace(&P.trees[2].merkle);
       KProfRegion kreg("k_constraints(region)", st);
       Fork fk(st);
-      // side-stream plan of the region (A/B: CM_CSTREAMS="g0,g1,g2,g3,small,slot0,slot1,slot2" = stream index of the size
+      // side-stream plan of the region (A/B: tuning key "cons_plan" = g0,g1,g2,g3,small,slot0,slot1,slot2 = stream index of the size
       // groups in descending size, of the batched small components and of the slotted ones)
-      static const std::vector<int> cplan = [] {
-        std::vector<int> v = {0, 1, 2, 3, 7, 4, 5, 6};
-        if (const char* e = getenv("CM_CSTREAMS")) {
-          std::vector<int> w;
-          for (const char* p = e; *p;) { w.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
-          if (w.size() == 8) v = w;
-        }
-        return v;
-      }();
+      // ("cons_plan": eight octal digits, default 01237456 = streams {0,1,2,3 | 7 | 4,5,6})
+      std::vector<int> cplan(8);
+      {
+        const int code = tune(T_CONS_PLAN);
+        for (int k = 0; k < 8; k++) cplan[k] = (code >> (3 * (7 - k))) & 7;
+      }
       launch_constraints_small(d_small_args, d_small_cids, (uint32_t)small_args.size(), small_max_log,
                                fk.stream(cplan[4]));   // first: latency-bound, hidden under the large kernels
+      ht.mark("constraints: small batch launched");
       int gi = 0, small_rr = 0;
       static const bool early_interp = getenv("CM_NO_EARLY_ACC_INTERP") == nullptr;   // A/B switch
+      // A WIDE component of few rows (poseidon2: 443 columns, 426 constraints on 2^10 evaluation rows) is one long program per row
+      // on four blocks: ~0.33 ms of pure latency.  In size order it was enqueued last and ran ALONE behind the large kernels
+      // (round-5 timeline: 5570 -> 5905 us of a region that the large groups had left at ~5720).  Launched first it hides under
+      // them.  "cons_wide_first" = 0: the plain size order (A/B).
+      const bool wide_first = tune(T_CONS_WIDE_FIRST) != 0;
+      auto is_wide = [&](int c) { return wide_first && air::component_info(c).n_trace >= 128 && clog[c] <= 14; };
+      std::vector<hipStream_t> cstream(air::N_COMPONENTS, nullptr);
+      for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it, ++gi)
+        for (int c : it->second) {
+          if (std::find(small_cids.begin(), small_cids.end(), c) != small_cids.end()) continue;
+          // the components of a size group share its accumulator: one stream for all of them; slotted ones are independent
+          cstream[c] = slot_of[c] >= 0 ? fk.stream(cplan[5 + (small_rr++ % 3)]) : fk.stream(gi == 0 ? Fork::main_or(cplan[0]) : cplan[gi % 4]);
+          if (is_wide(c)) launch_constraints(c, cargs[c], cstream[c]);
+        }
+      gi = 0;
       // large groups first (descending size) so the long kernels start early
       for (auto it = cgroups.rbegin(); it != cgroups.rend(); ++it, ++gi) {
         bool one_stream = true;   // every component of the group ran on the group's stream (no slots, no batched small ones)
         for (int c : it->second) {
           if (std::find(small_cids.begin(), small_cids.end(), c) != small_cids.end()) { one_stream = false; continue; }
-          // the components of a size group share its accumulator: one stream for all of them; slotted ones are independent
-          hipStream_t sc = slot_of[c] >= 0 ? fk.stream(cplan[5 + (small_rr++ % 3)]) : fk.stream(gi == 0 ? Fork::main_or(cplan[0]) : cplan[gi % 4]);
           if (slot_of[c] >= 0) one_stream = false;
-          launch_constraints(c, cargs[c], sc);
+          if (!is_wide(c)) launch_constraints(c, cargs[c], cstream[c]);
         }
         // DomainEvaluationAccumulator::finalize starts here for such a group: its accumulator is interpolated on the same
         // stream right behind its constraint kernels — no second fork/join region for the large accumulators
@@ -983,6 +1005,7 @@ struct SegmentProver {
           interpolate(accs.at(it->first).dev(), 4, it->first, *P.tw, fk.stream(gi == 0 ? Fork::main_or(cplan[0]) : cplan[gi % 4]));
           acc_interpolated.insert(it->first);
         }
+        ht.mark("constraints: size group launched");
       }
       fk.join();
       kreg.close();

@@ -22,7 +22,7 @@ dev = be.upload_input(synth_fibonacci(a.fib_n))
 
 PH = {}
 DEFAULTS = [("oods_split", 780), ("merkle_npw", -1), ("fork_width", 0), ("tree0_prio", -1), ("logup_width", 4), ("quot_rows", 2),
-            ("fft_chunk_mb", 0), ("pace", -1)]   # every other switch defaults to 1
+            ("fft_chunk_mb", 0), ("pace", -1), ("cons_plan", 0o01237456), ("logup_small_stream", -1), ("tail_grind_cap", 0)]   # every other switch defaults to 1
 
 
 def block(tag=None):
@@ -48,7 +48,7 @@ for _ in range(2):
     block()
 for spec in a.keys:
     key, _, vals = spec.partition("=")
-    von, voff = (int(x) for x in vals.split(",")) if vals else (1, 0)
+    von, voff = (int(x, 0) for x in vals.split(",")) if vals else (1, 0)
     on, off = [], []
     for r in range(a.reps):
         order = (1, 0) if r % 2 == 0 else (0, 1)

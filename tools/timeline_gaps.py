@@ -7,7 +7,9 @@ import csv, re, sys
 k, m = sys.argv[1], sys.argv[2]
 ev = []
 for r in csv.DictReader(open(k)):
-    n = re.sub(r'\(.*', '', r['Kernel_Name']).replace('cm::', '').replace('void ', '')[:44]
+    # (anonymous-namespace kernels — k_join_flag / k_join_collect of pool.hip — keep their names: stripping at the first "(" used to
+    # leave them empty, and the listing showed them as unnamed work)
+    n = re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', '')).replace('cm::', '').replace('void ', '')[:44]
     ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), n, r['Queue_Id'], r['Grid_Size_X']))
 for r in csv.DictReader(open(m)):
     ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r['Direction'][12:], '-', ''))
@@ -28,17 +30,32 @@ g = int(os.environ.get("GRINDS_PER_PROOF", "1"))   # 2 for library builds older 
 i0, i1 = proof_start(gi[-(2 * g + 1)]), proof_start(gi[-(g + 1)])
 sub = ev[i0:i1]
 t0 = sub[0][0]
-cur, busy, gaps, prev = t0, 0, [], None
-for s, e, n, q, g in sub:
-    if s > cur:
-        gaps.append((s - cur, (cur - t0) / 1e3, prev, n))
-        busy += e - s
-        cur = e
-    elif e > cur:
-        busy += e - cur
-        cur = e
-    prev = n
-print(f"span {(cur - t0) / 1e6:.3f} ms  busy {busy / 1e6:.3f} ms  idle {(cur - t0 - busy) / 1e6:.3f} ms  events {len(sub)}")
+def cover(events):
+    """union of the intervals: (end of the last one, busy time, gaps)"""
+    cur, busy, gaps, prev = t0, 0, [], None
+    for s, e, n, q, g in events:
+        if s > cur:
+            gaps.append((s - cur, (cur - t0) / 1e3, prev, n))
+            busy += e - s
+            cur = e
+        elif e > cur:
+            busy += e - cur
+            cur = e
+        prev = n
+    return cur, busy, gaps
+# Three readings of "busy": every dispatch and copy; without the fork / join spin-wait kernels (a k_join_collect lane POLLS a flag
+# word until another stream's work is done: the GPU is waiting, not working); and without the staging copies as well
+SPIN = ('k_join_flag', 'k_join_collect')
+STAGE = ('k_stage_copy', 'COPY', 'copyBuffer', 'fillBuffer')
+end_all, busy_all, gaps = cover(sub)
+work = [x for x in sub if x[2] not in SPIN]
+_, busy_work, gaps_work = cover(work)
+_, busy_kern, _ = cover([x for x in work if not any(t in x[2] for t in STAGE)])
+span = end_all - t0
+print(f"span {span / 1e6:.3f} ms  busy {busy_all / 1e6:.3f} ms  idle {(span - busy_all) / 1e6:.3f} ms  events {len(sub)}")
+print(f"without the fork/join spin-wait kernels ({sum(1 for x in sub if x[2] in SPIN)} launches, {sum(x[1] - x[0] for x in sub if x[2] in SPIN) / 1e6:.3f} ms summed): "
+      f"busy {busy_work / 1e6:.3f} ms  idle {(span - busy_work) / 1e6:.3f} ms;  without the staging copies too: busy {busy_kern / 1e6:.3f} ms  idle {(span - busy_kern) / 1e6:.3f} ms")
+gaps = gaps_work
 for g in sorted(gaps, reverse=True)[:25]:
     print(f"gap {g[0] / 1e3:8.1f} us at {g[1]:9.1f} us  after {g[2]}  before {g[3]}")
 if '--list' in sys.argv:
