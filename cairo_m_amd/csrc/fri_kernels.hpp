@@ -39,8 +39,13 @@ struct QuotientArgs {
   // row-sharded launch (intra-proof multi-GPU): this rank computes rows [row0, row0 + n_rows) of the 2^log_size domain;
   // `cols` / `out` then point at the rank's row SLICES (index 0 = row0).  n_rows = 0: the whole domain.
   uint32_t row0 = 0, n_rows = 0;
+  // (round 6) the largest size group of a single-GPU proof: the FRI first-layer tree's LEAF layer (hash of the row's four
+  // coordinate words, Stwo MerkleOps::commit_on_layer with no children) is written by the quotient kernel itself, 32 B per row
+  // — the row's value is hashed in the registers it was computed in, next to a kernel that otherwise waits on HBM.  null = no.
+  uint32_t* leaf_hashes = nullptr;
 };
 void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st);
+bool quotient_leaf_serves(const QuotientArgs& a);   // may `leaf_hashes` be set for this launch?
 void fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t log_n, const Twiddles& tw,
                            const QM31& alpha, bool accumulate, hipStream_t st, const uint32_t* d_alpha = nullptr);
 // d_alpha != null: the folding challenge is read from device memory (4 u32) instead of `alpha`

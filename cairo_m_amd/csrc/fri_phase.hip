@@ -61,7 +61,16 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
       // (round 5) the transcript step behind a tree — mix_root + the draw of the folding challenge — runs in the block that hashes
       // the root (MerkleTopExtra): one launch less per layer on the protocol-serial chain.  A/B: CM_FRI_TOP_FUSE=0
       if (top_fuse) first_tree.top_extra = MerkleTopExtra{d_chan.u32(), d_alphas.u32(), d_roots.u32()};
-      first_tree.commit_prepared(st);
+      {
+        // (round 6) first_leaf_done: the DEEP-quotient kernel of the largest size group has already written the leaf layer
+        // (first_tree.leaf_prealloc, adopted by plan_commit): the plan starts at its second launch
+        const bool had_leaf = first_leaf_done && first_tree.leaf_prealloc.p != nullptr;
+        auto plan = first_tree.plan_commit();
+        const int nl = (int)q_logs[0];
+        CM_CHECK(!had_leaf || (plan.size() > 1 && plan[0].hi == nl && plan[0].lo == nl && !first_tree.leaf_prealloc.p),
+                 "fri: the first-layer tree's plan does not start with a launch of the leaf layer alone");
+        for (size_t k = had_leaf ? 1 : 0; k < plan.size(); k++) first_tree.run_launch(plan[k], st);
+      }
       if (!first_tree.top_launch_has_extras) chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
     } else {
       uint32_t a4[4];

@@ -121,8 +121,12 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
 // the R * n_batches CM31 denominators of a thread are inverted with ONE field inversion (Montgomery's trick: prefix
 // products, one inverse, back-substitution) instead of one 37-multiplication exponentiation each — in the one-row kernel the
 // inversions were ~40 % of the VALU work of a row.  Same field elements, so the output is bit-identical.
-template <int R>
+// LEAF: the kernel also writes a.leaf_hashes[row] = hash_node(no children, the row's four words) — the leaf layer of the FRI
+// first-layer tree (framing and store pattern of k_fold_leaf / k_merkle_narrow<RFC, false, 4>: the 64 rows of a wave are
+// consecutive, their hashes leave through a wave-private LDS window as two wave-contiguous 1 KiB stores).
+template <int R, bool LEAF = false, bool RFC = false>
 __global__ void __launch_bounds__(256) k_quotients_rows(QuotientArgs a) {
+  __shared__ uint4 leaf_stage[LEAF ? 4 : 1][LEAF ? 128 : 1];
   const uint32_t rbase = blockIdx.x * (256u * R) + threadIdx.x;     // n is a multiple of 256 R (the launcher checks)
   const uint32_t nb = a.n_batches;                                   // 1 or 2
   M31 py[R];
@@ -222,6 +226,33 @@ __global__ void __launch_bounds__(256) k_quotients_rows(QuotientArgs a) {
   for (int k = 0; k < R; k++) {
     const uint32_t row = rbase + 256u * k;
     a.out[0][row] = acc[k].a.a.v; a.out[1][row] = acc[k].a.b.v; a.out[2][row] = acc[k].b.a.v; a.out[3][row] = acc[k].b.b.v;
+  }
+  if (LEAF) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint4* st = leaf_stage[w];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      uint32_t z[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) z[i] = 0;   // 12 literal zeros: most message additions of the compression fold away
+      z[0] = acc[k].a.a.v; z[1] = acc[k].a.b.v; z[2] = acc[k].b.a.v; z[3] = acc[k].b.b.v;
+      NodeFrame<RFC> fr(false, 4);
+      uint32_t h[8];
+      fr.init(h);
+      fr.absorb(h, z, 16);
+      st[lane * 2 + 0] = make_uint4(h[0], h[1], h[2], h[3]);
+      st[lane * 2 + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t wave_row0 = blockIdx.x * (256u * R) + 256u * k + 64u * w;   // the wave's 64 consecutive rows of this k
+      uint4* o = reinterpret_cast<uint4*>(a.leaf_hashes + (size_t)wave_row0 * 8);
+      o[lane] = st[lane];
+      o[64 + lane] = st[64 + lane];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   }
 }
 
@@ -486,12 +517,22 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
 }
 
 // ================================================================= host wrappers
+// can the two-rows kernel write the leaf hashes of this group?  (whole domain, the default two-rows form, a layer that is a launch
+// of its own in MerkleTree::plan_commit)
+bool quotient_leaf_serves(const QuotientArgs& a) {
+  return a.n_rows == 0 && a.row0 == 0 && a.log_size >= MERKLE_MULTI_MAX_TOP && tune(T_QUOT_ROWS) == 2 && a.entry_cols && a.n_batches >= 1 &&
+         a.n_batches <= 2;
+}
 void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st) {
   uint32_t n = a.n_rows ? a.n_rows : (1u << a.log_size);
-  KProfScope kp("k_quotients", (4.0 * n_cols + 16.0) * (double)n, st);
+  KProfScope kp("k_quotients", (4.0 * n_cols + 16.0 + (a.leaf_hashes ? 32.0 : 0.0)) * (double)n, st);
   // two rows per thread with one shared denominator inversion (A/B: CM_QUOT_ROWS=1 restores the one-row kernel)
   const int rows = tune(T_QUOT_ROWS);
-  if (a.log_size >= 14 && rows == 2 && a.entry_cols && a.n_batches >= 1 && a.n_batches <= 2 && n % 512 == 0)
+  if (a.leaf_hashes) {   // (the caller has checked quotient_leaf_serves)
+    CM_CHECK(quotient_leaf_serves(a), "launch_quotients: leaf hashes asked for a launch the row kernel does not serve");
+    if (framing().hash_node_rfc) hipLaunchKernelGGL((k_quotients_rows<2, true, true>), dim3(n / 512), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_quotients_rows<2, true, false>), dim3(n / 512), dim3(256), 0, st, a);
+  } else if (a.log_size >= 14 && rows == 2 && a.entry_cols && a.n_batches >= 1 && a.n_batches <= 2 && n % 512 == 0)
     hipLaunchKernelGGL(k_quotients_rows<2>, dim3(n / 512), dim3(256), 0, st, a);
   else if (a.log_size >= 14 && rows == 4 && a.entry_cols && a.n_batches >= 1 && a.n_batches <= 2 && n % 1024 == 0)
     hipLaunchKernelGGL(k_quotients_rows<4>, dim3(n / 1024), dim3(256), 0, st, a);

@@ -86,6 +86,10 @@ struct MerkleTree {
   // it enqueues the next phase (Prover::pace): its wake-up and launch latency hide behind the tree top.
   hipEvent_t pace_ev = nullptr;
   bool pace_recorded = false;
+  // (round 6) the leaf layer's buffer, handed in by a caller whose own kernel writes that layer (the DEEP-quotient kernel hashes the
+  // rows it produces: Prover::deep_quotients): plan_commit() adopts it as layers[max_log] instead of allocating; the caller then
+  // skips the plan's first launch (hi == lo == max_log)
+  DevBuf leaf_prealloc;
   MerkleTopExtra top_extra;                      // extras of the tree-top launch (engine.hpp): set before plan_commit()
   bool top_launch_has_extras = false, top_launch_has_fold = false;   // what the last plan_commit() could place
   const uint32_t* const* d_cols_view = nullptr;  // device copy of `cols` inside somebody else's upload (UploadBatch)
@@ -189,7 +193,8 @@ struct MerkleTree {
       if (levels == 1 || wide) {
         size_t c0 = ci;
         ci += n_here;
-        layers[log].alloc((size_t)32 << log);
+        if (log == (int)max_log && leaf_prealloc.p && leaf_prealloc.bytes >= ((size_t)32 << log)) layers[log] = std::move(leaf_prealloc);
+        else layers[log].alloc((size_t)32 << log);
         const uint32_t* prev = (log < (int)max_log) ? layers[log + 1].u32() : nullptr;
         const uint32_t* const* dc = dcols() + c0;
         const uint32_t nc = (uint32_t)(ci - c0);

@@ -1377,6 +1377,15 @@ struct SegmentProver {
         q_logs.push_back(g.log);
         quotients.push_back(std::move(g.out));
       }
+      // (round 6) The FRI first-layer tree's leaf layer — 2^log hashes of four words each, 8.4 M compressions at the metric config,
+      // 0.21 ms as a launch of its own with the GPU otherwise idle — is written by the quotient kernel of the LARGEST size group:
+      // that kernel waits on HBM (4 B per LDE cell in, 4.1 TB/s) and its VALU ports are half idle.  "quot_leaf" = 0: separate launch.
+      if (tune(T_QUOT_LEAF) != 0 && !qargs.empty() && (qargs.size() == 1 || qargs[1].first.log_size < qargs[0].first.log_size) &&
+          quotient_leaf_serves(qargs[0].first)) {
+        fri.first_tree.leaf_prealloc.alloc((size_t)32 << qargs[0].first.log_size);
+        qargs[0].first.leaf_hashes = fri.first_tree.leaf_prealloc.u32();
+        fri.first_leaf_done = true;
+      }
       // the small groups (latency-bound column-slice kernels, ~170 us in a row) go FIRST, together on one side stream, so that
       // they hide under the large groups instead of trailing them (they ended the region ~90 us after the last large kernel);
       // the large groups follow by descending size, one stream each

@@ -483,6 +483,7 @@ struct FriPhase {
   MerkleTree first_tree;
   std::vector<std::unique_ptr<InnerLayer>> inner;
   bool have_first = true;       // false after a resumed commit: no first-layer tree here
+  bool first_leaf_done = false; // the DEEP-quotient kernel wrote first_tree's leaf layer (first_tree.leaf_prealloc)
   uint32_t inner_fold0 = 1;     // folds between the query domain and inner[0]
   void commit(Prover& P, const cm_pcs_config& cfg, std::vector<ColumnSet>& quotients, const std::vector<uint32_t>& q_logs, ProofData& pf,
               const std::function<void()>& while_gpu_busy, const FriResume* resume = nullptr) {
