@@ -293,6 +293,25 @@ struct QAcc {
     q0 += v * c4[0]; q1 += v * c4[1]; q2 += v * c4[2]; q3 += v * c4[3];
     if (++pending == 4) { q0 = fold(q0); q1 = fold(q1); q2 = fold(q2); q3 = fold(q3); pending = 0; }
   }
+  // += c * x for a QM31 coefficient c (4 canonical words) and a QM31 value x, WITHOUT a QM31 product: with the basis
+  // e = (1, i, u, iu), c x = sum_j x_j (c e_j) and the coordinates of c e_j are fixed linear forms of c = (a, b, c, d):
+  //   c e_0 = (a, b, c, d)   c e_1 = (-b, a, -d, c)   c e_2 = (2c - d, c + 2d, a, b)   c e_3 = (-(c + 2d), 2c - d, -b, a)
+  // so every coordinate of the sum takes four raw products (one v_mad_u64_u32 each) on top of the lazily folded accumulator — 16
+  // multiply-adds + 4 one-instruction folds instead of a 20-product QM31 multiplication with four Mersenne folds and four modular
+  // additions.  The coefficient is wave-uniform in the AIR kernels (a random-coefficient power read through scalar loads), so its five
+  // derived words (-b, -d, 2c - d, c + 2d, -(c + 2d)) cost scalar instructions.  Negatives are P - v in [1, P]: x * P = 0 (mod P).
+  CM_HD void add_q(const uint32_t* c4, const QM31& x) {
+    if (pending) { q0 = fold(q0); q1 = fold(q1); q2 = fold(q2); q3 = fold(q3); pending = 0; }
+    const uint32_t a = c4[0], b = c4[1], c = c4[2], d = c4[3];
+    const uint32_t nb = P - b, nd = P - d;
+    const uint32_t e = (M31(c) + M31(c) - M31(d)).v, f = (M31(c) + M31(d) + M31(d)).v, nf = P - f;
+    const unsigned long long x0 = x.a.a.v, x1 = x.a.b.v, x2 = x.b.a.v, x3 = x.b.b.v;
+    q0 += x0 * a + x1 * nb + x2 * e + x3 * nf;
+    q1 += x0 * b + x1 * a + x2 * f + x3 * e;
+    q2 += x0 * c + x1 * nd + x2 * a + x3 * nb;
+    q3 += x0 * d + x1 * c + x2 * b + x3 * a;
+    q0 = fold(q0); q1 = fold(q1); q2 = fold(q2); q3 = fold(q3);
+  }
   CM_HD QM31 value() const {
     return QM31(M31::reduce(fold(q0)), M31::reduce(fold(q1)), M31::reduce(fold(q2)), M31::reduce(fold(q3)));
   }

@@ -217,8 +217,15 @@ struct DomainEval : air::LogupStream<DomainEval, M31, QM31> {
   __device__ M31 preproc(int id) { return M31(CM_GCOL(pp[id])[row]); }
   __device__ M31 c(uint32_t v) { return M31(v); }
   __device__ void constraint(M31 x) { base_acc.add(coeff + 4 * (kb++), x); }
-  __device__ QM31 total() const { return acc + base_acc.value(); }
+  __device__ QM31 total() const { return base_acc.value(); }
+  // (round 6) rho^k * X for a QM31 constraint value X joins the same lazy accumulator as the base-field constraints (QAcc::add_q):
+  // no QM31 product, no reduction until total()
+#ifdef CM_CONSTRAINT_Q_PLAIN   /* A/B: the round-5 form */
   __device__ void constraint_q(QM31 x) { acc += QM31::from_u32(coeff + 4 * (n_base + kl++)) * x; }
+  __device__ QM31 total_plain() const { return acc + base_acc.value(); }
+#else
+  __device__ void constraint_q(QM31 x) { base_acc.add_q(coeff + 4 * (n_base + kl++), x); }
+#endif
   __device__ QM31 combine(int r, const M31* v, int n) { return dev_combine(rels, r, v, n); }
   __device__ QM31 ef_from(M31 m) { return QM31(m); }
   __device__ void on_entry(int, M31, const M31*, int) {}

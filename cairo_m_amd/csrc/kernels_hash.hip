@@ -45,6 +45,31 @@ __global__ void k_chan_mix_root_draw(uint32_t* chan, const uint32_t* root, uint3
   chan_mix_root_draw_quad(threadIdx.x, chan, root, felt_out, root_log, x8, felt);
 }
 
+// Sharded FRI layer on the stream (prover_sharded.inc, round 6): the N sub-roots the all-gather left in `sub` (rank-major, 8 words
+// each) -> the top log2 N levels of the tree (children-only nodes: Stwo's raw compression from the zero state, the host twin is
+// hash_pair_host) -> root -> mix_root + draw_felt on the device copy of the channel.  `sub_log` keeps the sub-roots for the host,
+// which rebuilds the top levels for the decommitment and replays the transcript step once per proof instead of once per layer.
+__global__ void __launch_bounds__(64) k_shard_top_step(const uint32_t* __restrict__ sub, uint32_t n, uint32_t* chan, uint32_t* felt_out,
+                                                       uint32_t* root_log, uint32_t* sub_log) {
+  __shared__ uint32_t nodes[2][8 * 8];
+  __shared__ uint32_t x8[8], felt[4];
+  const uint32_t t = threadIdx.x;
+  for (uint32_t i = t; i < 8 * n; i += 64) { const uint32_t w = sub[i]; nodes[0][i] = w; sub_log[i] = w; }
+  __syncthreads();
+  uint32_t cur = 0;
+  for (uint32_t m = n; m > 1; m >>= 1) {
+    if (t < m / 2) {
+      uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, msg[16];
+      for (int k = 0; k < 16; k++) msg[k] = nodes[cur][16 * t + k];
+      b2s_compress(h, msg);
+      for (int k = 0; k < 8; k++) nodes[cur ^ 1][8 * t + k] = h[k];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (t < 4) chan_mix_root_draw_quad(t, chan, nodes[cur], felt_out, root_log, x8, felt);
+}
+
 // powers[g] = rho^(n - 1 - g): the random-coefficient powers of the composition polynomial, one thread per power (square and
 // multiply), from the coefficient the device-side transcript step (k_chan_mix_root_draw) left in device memory
 __global__ void __launch_bounds__(256) k_coeff_powers(const uint32_t* __restrict__ rho4, uint32_t* __restrict__ powers, uint32_t n) {
@@ -191,6 +216,11 @@ void merkle_multi(const MerkleMultiArgs& a, double alg_bytes, hipStream_t st) {
 }
 void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log, hipStream_t st) {
   hipLaunchKernelGGL(k_chan_mix_root_draw, dim3(1), dim3(64), 0, st, d_chan, d_root, d_felt_out, d_root_log);
+  CM_HIP(hipGetLastError());
+}
+void shard_top_step(const uint32_t* d_sub, uint32_t n, uint32_t* d_chan, uint32_t* d_felt_out, uint32_t* d_root_log, uint32_t* d_sub_log, hipStream_t st) {
+  CM_CHECK(n >= 1 && n <= 8 && (n & (n - 1)) == 0, "shard_top_step: rank count");
+  hipLaunchKernelGGL(k_shard_top_step, dim3(1), dim3(64), 0, st, d_sub, n, d_chan, d_felt_out, d_root_log, d_sub_log);
   CM_HIP(hipGetLastError());
 }
 void chan_init_mix_root_draw(const uint32_t init9[9], uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log,
