@@ -614,6 +614,15 @@ def main():
                                      "register_only_note": "the same compression code looping on registers only, whole GPU (tools/chain_lab.hip, "
                                                            "profiles/r03w_chain_lab.txt): the rate no Merkle kernel can exceed with this op mix"}
                                     if name == "k_merkle_layer" else {}),
+                                 **({"alone": {"achieved": al["work"] / (al["ms"] * 1e-3), "frac_of_peak": al["work"] / (al["ms"] * 1e-3) / ALU_PEAK[name][0],
+                                               "frac_of_register_only": al["work"] / (al["ms"] * 1e-3) / B2S_REGISTER_ONLY,
+                                               "launches": al["calls"], "ms_per_step": al["ms"] / n_prof, "compressions_per_step": al["work"] / n_prof,
+                                               "note": "the same class over the launches that have the GPU to themselves (FRI commit phase and composition tree "
+                                                       "of a lone proof: one kernel at a time on the main stream; instrumented pass).  `achieved` above is over "
+                                                       "ALL launches of the timed region, including the trace / interaction trees whose hashing the commitment "
+                                                       "pipeline overlaps with the transforms of the next size group — both kernels are slower while they share "
+                                                       "the GPU, the sum is what the pipeline shortens"}}
+                                    if name == "k_merkle_layer" and (al := kprof_all.get("k_merkle_layer(alone)")) and al.get("ms") else {}),
                                  "note": "this class is integer-VALU-bound, not HBM-bound (DESIGN.md §3); peak = 1 / sum(ops_i / measured lane-op rate_i), "
                                          "rates from profiles/r03k_valu_lab.txt (tools/valu_lab.hip)"}
                                 if name in ALU_PEAK and k.get("work") else None),

@@ -11,6 +11,7 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
                               const FriResume* resume) {
   hipStream_t st = P.st;
   Channel& ch = P.ch;
+  KProfAloneScope kprof_alone_scope;   // (measurement only: a lone proof runs this phase one kernel at a time, kprof.hpp)
   // ---- FRI commit ----
   // The whole commit phase is enqueued without a host round trip: after each layer's Merkle tree a 1-thread
   // kernel does the transcript step (mix_root, draw the folding challenge) on a device copy of the channel,

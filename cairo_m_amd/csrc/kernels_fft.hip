@@ -23,6 +23,7 @@
 #include "field.hpp"
 #include "device_common.hpp"
 #include "fft_pass.hpp"
+#include "engine.hpp"
 
 namespace cm {
 
@@ -251,8 +252,11 @@ __global__ void __launch_bounds__(1 << (14 - E)) k_fft_fused_rb(FftFusedArgs a) 
 }
 template <int W, int E = 4>
 static void launch_fused_one(const FftFusedArgs& a, uint32_t ntiles, uint32_t ncols, hipStream_t st) {
-  constexpr size_t lds = ((size_t)4 << 14) + ((size_t)4 << 9);
-  static const hipError_t once = hipFuncSetAttribute((const void*)k_fft_fused_rb<W, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  constexpr size_t lds0 = ((size_t)4 << 14) + ((size_t)4 << 9);
+  // "fft_half_occ" (A/B, bit 0: the 2^14-tile kernels): ask for more LDS than the tile needs so that ONE block fits a CU instead of two —
+  // 4 waves per SIMD are left for the Merkle kernels the commitment pipeline runs next to the transforms
+  const size_t lds = (tune(T_FFT_HALF_OCC) & 1) ? (size_t)84 * 1024 : lds0;
+  static const hipError_t once = hipFuncSetAttribute((const void*)k_fft_fused_rb<W, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024);
   (void)once;
   hipLaunchKernelGGL((k_fft_fused_rb<W, E>), dim3(ntiles, ncols), dim3(1u << (14 - E)), lds, st, a);
 }
@@ -270,10 +274,13 @@ void launch_fft_fused_rb(const FftPassArgs& inv, const FftPassArgs& fwd, uint32_
 
 template <bool INV, int W, int TL, int E>
 static void launch_one(const FftPassArgs& a, uint32_t ntiles, uint32_t ncols, hipStream_t st) {
-  constexpr size_t lds = ((size_t)4 << TL) + ((size_t)4 << (TL - 5));
-  if (lds > 48 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
+  constexpr size_t lds0 = ((size_t)4 << TL) + ((size_t)4 << (TL - 5));
+  // "fft_half_occ" (A/B): bit 0 = one 2^14-tile block per CU instead of two, bit 1 = four 2^12-tile blocks per CU instead of eight
+  const int ho = tune(T_FFT_HALF_OCC);
+  const size_t lds = (TL == 14 && (ho & 1)) ? (size_t)84 * 1024 : (TL == 12 && (ho & 2)) ? (size_t)33 * 1024 : lds0;
+  if (lds0 > 48 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
     static const hipError_t once =
-        hipFuncSetAttribute((const void*)k_fft_pass_rb<INV, W, TL, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k_fft_pass_rb<INV, W, TL, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024);
     (void)once;
   }
   hipLaunchKernelGGL((k_fft_pass_rb<INV, W, TL, E>), dim3(ntiles, ncols), dim3(1u << (TL - E)), lds, st, a);

@@ -1041,6 +1041,7 @@ struct SegmentProver {
       }
       t.coeffs = std::move(acc_top);
       oods_prepare();   // needs tree 3's coefficient pointers, nothing of its commitment
+      KProfAloneScope kprof_alone_scope;   // (measurement only: the composition tree has the GPU to itself, kprof.hpp)
       P.commit_enqueue(t, nullptr, true, st, true, false, P.pipe_stream());
     }
   }

@@ -2,7 +2,8 @@
 // (E = 4, 1024 threads) for the strided passes of 9 / 10 layers — with E = 4 they are THREE rounds (4 + 1 + 4 / 4 + 2 + 4: the middle
 // round of one or two layers still pays a full LDS exchange), with E = 5 two (5 + 4 / 5 + 5) — and for the fused kernel that ends
 // the inverse transform of 2^21 rows and starts the extension (k_fft_fused_rb<9>).  Timing only (tables are memset): 64 columns.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I cairo_m_amd/csrc tools/fft_lab2.hip -o tools/fft_lab2
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I cairo_m_amd/csrc tools/fft_lab2.hip -o tools/fft_lab2 -Lcairo_m_amd -l:libcairom_hip.so -Wl,-rpath,'$ORIGIN/../cairo_m_amd'
+//   (kernels_fft.hip reads a tuning switch of the library: link against it)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
