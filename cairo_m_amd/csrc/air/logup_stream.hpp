@@ -43,7 +43,7 @@ struct LogupStream {
   template <class... V>
   AIR_HD void rel(int r, F mult, V... vals) {
     F arr[] = {vals...};
-    rel_arr(r, mult, arr, (int)sizeof...(V));
+    self().rel_arr(r, mult, arr, (int)sizeof...(V));   // (an evaluator may take the entries one by one: gpu_air.hpp LogupEval)
   }
   AIR_HD void complete(EF N, EF Dd) {
     if (have_pending) self().emit_batch(false, pend_n, pend_d);

@@ -137,6 +137,93 @@ struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
   __device__ QM31 combine(int r, const M31* v, int n) { return dev_combine(rels, r, v, n); }
   __device__ QM31 ef_from(M31 m) { return QM31(m); }
   __device__ void on_entry(int, M31, const M31*, int) {}
+  // (round 6) ENTRY-WISE fractions.  The interaction column of batch j holds prev + n0/d0 + n1/d1; Stwo forms the pair as
+  // (n0 d1 + n1 d0) / (d0 d1) and inverts the product — in the field that is the same element as the sum of the two quotients, so
+  // each entry's 1/d is computed on its own: norm_u(d) = d.a^2 - R d.b^2 in CM31, its norm in M31, ONE M31 inversion for a group of
+  // up to LOGUP_INV_ENTRIES entries (Montgomery's trick), then conj / norm back up.  24 field multiplications per entry against 71 per
+  // PAIR of the batch form (the 20-product d0 d1, the norm of the product, and a 20-product numerator x inverse at the end);
+  // the canonical words written are identical.  Every index below is a compile-time constant after inlining (a component's
+  // stream is straight-line code), so the buffers live in registers.  CM_LOGUP_BATCH_FORM: the round-3 batch form (A/B).
+  // INVARIANT (shared inversion): a zero norm in a group makes inv(all) = 0 and zeroes ALL fractions of the group, where the
+  // per-batch form lost one.  A denominator z - sum alpha^i v_i is zero with probability ~2^-124 per entry over the verifier's
+  // (z, alpha) — Stwo's own batch inverse panics on it, the reference would not produce a proof either — and a proof made
+  // from such a row fails the OODS composition check of this prover (check_composition_at_oods), so it cannot leave the library.
+#ifndef CM_LOGUP_BATCH_FORM
+#ifndef CM_LOGUP_INV_ENTRIES
+#define CM_LOGUP_INV_ENTRIES 8
+#endif
+  static constexpr int GE = CM_LOGUP_INV_ENTRIES;
+  static_assert(GE % 2 == 0, "groups end on a batch boundary");
+  QM31 ed[GE];   // denominators, slot 0 = the newest entry (a shift register: constant indices even before `cnt` is promoted)
+  M31 em[GE];    // multiplicities
+  int cnt = 0;
+  __device__ __forceinline__ void rel_arr(int r, M31 mult, const M31* vals, int n) {
+    const QM31 den = dev_combine(rels, r, vals, n);
+#pragma unroll
+    for (int k = GE - 1; k > 0; k--) { ed[k] = ed[k - 1]; em[k] = em[k - 1]; }
+    ed[0] = den; em[0] = mult; cnt++;
+    if (cnt == GE) flush();
+  }
+  // an odd entry count leaves a last batch of ONE entry (Stwo's finalize_logup_in_pairs): it is paired with a zero fraction 0 / 1, so
+  // that every group — the last one too — is whole pairs with the OLDER entry of a pair in the odd slot of the shift register
+  __device__ __forceinline__ void finalize_pairs() {
+    if (cnt & 1) {
+#pragma unroll
+      for (int k = GE - 1; k > 0; k--) { ed[k] = ed[k - 1]; em[k] = em[k - 1]; }
+      ed[0] = QM31(M31(1)); em[0] = M31(0); cnt++;
+    }
+    flush();
+  }
+  __device__ __forceinline__ void finalize_single() { finalize_pairs(); }
+  __device__ void emit_batch(bool, QM31, QM31) {}   // (unused: the entries never reach LogupStream's pairing)
+  __device__ __forceinline__ void flush() {
+    const int n = cnt;
+    if (n == 0) return;
+    CM31 t[GE];
+    M31 nr[GE], pre[GE], ni[GE];
+    M31 all;
+#pragma unroll
+    for (int k = 0; k < GE; k++)
+      if (k < n) {
+        t[k] = ed[k].a * ed[k].a - mul_R(ed[k].b * ed[k].b);
+#if defined(__HIP_DEVICE_COMPILE__)
+        nr[k] = m31_fold64((unsigned long long)t[k].a.v * t[k].a.v + (unsigned long long)t[k].b.v * t[k].b.v);
+#else
+        nr[k] = t[k].a * t[k].a + t[k].b * t[k].b;
+#endif
+        pre[k] = k == 0 ? nr[0] : pre[k - 1] * nr[k];
+        all = pre[k];
+      }
+    M31 run = inv(all);
+#pragma unroll
+    for (int k = GE - 1; k >= 0; k--)
+      if (k < n) {
+        ni[k] = k == 0 ? run : run * pre[k - 1];
+        if (k > 0) run = run * nr[k];
+      }
+    QM31 fr[GE];   // m_k / d_k
+#pragma unroll
+    for (int k = 0; k < GE; k++)
+      if (k < n) {
+        const M31 nm = ni[k] * em[k];                                     // the multiplicity rides on the M31 inverse: one product
+        const CM31 ti(t[k].a * nm, -(t[k].b * nm));                       // m / norm_u(d)
+        fr[k] = QM31(ed[k].a * ti, -(ed[k].b * ti));                      // m conj_u(d) / norm_u(d)
+      }
+    // oldest entry first: slots n-1, n-2 make the first batch (n is even: finalize_pairs pads an odd stream)
+#pragma unroll
+    for (int k = GE - 1; k >= 1; k -= 2)
+      if (k < n) {
+        const QM31 v = prev + fr[k] + fr[k - 1];
+        CM_GCOL_W(out[4 * batch + 0])[row] = v.a.a.v;
+        CM_GCOL_W(out[4 * batch + 1])[row] = v.a.b.v;
+        CM_GCOL_W(out[4 * batch + 2])[row] = v.b.a.v;
+        CM_GCOL_W(out[4 * batch + 3])[row] = v.b.b.v;
+        prev = v;
+        batch++;
+      }
+    cnt = 0;
+  }
+#else
   // The batches of a row are buffered, up to LOGUP_INV_GROUP at a time, and their denominators inverted TOGETHER: a QM31 inverse
   // is conj / norm with one M31 inversion (37 multiplications by Fermat) at the bottom; Montgomery's trick replaces the group's
   // M31 inversions by one inversion + 3 multiplications each.  Every index below is a compile-time constant after inlining (the
@@ -198,6 +285,7 @@ struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
       }
     cnt = 0;
   }
+#endif
 };
 
 struct DomainEval : air::LogupStream<DomainEval, M31, QM31> {
