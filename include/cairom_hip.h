@@ -393,6 +393,12 @@ int32_t cm_set_device_tail(int32_t on);
  * layer size, 0 = k_merkle_layer, 1..8 chunks per wave), "fork_width" (0 = all side streams), "pp_side" (1), "tree0_prio" (-1 high
  * priority stream, 0 fork side stream, 1 low), "tree1_first" (1), "logup_width" (4), "quot_rows" (2), "fri_fold_leaf" (1),
  * "fft_fused" (1), "commit_pipe" (1), "fft_chunk_mb" (0 = off), "pace" (-1 = by load), "pace_early" (1).
+ * Round 6: "cons_wide_first" (1: a wide component of few rows — poseidon2's 443 columns — is the first launch of the constraint
+ * region), "cons_plan" (side-stream plan of that region as eight octal digits, default 01237456), "logup_small_stream" (-1 = stream
+ * `logup_width`; 0..7 picks the side stream of the batched small LogUp launch), "quot_leaf" (1: the DEEP-quotient kernel of the largest
+ * size group also writes the leaf hashes of the FRI first-layer tree), "shard_fri_stream" (1: cm_prove_sharded keeps its row-sharded
+ * FRI layers on the stream — tree top and transcript step on the device, one host replay per proof), "fft_half_occ" (0; bit 0 / 1 =
+ * one 2^14-tile / four 2^12-tile transform blocks per CU instead of two / eight: measured slower, kept for A/B).
  * Test hook: "tail_grind_cap" (0 = off; v > 0 stops the device tail's proof-of-work search after 2^(v-1) nonces, so that the
  * host-driven fallback behind a missed nonce — probability e^-16 in production — can be exercised; same proof bytes).
  * status 1 for an unknown key or a value outside the key's range.  Flip a switch only while no proof is running in the process: a

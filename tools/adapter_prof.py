@@ -21,3 +21,11 @@ for i in range(a.reps):
     ts.append((time.perf_counter() - t) * 1e3)
     be.free_input(d)
 print("adapt_segment ms:", [round(x, 3) for x in ts], "min", round(min(ts), 3))
+try:   # sizes of the two sorts (the vendor radix sort's algorithmic traffic: DESIGN 3.2)
+    from cairo_m_amd.lib import runner_segment_arrays
+    arr = runner_segment_arrays(seg.view)
+    n_steps, n_mem = len(arr["trace"]), len(arr["memory_trace"])
+    print(f"n_steps {n_steps}  n_memory_entries {n_mem}  sort traffic model: {n_mem} pairs x 8 B x (read + write) x 4 digit passes + "
+          f"{n_steps} pairs x 8 B x 2 x 2 passes = {(n_mem * 64 + n_steps * 32) / 1e9:.3f} GB")
+except Exception as e:   # noqa: BLE001
+    print("sizes unavailable:", e)
