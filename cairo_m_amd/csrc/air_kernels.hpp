@@ -23,6 +23,10 @@ struct ConstraintArgs {
   // kernels index columns by the global row), the last four interaction columns (the cumulative sum, read at the previous
   // row as well) and pp are full columns.
   uint32_t row0 = 0, n_rows = 0;
+  // (round 6, sharded prover) the four cumulative-sum columns of a split component at the PREVIOUS row of every row of the rank's range
+  // (pointers `row0` words in front of the halo slices, like tr / it): the range's own neighbours instead of four whole columns.
+  // null: the last four `it` columns are whole and are read at prev_row.
+  const uint32_t* const* it_prev = nullptr;
 };
 
 void launch_opcode_trace(int cid, const void* bundles, uint32_t n, const void* acc, uint32_t log_size, uint32_t* const* d_cols,

@@ -40,6 +40,19 @@ __device__ __forceinline__ QM31 block_reduce_qm31(QM31 q) {
   return r;
 }
 
+// Row `offset` trace-steps away on bit-reversed storage of log n (trace domain log = trace_log <= n).
+CM_HD uint32_t shifted_row(uint32_t r, uint32_t n, uint32_t trace_log, int offset) {
+  uint32_t i = bit_reverse(r, n);
+  uint32_t half = 1u << (n - 1);
+  uint32_t mod_mask = (n + 1 >= 32) ? 0xffffffffu : ((1u << (n + 1)) - 1);
+  uint32_t e = i < half ? (1u + 4u * i) : (0u - (1u + 4u * (i - half)));
+  e += (uint32_t)offset * (1u << (n + 1 - trace_log));
+  e &= mod_mask;
+  uint32_t j = ((e & 3u) == 1u) ? (e - 1u) / 4u : half + (((mod_mask + 1u) - e - 1u) & mod_mask) / 4u;
+  return bit_reverse(j, n);
+}
+
+
 // ---- host error handling -------------------------------------------------------------------------
 struct CmError : std::runtime_error {
   int code;

@@ -294,6 +294,7 @@ struct DomainEval : air::LogupStream<DomainEval, M31, QM31> {
   const uint32_t* const* pp;   // tree-0 LDE columns by PreprocId
   const DevRelations* rels;
   const uint32_t* coeff;       // 4 u32 per constraint
+  const uint32_t* const* it_prev = nullptr;   // optional: the four cumulative-sum columns AT THE PREVIOUS ROW, indexed by `row` (sharded halo)
   uint32_t row, prev_row;
   int n_base;
   QM31 cumsum_shift;
@@ -326,23 +327,15 @@ struct DomainEval : air::LogupStream<DomainEval, M31, QM31> {
       prev_col = cur;
       constraint_q(diff * den - num);
     } else {
-      QM31 pr = mask(prev_row), cur = mask(row);
+      QM31 pr = it_prev ? QM31(M31(CM_GCOL(it_prev[0])[row]), M31(CM_GCOL(it_prev[1])[row]), M31(CM_GCOL(it_prev[2])[row]), M31(CM_GCOL(it_prev[3])[row]))
+                        : mask(prev_row);
+      QM31 cur = mask(row);
       ii += 4;
       constraint_q((cur - pr - prev_col + cumsum_shift) * den - num);
     }
   }
 };
 
-// Row `offset` trace-steps away on bit-reversed storage of log n (trace domain log = trace_log <= n).
-__device__ __forceinline__ uint32_t shifted_row(uint32_t r, uint32_t n, uint32_t trace_log, int offset) {
-  uint32_t i = bit_reverse(r, n);
-  uint32_t half = 1u << (n - 1);
-  uint32_t mod_mask = (n + 1 >= 32) ? 0xffffffffu : ((1u << (n + 1)) - 1);
-  uint32_t e = i < half ? (1u + 4u * i) : (0u - (1u + 4u * (i - half)));
-  e += (uint32_t)offset * (1u << (n + 1 - trace_log));
-  e &= mod_mask;
-  uint32_t j = ((e & 3u) == 1u) ? (e - 1u) / 4u : half + (((mod_mask + 1u) - e - 1u) & mod_mask) / 4u;
-  return bit_reverse(j, n);
-}
+// (shifted_row: device_common.hpp)
 
 }  // namespace cm

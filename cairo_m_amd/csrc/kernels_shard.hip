@@ -32,6 +32,35 @@ __global__ void __launch_bounds__(256) k_sum_copies(const uint32_t* __restrict__
   }
 }
 
+__global__ void __launch_bounds__(256) k_pack_parity(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t half_len, uint32_t parity) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < half_len) dst[i] = src[2 * i + parity];
+}
+__global__ void __launch_bounds__(256) k_halo_build(const uint32_t* __restrict__ even_half, const uint32_t* __restrict__ odd_half, uint32_t even_src,
+                                                    uint32_t odd_src, uint32_t row0, uint32_t len, uint32_t n, uint32_t trace_log, uint32_t log_ranks,
+                                                    uint32_t* __restrict__ out, uint32_t* __restrict__ err) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= len) return;
+  const uint32_t pr = shifted_row(row0 + q, n, trace_log, -1);          // global position of the previous row
+  const uint32_t slice_log = n - log_ranks;
+  const uint32_t owner = pr >> slice_log, qp = pr & ((1u << slice_log) - 1);
+  const bool odd = (q & 1u) != 0;
+  if (owner != (odd ? odd_src : even_src) || (qp & 1u) != (q & 1u)) { *err = 1; return; }
+  out[q] = (odd ? odd_half : even_half)[qp >> 1];
+}
+void pack_parity(const uint32_t* d_src, uint32_t* d_dst, uint32_t half_len, uint32_t parity, hipStream_t st) {
+  if (!half_len) return;
+  hipLaunchKernelGGL(k_pack_parity, dim3((half_len + 255) / 256), dim3(256), 0, st, d_src, d_dst, half_len, parity);
+  CM_HIP(hipGetLastError());
+}
+void halo_build(const uint32_t* d_even_half, const uint32_t* d_odd_half, uint32_t even_src, uint32_t odd_src, uint32_t row0, uint32_t len,
+                uint32_t n, uint32_t trace_log, uint32_t log_ranks, uint32_t* d_out, uint32_t* d_err, hipStream_t st) {
+  if (!len) return;
+  hipLaunchKernelGGL(k_halo_build, dim3((len + 255) / 256), dim3(256), 0, st, d_even_half, d_odd_half, even_src, odd_src, row0, len, n, trace_log,
+                     log_ranks, d_out, d_err);
+  CM_HIP(hipGetLastError());
+}
+
 void copy_segments(const std::vector<CopySeg>& segs, hipStream_t st) {
   if (segs.empty()) return;
   uint64_t mx = 0;
