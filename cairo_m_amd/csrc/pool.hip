@@ -212,7 +212,7 @@ std::atomic<int>* tune_values() {
     std::atomic<int>* x = new std::atomic<int>[T_COUNT];
     for (int k = 0; k < T_COUNT; k++) {
       const char* e = getenv(TUNE_TABLE[k].env);
-      x[k].store(e ? std::min(std::max(atoi(e), TUNE_TABLE[k].lo), TUNE_TABLE[k].hi) : TUNE_TABLE[k].dflt);
+      x[k].store(e ? std::min(std::max((int)strtol(e, nullptr, 0), TUNE_TABLE[k].lo), TUNE_TABLE[k].hi) : TUNE_TABLE[k].dflt);   // (base 0: CM_CONS_PLAN=01237456 is octal)
     }
     return x;
   }();
