@@ -71,7 +71,9 @@ void copy_segments(const std::vector<CopySeg>& segs, hipStream_t st) {
   if (bx > 256) bx = 256;
   hipLaunchKernelGGL(k_copy_segments, dim3(bx, (uint32_t)segs.size()), dim3(256), 0, st, d.as<CopySeg>());
   CM_HIP(hipGetLastError());
-  CM_HIP(hipStreamSynchronize(st));   // the segment table is a temporary
+  // (no host synchronisation: the segment table goes back to the calling thread's device pool, whose blocks are reused in stream
+  // order on that thread's streams — the rule the single-GPU prover's early teardown relies on; round 6: this call used to stop the
+  // stream ~10 times per sharded proof)
 }
 void sum_copies(const uint32_t* d_in, uint32_t n_copies, uint64_t stride, uint64_t words, uint32_t* d_out, bool modular, hipStream_t st) {
   if (!words) return;
