@@ -304,6 +304,8 @@ def main():
     ap.add_argument("--pipelined", type=int, default=4,
                     help="after the timed region, also measure throughput with this many segment proofs in flight "
                          "(reported as the extra `pipelined` object, N=1 only; 0 = skip)")
+    ap.add_argument("--cached-setup-steps", type=int, default=8,
+                    help="lone proofs of the untimed `with_cached_setup` leg (preprocessed tree + twiddles kept between proofs); 0 = skip")
     ap.add_argument("--preprocessed-cache", action="store_true",
                     help="NOT the headline number: keep the committed preprocessed tree between proofs (SURVEY 8f-4); the "
                          "default recomputes tree 0 in every proof like the reference does")
@@ -447,6 +449,31 @@ def main():
         pipelined = {"inflight": args.pipelined, "proofs": n_pipe, "api": "cm_prove_many", "ms_per_proof": dtp * 1e3 / n_pipe,
                      "value": n_pipe * cells / dtp, "unit": "M31 trace cells/s",
                      "note": "throughput with several independent segment proofs in flight on the GPU (not the headline value)"}
+
+    cached_setup = None
+    if world == 1 and rank == 0 and not args.preprocessed_cache and args.cached_setup_steps > 0:
+        # What a service that proves many segments of ONE AIR would run with: the preprocessed tree (tree 0: it depends on the AIR only)
+        # and the twiddle tables kept between proofs (cm_set_preprocessed_cache, cm_set_twiddle_cache; proof bytes unchanged:
+        # test_preprocessed_cache_keeps_proof_bytes).  NOT the headline: the reference rebuilds both inside prove_cairo_m, and so does
+        # every proof of the timed region above.
+        be.set_preprocessed_cache(True)
+        be.set_twiddle_cache(True)
+        for _ in range(4):   # (the pool settles on a new set of blocks once tree 0 stays allocated)
+            be.prove_device(dev).free()
+        per = []
+        for _ in range(args.cached_setup_steps):
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            be.prove_device(dev).free()
+            torch.cuda.synchronize()
+            per.append(time.perf_counter() - tc)
+        dtc = sorted(per)[len(per) // 2]   # median of individually timed proofs
+        be.set_preprocessed_cache(False)
+        be.set_twiddle_cache(False)
+        cached_setup = {"ms_per_proof": dtc * 1e3, "value": cells / dtc, "unit": "M31 trace cells/s", "proofs_timed": args.cached_setup_steps,
+                        "statistic": "median of individually timed lone proofs",
+                        "note": "lone proofs with the preprocessed tree and the twiddle tables cached between proofs (same proof bytes); "
+                                "not the headline value: the timed region rebuilds both in every proof like the reference does"}
 
     alt = None
     if world == 1 and rank == 0 and args.alt_fib_n > 0:
@@ -663,7 +690,7 @@ def main():
                                "(constraints ... decommit phases of the last timed proof)"},
                "gpu_idle_traced": traced_idle(),
                "alt_reading": alt,
-               "phase_ms": phases, "roofline": roofline, "pipelined": pipelined, "sharded": sharded, "end_to_end": end_to_end,
+               "phase_ms": phases, "roofline": roofline, "pipelined": pipelined, "with_cached_setup": cached_setup, "sharded": sharded, "end_to_end": end_to_end,
                "proof_verified": verified}
         if world == 1 and not args.no_cpu_baseline:
             same = args.cpu_sample_n == args.fib_n
