@@ -30,7 +30,8 @@ namespace cm {
 // multiplications) instead of a 31-step double-and-add (~250).  The inverses come from Montgomery batches of 8 per thread
 // (one x^(P-2) per 8 elements).  Together ~10x fewer multiplications than the element-wise form: the tables are rebuilt in
 // every proof like the reference does (prover.rs:56-60), so this is on the proof's clock.
-constexpr uint32_t TW_LO = 13, TW_BATCH = 8;
+constexpr uint32_t TW_LO = 13;
+// entries per thread = size of a Montgomery batch (one x^(P-2) per batch): tuning key "tw_batch" (2 / 4 / 8 / 16), default 8
 __global__ void k_twiddle_point_tables(uint32_t R, uint32_t* __restrict__ tab) {   // tab: lo[2^TW_LO] then hi[...], (x, y) pairs
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t sh = 30 - R, n_lo = 1u << TW_LO, n_hi = (R + 1 > TW_LO) ? 1u << (R + 1 - TW_LO) : 1u;
@@ -47,6 +48,7 @@ __device__ __forceinline__ CPoint<M31> twiddle_point(const uint32_t* __restrict_
   return cadd(CPoint<M31>{M31(a.x), M31(a.y)}, CPoint<M31>{M31(b.x), M31(b.y)});
 }
 // out[k] = v[k], iout[k] = 1 / v[k] for TW_BATCH non-zero values of one thread
+template <uint32_t TW_BATCH>
 __device__ __forceinline__ void batch_inverse8(const M31 (&v)[TW_BATCH], M31 (&iv)[TW_BATCH], uint32_t n) {
   M31 pre[TW_BATCH];
   M31 acc(1);
@@ -54,6 +56,7 @@ __device__ __forceinline__ void batch_inverse8(const M31 (&v)[TW_BATCH], M31 (&i
   M31 ia = inv(acc);
   for (uint32_t k = n; k-- > 0;) { iv[k] = ia * pre[k]; ia = ia * v[k]; }
 }
+template <uint32_t TW_BATCH>
 __global__ void __launch_bounds__(256) k_twiddles_x(uint32_t* __restrict__ xtw, uint32_t* __restrict__ ixtw, uint32_t R, const uint32_t* __restrict__ tab) {
   const uint32_t total = (1u << (R - 1)) - 1;
   const uint32_t nthreads = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -79,6 +82,7 @@ __global__ void __launch_bounds__(256) k_twiddles_x(uint32_t* __restrict__ xtw, 
   if (t0 == 0) { xtw[total] = 0; ixtw[total] = 0; }   // the unused last entry (was a hipMemsetAsync each: four API calls at the very
                                                        // start of a proof, where the host's launch rate is the bound)
 }
+template <uint32_t TW_BATCH>
 __global__ void __launch_bounds__(256) k_twiddles_y(uint32_t* __restrict__ ytw, uint32_t* __restrict__ iytw, uint32_t R, const uint32_t* __restrict__ tab) {
   const uint32_t nthreads = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
   M31 v[TW_BATCH], iv[TW_BATCH];
@@ -426,9 +430,13 @@ void twiddles_build(const Twiddles& t, hipStream_t st) {
   size_t nx = (size_t)1 << (R - 1), ny = (size_t)1 << R;
   const uint32_t n_tab = (uint32_t)(twiddles_scratch_words(R) / 2);
   hipLaunchKernelGGL(k_twiddle_point_tables, dim3((n_tab + 255) / 256), dim3(256), 0, st, R, t.scratch);
-  auto blocks = [](size_t n) { return dim3((uint32_t)((n + 256 * TW_BATCH - 1) / (256 * TW_BATCH))); };
-  hipLaunchKernelGGL(k_twiddles_x, blocks(nx), dim3(256), 0, st, t.xtw, t.ixtw, R, t.scratch);
-  hipLaunchKernelGGL(k_twiddles_y, blocks(ny), dim3(256), 0, st, t.ytw, t.iytw, R, t.scratch);
+  const uint32_t tb = (uint32_t)tune(T_TW_BATCH);
+  auto blocks = [tb](size_t n) { return dim3((uint32_t)((n + 256 * tb - 1) / (256 * tb))); };
+#define CM_TW(B)                                                                                            \
+  hipLaunchKernelGGL(k_twiddles_x<B>, blocks(nx), dim3(256), 0, st, t.xtw, t.ixtw, R, t.scratch);           \
+  hipLaunchKernelGGL(k_twiddles_y<B>, blocks(ny), dim3(256), 0, st, t.ytw, t.iytw, R, t.scratch);
+  if (tb == 2) { CM_TW(2) } else if (tb == 4) { CM_TW(4) } else if (tb == 16) { CM_TW(16) } else { CM_CHECK(tb == 8, "tw_batch: 2, 4, 8 or 16"); CM_TW(8) }
+#undef CM_TW
   CM_HIP(hipGetLastError());
 }
 Twiddles* twiddles_create(uint32_t R, hipStream_t st) {
