@@ -617,15 +617,19 @@ struct SegmentProver {
     // tree 1 first: its large transforms start as soon as the trace exists and keep the GPU busy while the host issues tree 0's
     // chain of small launches (enqueued first, that chain delayed the first tree-1 kernel by the host time of ~30 launches)
     const bool tree1_first = tune(T_TREE1_FIRST) != 0;   // A/B switch
-    if (build_tree0 && !tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, tree0_stream);
+    if (build_tree0 && !tree1_first && !(tune(T_TREE0_GUEST) != 0 && !pp_cache_enabled())) P.commit_enqueue(P.trees[0], &pp_evals, false, tree0_stream);
     P.trees[1].merkle.pace_ev = Prover::pace_event(1);
+    // (round 6) "tree0_guest": the seven preprocessed columns ride in tree 1's size-group launches (Prover::GuestTree) and only tree 0's
+    // Merkle launches run on its stream.  Not with the preprocessed cache on: a cached tree must own its device tables.
+    const bool tree0_guest = build_tree0 && tune(T_TREE0_GUEST) != 0 && !pp_cache_enabled();
     {
-      Prover::CommitPrep cp1 = P.commit_prepare(P.trees[1], &tr_evals, false, st, true, false, P.pipe_stream());
+      Prover::GuestTree guest{&P.trees[0], &pp_evals, tree0_stream};
+      Prover::CommitPrep cp1 = P.commit_prepare(P.trees[1], &tr_evals, false, st, true, false, P.pipe_stream(), nullptr, tree0_guest ? &guest : nullptr);
       ht.mark("trace_commit: tree 1 prepared");
       P.commit_launch(cp1);
       ht.mark("trace_commit: tree 1 launched");
     }
-    if (build_tree0 && tree1_first) P.commit_enqueue(P.trees[0], &pp_evals, false, tree0_stream);
+    if (build_tree0 && tree1_first && !tree0_guest) P.commit_enqueue(P.trees[0], &pp_evals, false, tree0_stream);
     ht.mark("trace_commit: tree 0 enqueued");
     // Root 0 first (transcript order, prover.rs:70-82: root 0, claim, root 1): tree 0 has been running on its side stream next
     // to all of the above; its root is copied on THAT stream and waited for here, while the GPU is still busy with tree 1.

@@ -159,6 +159,12 @@ struct Prover {
   // pointer tables, layer buffers, the launch plan) then runs while the LogUp kernels execute instead of between the LogUp tail
   // and the first transform (round-5 timeline: 50 us of idle GPU there).
   struct Grp { uint32_t log, n; size_t off; uint32_t n_early; };
+  // (round 6) GUEST columns: the columns of ANOTHER tree (the preprocessed tree next to the execution trace) ride in this tree's
+  // size-group launches — one more column in the y-dimension of launches that are there anyway, instead of a chain of ~12 small
+  // transform launches of its own on a side stream (a 2^18-row group of four columns is 64 blocks: a quarter of the chip for
+  // 0.16 ms at high priority, inside the throughput-bound part of tree 1's commitment).  The guest's Merkle tree stays its own
+  // (`stream`), launch by launch behind the size groups that carry its columns.
+  struct GuestTree { CommittedTree* t; ColumnSet* evals; hipStream_t stream; };
   struct CommitPrep {
     CommittedTree* t = nullptr;
     bool from_coeffs = false, with_merkle = true, evals_in_place = false;
@@ -171,15 +177,19 @@ struct Prover {
     SmallCommitJob* d_sjobs = nullptr;
     uint32_t small_max = 0;
     std::vector<MerkleTree::CommitLaunch> plan;
+    GuestTree guest{nullptr, nullptr, nullptr};
+    std::vector<MerkleTree::CommitLaunch> guest_plan;
   };
   void commit_enqueue(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true,
                       bool evals_in_place = false, hipStream_t s_tr = nullptr, const DeferredCols* defer = nullptr) {
-    CommitPrep cp = commit_prepare(t, evals, from_coeffs, s, with_merkle, evals_in_place, s_tr, defer);
+    CommitPrep cp = commit_prepare(t, evals, from_coeffs, s, with_merkle, evals_in_place, s_tr, defer, nullptr);
     commit_launch(cp);
   }
   // `defer->late` must be final; `defer->ready` may still be null (it is read by commit_launch)
   CommitPrep commit_prepare(CommittedTree& t, ColumnSet* evals, bool from_coeffs, hipStream_t s, bool with_merkle = true,
-                            bool evals_in_place = false, hipStream_t s_tr = nullptr, const DeferredCols* defer = nullptr) {
+                            bool evals_in_place = false, hipStream_t s_tr = nullptr, const DeferredCols* defer = nullptr,
+                            const GuestTree* guest = nullptr) {
+    CM_CHECK(!guest || (!from_coeffs && !defer && guest->t && guest->evals), "commit: guest columns ride with a tree committed from evaluations");
     const bool pipe_on = tune(T_COMMIT_PIPE) != 0;
     if (!pipe_on || !with_merkle || s_tr == s) s_tr = nullptr;
     CommitPrep cp;
@@ -202,18 +212,41 @@ struct Prover {
     for (auto& l : lde_logs) l += cfg.log_blowup_factor;
     t.lde.alloc(lde_logs, s, false);
     ub.add(t.lde.ptrs, &t.lde.d_view);
+    std::map<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> ggroups;   // guest columns by log
+    if (guest) {
+      cp.guest = *guest;
+      CommittedTree& gt = *guest->t;
+      const std::vector<uint32_t>& gl = guest->evals->logs;
+      gt.coeffs.alloc(gl, s, false);
+      ub.add(gt.coeffs.ptrs, &gt.coeffs.d_view);
+      std::vector<uint32_t> glde(gl);
+      for (auto& l : glde) l += cfg.log_blowup_factor;
+      gt.lde.alloc(glde, s, false);
+      ub.add(gt.lde.ptrs, &gt.lde.d_view);
+      ggroups = by_log(gl);
+      for (auto& kv : ggroups) groups[kv.first];   // a size only the guest has becomes a group of its own
+      std::vector<const uint32_t*> gcols(gt.lde.ptrs.begin(), gt.lde.ptrs.end());
+      gt.merkle.prepare(gcols, gt.lde.logs);
+      ub.add(gt.merkle.cols, &gt.merkle.d_cols_view);
+    }
     // pointer table of all size groups of the tree: [src | coeffs | lde] per group
     std::vector<Grp>& grps = cp.grps;
     std::vector<const uint32_t*> table;
     table.reserve(3 * logs.size());
     for (auto& kv : groups) {
-      Grp g{kv.first, (uint32_t)kv.second.size(), table.size(), (uint32_t)kv.second.size()};
+      const std::vector<uint32_t>* gi = nullptr;   // the guest's columns of this size
+      if (guest) { auto it = ggroups.find(kv.first); if (it != ggroups.end()) gi = &it->second; }
+      const uint32_t n_all = (uint32_t)(kv.second.size() + (gi ? gi->size() : 0));
+      Grp g{kv.first, n_all, table.size(), n_all};
       if (defer)
         g.n_early = (uint32_t)(std::stable_partition(kv.second.begin(), kv.second.end(), [&](size_t i) { return !defer->late[i]; }) -
                                kv.second.begin());
       for (auto i : kv.second) table.push_back(from_coeffs ? nullptr : evals->ptrs[i]);
+      if (gi) for (auto i : *gi) table.push_back(guest->evals->ptrs[i]);
       for (auto i : kv.second) table.push_back(t.coeffs.ptrs[i]);
+      if (gi) for (auto i : *gi) table.push_back(guest->t->coeffs.ptrs[i]);
       for (auto i : kv.second) table.push_back(t.lde.ptrs[i]);
+      if (gi) for (auto i : *gi) table.push_back(guest->t->lde.ptrs[i]);
       grps.push_back(g);
     }
     ub.add(table, &cp.d_table);
@@ -236,9 +269,17 @@ struct Prover {
         sjobs.push_back(SmallCommitJob{src, t.coeffs.ptrs[i], t.lde.ptrs[i], logs[i], inv_pow2[logs[i]]});
         cp.small_max = std::max(cp.small_max, logs[i]);
       }
+    if (guest)
+      for (size_t i = 0; i < guest->evals->logs.size(); i++) {
+        const uint32_t l = guest->evals->logs[i];
+        if (!small_commit_serves(l, cfg.log_blowup_factor)) continue;
+        sjobs.push_back(SmallCommitJob{guest->evals->ptrs[i], guest->t->coeffs.ptrs[i], guest->t->lde.ptrs[i], l, inv_pow2[l]});
+        cp.small_max = std::max(cp.small_max, l);
+      }
     if (!sjobs.empty()) ub.add(sjobs, &cp.d_sjobs);
     t.tables = ub.flush(s);   // ONE host->device copy for the whole tree
     if (with_merkle && s_tr) cp.plan = t.merkle.plan_commit();
+    if (guest) cp.guest_plan = guest->t->merkle.plan_commit();   // (behind the flush: the plan captures the device column table)
     return cp;
   }
   void commit_launch(CommitPrep& cp) {
@@ -273,6 +314,21 @@ struct Prover {
           waited = true;
         }
         t.merkle.run_launch(plan[next_launch++], s);
+      }
+    };
+    // the guest tree's Merkle launches whose columns all have at least 2^ready_log rows, on the guest's stream behind `ts`
+    size_t guest_next = 0;
+    auto guest_ready = [&](int ready_log) {
+      if (!cp.guest.t) return;
+      bool waited = false;
+      while (guest_next < cp.guest_plan.size() && cp.guest_plan[guest_next].lo >= ready_log) {
+        if (!waited) {
+          hipEvent_t e = pipe_event();
+          CM_HIP(hipEventRecord(e, ts));
+          CM_HIP(hipStreamWaitEvent(cp.guest.stream, e, 0));
+          waited = true;
+        }
+        cp.guest.t->merkle.run_launch(cp.guest_plan[guest_next++], cp.guest.stream);
       }
     };
     // the small columns (and the late ones of every group) need `defer->ready`: not in front of the first large group's early
@@ -327,12 +383,14 @@ struct Prover {
       for (size_t gj = gi + 1; gj < grps.size(); gj++)
         if (!small_commit_serves(grps[gj].log, cfg.log_blowup_factor)) { next_log = (int)(grps[gj].log + cfg.log_blowup_factor); break; }
       hash_ready(next_log + 1);
+      guest_ready(next_log + 1);
     }
     late_ready();
     if (with_merkle) {
       if (s_tr) hash_ready(0);   // (a tree of small columns only: nothing was hashed inside the loop)
       else t.merkle.commit_prepared(s);
     }
+    guest_ready(0);
   }
   // the stream the transforms of a pipelined commitment run on (a side stream of the calling thread; A/B: CM_PIPE_STREAM = index)
   static hipStream_t pipe_stream() {

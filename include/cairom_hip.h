@@ -398,7 +398,8 @@ int32_t cm_set_device_tail(int32_t on);
  * `logup_width`; 0..7 picks the side stream of the batched small LogUp launch), "quot_leaf" (1: the DEEP-quotient kernel of the largest
  * size group also writes the leaf hashes of the FRI first-layer tree), "shard_fri_stream" (1: cm_prove_sharded keeps its row-sharded
  * FRI layers on the stream — tree top and transcript step on the device, one host replay per proof), "shard_halo" (1: the previous-row
- * neighbours of a split component's cumulative-sum columns come from the two neighbouring row ranges instead of an all-gather), "fft_half_occ" (0; bit 0 / 1 =
+ * neighbours of a split component's cumulative-sum columns come from the two neighbouring row ranges instead of an all-gather), "tree0_guest"
+ * (0; 1 = the preprocessed columns are transformed inside the trace tree's size-group launches: measured neutral), "tw_batch" (8), "fft_half_occ" (0; bit 0 / 1 =
  * one 2^14-tile / four 2^12-tile transform blocks per CU instead of two / eight: measured slower, kept for A/B).
  * Test hook: "tail_grind_cap" (0 = off; v > 0 stops the device tail's proof-of-work search after 2^(v-1) nonces, so that the
  * host-driven fallback behind a missed nonce — probability e^-16 in production — can be exercised; same proof bytes).
