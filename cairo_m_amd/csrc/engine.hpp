@@ -193,7 +193,7 @@ enum TuneKey { T_OODS_POLL, T_OODS_HOST_WRITE, T_STAGE_COPY_KERNEL, T_STAGE_LAZY
                // test hook: > 0 caps the device tail's proof-of-work search at 2^(value-1) nonces so that the host fallback runs
                T_TAIL_GRIND_CAP,
                // round 6: launch order inside the fork regions
-               T_CONS_WIDE_FIRST, T_LOGUP_SMALL_STREAM, T_CONS_PLAN, T_QUOT_LEAF, T_SHARD_FRI_STREAM, T_FFT_HALF_OCC, T_SHARD_HALO, T_TW_BATCH, T_TREE0_GUEST, T_COUNT };
+               T_CONS_WIDE_FIRST, T_LOGUP_SMALL_STREAM, T_CONS_PLAN, T_QUOT_LEAF, T_SHARD_FRI_STREAM, T_FFT_HALF_OCC, T_SHARD_HALO, T_TW_BATCH, T_TREE0_GUEST, T_MERKLE_MULTI_TOP, T_COUNT };
 struct TuneEntry { const char* key; const char* env; int dflt, lo, hi; };
 extern const TuneEntry TUNE_TABLE[T_COUNT];
 std::atomic<int>* tune_values();

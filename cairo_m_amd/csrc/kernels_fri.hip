@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
 // can the two-rows kernel write the leaf hashes of this group?  (whole domain, the default two-rows form, a layer that is a launch
 // of its own in MerkleTree::plan_commit)
 bool quotient_leaf_serves(const QuotientArgs& a) {
-  return a.n_rows == 0 && a.row0 == 0 && a.log_size >= MERKLE_MULTI_MAX_TOP && tune(T_QUOT_ROWS) == 2 && a.entry_cols && a.n_batches >= 1 &&
+  return a.n_rows == 0 && a.row0 == 0 && a.log_size >= (uint32_t)tune(T_MERKLE_MULTI_TOP) && tune(T_QUOT_ROWS) == 2 && a.entry_cols && a.n_batches >= 1 &&
          a.n_batches <= 2;
 }
 void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st) {

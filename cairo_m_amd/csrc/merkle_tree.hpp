@@ -176,7 +176,7 @@ struct MerkleTree {
       if (log < 8) levels = 1;
       // big layers are throughput-bound: one node per thread with every lane busy beats the fused kernel
       // (whose parent levels run on half / quarter of the block); fusion pays only once launches are latency-bound
-      if (log >= (int)MERKLE_MULTI_MAX_TOP) levels = 1;
+      if (log >= tune(T_MERKLE_MULTI_TOP)) levels = 1;   // (default MERKLE_MULTI_MAX_TOP = 19; A/B: "merkle_multi_top")
       // a mid-size layer carrying many columns is one long compression chain per node: quad-lane kernel
       size_t n_here = 0;
       while (ci + n_here < cols.size() && col_logs[ci + n_here] == (uint32_t)log) n_here++;

@@ -518,3 +518,36 @@ def test_pool_trim_releases_parked_teardown(backend):
         assert f2.value + (8 << 20) >= f0.value, (f0.value, f1.value, f2.value)
     finally:
         inp.free()
+
+
+# (key, alternative value, default): every switch of include/cairom_hip.h's cm_set_tuning list that selects a different CODE PATH
+_TUNING_ALTERNATIVES = [
+    ("quot_leaf", 0, 1), ("cons_wide_first", 0, 1), ("tree0_guest", 1, 0), ("logup_small_stream", 5, -1), ("cons_plan", 0o01537426, 0o01237456),
+    ("fft_half_occ", 3, 0), ("tw_batch", 4, 8), ("merkle_multi_top", 21, 19), ("fri_top_fuse", 0, 1), ("fri_fold_leaf", 0, 1), ("fft_fused", 0, 1),
+    ("commit_pipe", 0, 1), ("trace_hist_fuse", 0, 1), ("logup_defer", 0, 1), ("flag_join", 0, 1), ("flag_fork", 0, 1), ("defer_teardown", 0, 1),
+    ("quot_rows", 1, 2), ("merkle_npw", 0, -1), ("tree0_prio", 0, -1), ("pp_side", 0, 1), ("oods_split", 1000, 780), ("fft_chunk_mb", 100, 0),
+]
+
+
+@pytest.mark.parametrize("key,alt,dflt", _TUNING_ALTERNATIVES, ids=[k for k, _, _ in _TUNING_ALTERNATIVES])
+def test_every_tuning_switch_keeps_the_proof_bytes(backend, key, alt, dflt):
+    """cm_set_tuning: "every form produces the same proof bytes".  One proof with the switch at its alternative value (the code path the
+    default run never takes — among them the round-6 ones: separate first-layer leaf launch, guest columns of tree 0, other stream plans,
+    half-occupancy transforms) must equal, word for word, the proof of the same input with every switch at its default."""
+    import ctypes as C
+    L = backend.L
+    inp = synth_fibonacci(30_000)
+    try:
+        assert L.cm_set_tuning(key.encode(), C.c_int32(dflt)) == 0
+        p0 = backend.prove(inp)
+        want = p0.words().copy()
+        p0.free()
+        assert L.cm_set_tuning(key.encode(), C.c_int32(alt)) == 0
+        for _ in range(2):   # (twice: a switch may change what a finished proof parks for its successor)
+            p1 = backend.prove(inp)
+            got = p1.words()
+            assert got.size == want.size and np.array_equal(got, want), key
+            p1.free()
+    finally:
+        L.cm_set_tuning(key.encode(), C.c_int32(dflt))
+        inp.free()

@@ -22,7 +22,7 @@ dev = be.upload_input(synth_fibonacci(a.fib_n))
 
 PH = {}
 DEFAULTS = [("oods_split", 780), ("merkle_npw", -1), ("fork_width", 0), ("tree0_prio", -1), ("logup_width", 4), ("quot_rows", 2),
-            ("fft_chunk_mb", 0), ("pace", -1), ("cons_plan", 0o01237456), ("logup_small_stream", -1), ("tail_grind_cap", 0), ("tw_batch", 8), ("fft_half_occ", 0)]   # every other switch defaults to 1
+            ("fft_chunk_mb", 0), ("pace", -1), ("cons_plan", 0o01237456), ("logup_small_stream", -1), ("tail_grind_cap", 0), ("tw_batch", 8), ("fft_half_occ", 0), ("tree0_guest", 0), ("merkle_multi_top", 19)]   # every other switch defaults to 1
 
 
 def block(tag=None):
