@@ -41,7 +41,9 @@ typedef uint64_t cm_stream_t;
 int32_t cm_init(int32_t device);
 int32_t cm_shutdown(void);
 /* Returns the calling host thread's cached device blocks to the driver (the per-thread pool otherwise keeps the high-water
- * mark of the largest segment proved: a 2^26-row segment leaves ~116 GiB cached). */
+ * mark of the largest segment proved: a 2^26-row segment leaves ~116 GiB cached) — including what the thread's last proof parked
+ * for its successor (the FRI phase and quotient columns of the deferred teardown: round 6; cm_shutdown and the pool's own
+ * out-of-memory retry release them too). */
 int32_t cm_pool_trim(void);
 /* Free / total bytes of the library device's HBM (hipMemGetInfo): segment sizing for the 288 GB of an MI355X. */
 int32_t cm_device_mem_info(uint64_t* free_bytes, uint64_t* total_bytes);
