@@ -164,16 +164,10 @@ struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
     ed[0] = den; em[0] = mult; cnt++;
     if (cnt == GE) flush();
   }
-  // an odd entry count leaves a last batch of ONE entry (Stwo's finalize_logup_in_pairs): it is paired with a zero fraction 0 / 1, so
-  // that every group — the last one too — is whole pairs with the OLDER entry of a pair in the odd slot of the shift register
-  __device__ __forceinline__ void finalize_pairs() {
-    if (cnt & 1) {
-#pragma unroll
-      for (int k = GE - 1; k > 0; k--) { ed[k] = ed[k - 1]; em[k] = em[k - 1]; }
-      ed[0] = QM31(M31(1)); em[0] = M31(0); cnt++;
-    }
-    flush();
-  }
+  // an odd entry count leaves a last batch of ONE entry (Stwo's finalize_logup_in_pairs): flush() pairs from the OLDEST entry on, so
+  // with an odd count the pairs sit in slots (n-1, n-2) ... (2, 1) and the single entry in slot 0; groups in the middle of a stream
+  // are always GE (even) entries
+  __device__ __forceinline__ void finalize_pairs() { flush(); }
   __device__ __forceinline__ void finalize_single() { finalize_pairs(); }
   __device__ void emit_batch(bool, QM31, QM31) {}   // (unused: the entries never reach LogupStream's pairing)
   __device__ __forceinline__ void flush() {
@@ -209,11 +203,13 @@ struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
         const CM31 ti(t[k].a * nm, -(t[k].b * nm));                       // m / norm_u(d)
         fr[k] = QM31(ed[k].a * ti, -(ed[k].b * ti));                      // m conj_u(d) / norm_u(d)
       }
-    // oldest entry first: slots n-1, n-2 make the first batch (n is even: finalize_pairs pads an odd stream)
+    // oldest entry first: slots n-1, n-2 make the first batch; an odd n (only in a component's last group) ends on the single slot 0
+    const int odd = n & 1;
 #pragma unroll
-    for (int k = GE - 1; k >= 1; k -= 2)
-      if (k < n) {
-        const QM31 v = prev + fr[k] + fr[k - 1];
+    for (int k = GE - 1; k >= 0; k--)
+      if (k < n && ((n - 1 - k) & 1) == 0) {   // k = the older slot of a pair, or the single slot 0 of an odd group
+        const bool single = odd && k == 0;
+        const QM31 v = single ? prev + fr[0] : prev + fr[k] + fr[k > 0 ? k - 1 : 0];
         CM_GCOL_W(out[4 * batch + 0])[row] = v.a.a.v;
         CM_GCOL_W(out[4 * batch + 1])[row] = v.a.b.v;
         CM_GCOL_W(out[4 * batch + 2])[row] = v.b.a.v;
