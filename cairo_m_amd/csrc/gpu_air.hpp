@@ -179,10 +179,25 @@ struct LogupEval : air::LogupStream<LogupEval, M31, QM31> {
 #pragma unroll
     for (int k = 0; k < GE; k++)
       if (k < n) {
-        t[k] = ed[k].a * ed[k].a - mul_R(ed[k].b * ed[k].b);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CM_LOGUP_NORM_PLAIN)
+        {
+          // norm_u(d) = a^2 - R b^2 with a = a0 + a1 i, b = b0 + b1 i, R = 2 + i, as ONE unreduced 64-bit sum per coordinate (signs folded
+          // into the operands as P - x, doubled terms as doubled operands < 2^32; a lazy fold wherever more than four product-units meet):
+          //   re = a0^2 - a1^2 - 2 b0^2 + 2 b1^2 + 2 b0 b1        im = 2 a0 a1 - b0^2 + b1^2 - 4 b0 b1
+          // 10 multiply-adds, 2 lazy folds, 2 Mersenne folds — against two lazy CM31 products (8 + 4 folds), mul_R and a modular subtraction
+          typedef unsigned long long u64;
+          const u64 a0 = ed[k].a.a.v, a1 = ed[k].a.b.v, b0 = ed[k].b.a.v, b1 = ed[k].b.b.v;
+          const u64 na1 = P - ed[k].a.b.v, nb0 = P - ed[k].b.a.v;
+          const uint32_t b0d = ed[k].b.a.v << 1, b1d = ed[k].b.b.v << 1, a1d = ed[k].a.b.v << 1;
+          u64 re = a0 * a0 + na1 * a1 + nb0 * b0d;                 // 1 + 1 + 2 units
+          re = m31_fold_lazy(re) + b1 * b1d + b0 * b1d;            // + 2 + 2 units
+          u64 im = a0 * a1d + nb0 * b0 + b1 * b1;                  // 2 + 1 + 1 units
+          im = m31_fold_lazy(im) + nb0 * b1d + nb0 * b1d;          // + 2 + 2 units  (-4 b0 b1)
+          t[k] = CM31(m31_fold64(re), m31_fold64(im));
+        }
         nr[k] = m31_fold64((unsigned long long)t[k].a.v * t[k].a.v + (unsigned long long)t[k].b.v * t[k].b.v);
 #else
+        t[k] = ed[k].a * ed[k].a - mul_R(ed[k].b * ed[k].b);
         nr[k] = t[k].a * t[k].a + t[k].b * t[k].b;
 #endif
         pre[k] = k == 0 ? nr[0] : pre[k - 1] * nr[k];
