@@ -72,3 +72,43 @@ def test_plan_follows_the_pcs_config_and_checks_capacities():
         assert rc == 1 and list(tr) == [77] * 8
     finally:
         inp.free()
+
+
+def test_previous_row_halo_neighbours():
+    """The sharded prover's halo (prover_sharded.inc, k_halo_build): on bit-reversed storage of the evaluation domain (log n, trace log
+    n - 1) the previous trace row of every EVEN local position of rank R's row range lies in the range of rank bitrev(bitrev(R) - 1),
+    of every ODD position in the range of rank bitrev(bitrev(R) + 1), at a local position of the same parity — so the even half of a
+    rank's slice goes to one neighbour, the odd half to the other, and nothing else is needed.  Model of cm::shifted_row
+    (device_common.hpp), exhaustive for 2 / 4 / 8 ranks at three sizes."""
+    def brev(i, log):
+        r = 0
+        for b in range(log):
+            r |= ((i >> b) & 1) << (log - 1 - b)
+        return r
+
+    def shifted_row(r, n, trace_log, offset):
+        i = brev(r, n)
+        half = 1 << (n - 1)
+        mask = (1 << (n + 1)) - 1
+        e = (1 + 4 * i) if i < half else (-(1 + 4 * (i - half))) & 0xffffffff
+        e = (e + offset * (1 << (n + 1 - trace_log))) & mask
+        j = (e - 1) // 4 if (e & 3) == 1 else half + (((mask + 1) - e - 1) & mask) // 4
+        return brev(j, n)
+
+    for n in (6, 9, 11):
+        for log_ranks in (1, 2, 3):
+            N, L = 1 << log_ranks, 1 << (n - log_ranks)
+            for R in range(N):
+                rho = brev(R, log_ranks)
+                src_even, src_odd = brev((rho - 1) % N, log_ranks), brev((rho + 1) % N, log_ranks)
+                seen = {src_even: set(), src_odd: set()}
+                for q in range(L):
+                    pr = shifted_row(R * L + q, n, n - 1, -1)
+                    owner, qp = pr >> (n - log_ranks), pr & (L - 1)
+                    assert owner == (src_odd if q & 1 else src_even) and (qp & 1) == (q & 1), (n, N, R, q)
+                    seen[owner].add(qp)
+                # every row of the two halves is needed exactly once: the exchange moves no word twice and none in vain
+                if src_even != src_odd:
+                    assert seen[src_even] == set(range(0, L, 2)) and seen[src_odd] == set(range(1, L, 2))
+                else:
+                    assert seen[src_even] == set(range(L))
