@@ -98,7 +98,7 @@ __device__ __forceinline__ void mix_u64_dev(const uint32_t (&dg)[8], uint64_t v,
 // Lane q of a quad holds column q of the 4x4 state (a = v[q], b = v[4+q], c = v[8+q], d = v[12+q]); the
 // diagonal step rotates b, c, d by 1, 2, 3 lanes with DPP quad_perm moves.  Every lane keeps all 16 message
 // words (the 4 lanes of a quad load the same addresses: one fetch) and selects its two words per G with
-// lane-id selects.  ~1.4 us per compression (tools/merkle_lab.hip), bit-identical to b2s_compress.
+// lane-id selects.  ~1.4 us per compression (tools/chain_lab.hip), bit-identical to b2s_compress.
 #define CM_QP(p0, p1, p2, p3) ((p0) | ((p1) << 2) | ((p2) << 4) | ((p3) << 6))
 #define CM_QUAD_ROT(x, ctrl) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), (ctrl), 0xf, 0xf, true))
 __device__ __forceinline__ uint32_t b2s_sel4(uint32_t q, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {

@@ -1,5 +1,5 @@
 // Merkle layer kernels for gfx950 (Blake2s, Stwo MerkleOps<Blake2sMerkleHasher>::commit_on_layer framing).
-// Kept in a header so that tools/merkle_lab.hip can time variants against exactly the shipped kernels.
+// Kept in a header so that a lab (tools/*_lab.hip) can time variants against exactly the shipped kernels.
 #pragma once
 #include "blake2s_dev.hpp"
 #include "engine.hpp"
