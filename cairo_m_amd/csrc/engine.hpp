@@ -128,6 +128,8 @@ void merkle_top(MerkleTopArgs& a, hipStream_t st);   // fills a.ticket
 void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log, hipStream_t st);
 // sharded FRI layer (kernels_hash.hip k_shard_top_step): N gathered sub-roots -> top levels -> root -> mix_root + draw_felt on d_chan
 void shard_top_step(const uint32_t* d_sub, uint32_t n, uint32_t* d_chan, uint32_t* d_felt_out, uint32_t* d_root_log, uint32_t* d_sub_log, hipStream_t st);
+// the top levels alone (kernels_hash.hip k_shard_top): N gathered sub-roots -> root (8 words at d_root_out), sub-roots kept at d_sub_log
+void shard_top(const uint32_t* d_sub, uint32_t n, uint32_t* d_root_out, uint32_t* d_sub_log, hipStream_t st);
 // same, with the channel state {digest[8], n_sent} passed in the kernel arguments and stored to d_chan first
 void chan_init_mix_root_draw(const uint32_t init9[9], uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log,
                              hipStream_t st);
@@ -193,7 +195,7 @@ enum TuneKey { T_OODS_POLL, T_OODS_HOST_WRITE, T_STAGE_COPY_KERNEL, T_STAGE_LAZY
                // test hook: > 0 caps the device tail's proof-of-work search at 2^(value-1) nonces so that the host fallback runs
                T_TAIL_GRIND_CAP,
                // round 6: launch order inside the fork regions
-               T_CONS_WIDE_FIRST, T_LOGUP_SMALL_STREAM, T_CONS_PLAN, T_QUOT_LEAF, T_SHARD_FRI_STREAM, T_FFT_HALF_OCC, T_SHARD_HALO, T_TW_BATCH, T_TREE0_GUEST, T_MERKLE_MULTI_TOP, T_COUNT };
+               T_CONS_WIDE_FIRST, T_LOGUP_SMALL_STREAM, T_CONS_PLAN, T_QUOT_LEAF, T_SHARD_FRI_STREAM, T_FFT_HALF_OCC, T_SHARD_HALO, T_TW_BATCH, T_TREE0_GUEST, T_MERKLE_MULTI_TOP, T_SHARD_TREE_STREAM, T_SHARD_FRI_STOP_LOG, T_COUNT };
 struct TuneEntry { const char* key; const char* env; int dflt, lo, hi; };
 extern const TuneEntry TUNE_TABLE[T_COUNT];
 std::atomic<int>* tune_values();

@@ -70,6 +70,28 @@ __global__ void __launch_bounds__(64) k_shard_top_step(const uint32_t* __restric
   if (t < 4) chan_mix_root_draw_quad(t, chan, nodes[cur], felt_out, root_log, x8, felt);
 }
 
+// The same top levels WITHOUT a transcript step (sharded trees 1 / 2 / 3, round 6): root -> `root_out` (8 words), the sub-roots ->
+// `sub_log`; the transcript kernels of the single-GPU prover (k_step_pow_relations, k_chan_init_mix_root_draw, k_chan_mix_root_draw)
+// then read the root from device memory exactly as they read a whole tree's layer 0.
+__global__ void __launch_bounds__(64) k_shard_top(const uint32_t* __restrict__ sub, uint32_t n, uint32_t* __restrict__ root_out, uint32_t* __restrict__ sub_log) {
+  __shared__ uint32_t nodes[2][8 * 8];
+  const uint32_t t = threadIdx.x;
+  for (uint32_t i = t; i < 8 * n; i += 64) { const uint32_t w = sub[i]; nodes[0][i] = w; sub_log[i] = w; }
+  __syncthreads();
+  uint32_t cur = 0;
+  for (uint32_t m = n; m > 1; m >>= 1) {
+    if (t < m / 2) {
+      uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, msg[16];
+      for (int k = 0; k < 16; k++) msg[k] = nodes[cur][16 * t + k];
+      b2s_compress(h, msg);
+      for (int k = 0; k < 8; k++) nodes[cur ^ 1][8 * t + k] = h[k];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (t < 8) root_out[t] = nodes[cur][t];
+}
+
 // powers[g] = rho^(n - 1 - g): the random-coefficient powers of the composition polynomial, one thread per power (square and
 // multiply), from the coefficient the device-side transcript step (k_chan_mix_root_draw) left in device memory
 __global__ void __launch_bounds__(256) k_coeff_powers(const uint32_t* __restrict__ rho4, uint32_t* __restrict__ powers, uint32_t n) {
@@ -221,6 +243,11 @@ void chan_mix_root_draw(uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_fe
 void shard_top_step(const uint32_t* d_sub, uint32_t n, uint32_t* d_chan, uint32_t* d_felt_out, uint32_t* d_root_log, uint32_t* d_sub_log, hipStream_t st) {
   CM_CHECK(n >= 1 && n <= 8 && (n & (n - 1)) == 0, "shard_top_step: rank count");
   hipLaunchKernelGGL(k_shard_top_step, dim3(1), dim3(64), 0, st, d_sub, n, d_chan, d_felt_out, d_root_log, d_sub_log);
+  CM_HIP(hipGetLastError());
+}
+void shard_top(const uint32_t* d_sub, uint32_t n, uint32_t* d_root_out, uint32_t* d_sub_log, hipStream_t st) {
+  CM_CHECK(n >= 1 && n <= 8 && (n & (n - 1)) == 0, "shard_top: rank count");
+  hipLaunchKernelGGL(k_shard_top, dim3(1), dim3(64), 0, st, d_sub, n, d_root_out, d_sub_log);
   CM_HIP(hipGetLastError());
 }
 void chan_init_mix_root_draw(const uint32_t init9[9], uint32_t* d_chan, const uint32_t* d_root, uint32_t* d_felt_out, uint32_t* d_root_log,

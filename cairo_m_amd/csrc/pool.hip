@@ -207,6 +207,7 @@ const TuneEntry TUNE_TABLE[T_COUNT] = {
     {"shard_fri_stream", "CM_SHARD_FRI_STREAM", 1, 0, 1}, {"fft_half_occ", "CM_FFT_HALF_OCC", 0, 0, 3},
     {"shard_halo", "CM_SHARD_HALO", 1, 0, 1},           {"tw_batch", "CM_TW_BATCH", 8, 2, 16},
     {"tree0_guest", "CM_TREE0_GUEST", 0, 0, 1},         {"merkle_multi_top", "CM_MERKLE_MULTI_TOP", 19, 17, 23},
+    {"shard_tree_stream", "CM_SHARD_TREE_STREAM", 1, 0, 1}, {"shard_fri_stop_log", "CM_SHARD_FRI_STOP_LOG", 16, 0, 99},
 };
 std::atomic<int>* tune_values() {
   static std::atomic<int>* v = [] {
