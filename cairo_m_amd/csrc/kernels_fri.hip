@@ -519,8 +519,12 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTailArgs a) {
 // ================================================================= host wrappers
 // can the two-rows kernel write the leaf hashes of this group?  (whole domain, the default two-rows form, a layer that is a launch
 // of its own in MerkleTree::plan_commit)
+// (a row range — the sharded prover's slice — is served like the whole domain: the kernel indexes columns, outputs and leaf hashes
+// by the LOCAL row and only takes the domain point at row0 + row; the range must be a power of two of at least 2^merkle_multi_top
+// rows, so that the leaf layer of the local subtree is a launch of its own)
 bool quotient_leaf_serves(const QuotientArgs& a) {
-  return a.n_rows == 0 && a.row0 == 0 && a.log_size >= (uint32_t)tune(T_MERKLE_MULTI_TOP) && tune(T_QUOT_ROWS) == 2 && a.entry_cols && a.n_batches >= 1 &&
+  const uint32_t n = a.n_rows ? a.n_rows : (1u << a.log_size);
+  return (n & (n - 1)) == 0 && n >= (1u << tune(T_MERKLE_MULTI_TOP)) && a.row0 % n == 0 && tune(T_QUOT_ROWS) == 2 && a.entry_cols && a.n_batches >= 1 &&
          a.n_batches <= 2;
 }
 void launch_quotients(const QuotientArgs& a, double n_cols, hipStream_t st) {
