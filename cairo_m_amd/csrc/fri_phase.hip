@@ -73,6 +73,10 @@ void FriPhase::commit_enqueue(Prover& P, const cm_pcs_config& cfg, std::vector<C
         for (size_t k = had_leaf ? 1 : 0; k < plan.size(); k++) first_tree.run_launch(plan[k], st);
       }
       if (!first_tree.top_launch_has_extras) chan_mix_root_draw(d_chan.u32(), first_tree.layers[0].u32(), d_alphas.u32(), d_roots.u32(), st);
+    } else if (resume->d_chan) {
+      CM_CHECK(resume->d_alpha_c != nullptr, "fri: a resumed commit needs both device sources");
+      CM_HIP(hipMemcpyAsync(d_chan.p, resume->d_chan, 9 * 4, hipMemcpyDeviceToDevice, st));        // (over the stale upload of P.ch above)
+      CM_HIP(hipMemcpyAsync(d_alphas.p, resume->d_alpha_c, 16, hipMemcpyDeviceToDevice, st));   // slot 0 = the circle-fold challenge
     } else {
       uint32_t a4[4];
       resume->alpha_c.to_u32(a4);

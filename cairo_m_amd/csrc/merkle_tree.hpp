@@ -45,8 +45,12 @@ struct GatherBatch {
     run_words += n_cols;
     return off;
   }
-  void run(hipStream_t st) {
-    // one upload (all address tables), three gather launches into one output buffer, ONE device->host copy
+  size_t total_words() const { return word_addrs.size() + hash_addrs.size() * 8 + run_words; }
+  // one upload (all address tables), three gather launches into one output buffer, ONE device->host copy into `land` (pinned host
+  // memory of at least total_words() words, or null = the thread's landing buffer); no wait: the results are valid once the stream
+  // has passed this point.  The device buffers stay with the batch.
+  DevBuf tables_, out_;
+  void enqueue(hipStream_t st, uint32_t* land = nullptr) {
     const size_t nw = word_addrs.size(), nh = hash_addrs.size() * 8, nr = run_words, total = nw + nh + nr;
     if (!total) return;
     UploadBatch ub;
@@ -56,15 +60,22 @@ struct GatherBatch {
     if (nw) ub.add(word_addrs, &d_w);
     if (nh) ub.add(hash_addrs, &d_h);
     if (nr) ub.add(runs, &d_r);
-    DevBuf tables = ub.flush(st), out(total * 4);
-    if (nw) gather_words(d_w, (uint32_t)word_addrs.size(), 1, out.u32(), st);
-    if (nh) gather_words(d_h, (uint32_t)hash_addrs.size(), 8, out.u32() + nw, st);
-    if (nr) gather_runs(d_r, (uint32_t)runs.size(), out.u32() + nw + nh, st);
-    const uint32_t* host = (const uint32_t*)stage_download_async(out.p, total * 4, st);
-    CM_HIP(hipStreamSynchronize(st));
+    tables_ = ub.flush(st);
+    out_.alloc(total * 4);
+    if (nw) gather_words(d_w, (uint32_t)word_addrs.size(), 1, out_.u32(), st);
+    if (nh) gather_words(d_h, (uint32_t)hash_addrs.size(), 8, out_.u32() + nw, st);
+    if (nr) gather_runs(d_r, (uint32_t)runs.size(), out_.u32() + nw + nh, st);
+    const uint32_t* host;
+    if (land) { CM_HIP(hipMemcpyAsync(land, out_.p, total * 4, hipMemcpyDeviceToHost, st)); host = land; }
+    else host = (const uint32_t*)stage_download_async(out_.p, total * 4, st);
     words = host;
     hashes = host + nw;
     run_out = host + nw + nh;
+  }
+  void run(hipStream_t st) {
+    if (!total_words()) return;
+    enqueue(st);
+    CM_HIP(hipStreamSynchronize(st));
   }
 };
 

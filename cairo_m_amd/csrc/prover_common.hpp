@@ -531,6 +531,11 @@ struct FriResume {
   size_t qi = 0;                // first quotient group that is not folded yet
   uint32_t n_inner_before = 0;  // inner layers committed before `layer_log` (their queries are folded away in plan_decommit)
   QM31 alpha_c;                 // the circle-fold challenge (the first FRI challenge)
+  // device sources (both or none): the layers in front ran their transcript steps on the device and the host has NOT replayed them
+  // yet — the device channel {digest[8], n_sent} and the circle-fold challenge are copied from here on the stream, P.ch is stale
+  // until the caller's replay (which must run before commit_finish)
+  const uint32_t* d_chan = nullptr;
+  const uint32_t* d_alpha_c = nullptr;
 };
 struct FriPhase {
   struct InnerLayer {

@@ -402,7 +402,10 @@ int32_t cm_set_device_tail(int32_t on);
  * FRI layers on the stream — tree top and transcript step on the device, one host replay per proof), "shard_halo" (1: the previous-row
  * neighbours of a split component's cumulative-sum columns come from the two neighbouring row ranges instead of an all-gather), "tree0_guest"
  * (0; 1 = the preprocessed columns are transformed inside the trace tree's size-group launches: measured neutral), "tw_batch" (8), "fft_half_occ" (0; bit 0 / 1 =
- * one 2^14-tile / four 2^12-tile transform blocks per CU instead of two / eight: measured slower, kept for A/B).
+ * one 2^14-tile / four 2^12-tile transform blocks per CU instead of two / eight: measured slower, kept for A/B), "shard_tree_stream" (1:
+ * cm_prove_sharded keeps the transcript steps behind its four commitment trees on the stream — tree top on the device, the single-GPU
+ * prover's step kernels, host replay at the two waits that are left before FRI; 0 = a host round trip per root), "shard_fri_stop_log"
+ * (16: FRI layers of at most 2^v rows are gathered and finished on every rank; 99 = FRI not sharded; also CM_SHARD_FRI_STOP_LOG).
  * Test hook: "tail_grind_cap" (0 = off; v > 0 stops the device tail's proof-of-work search after 2^(v-1) nonces, so that the
  * host-driven fallback behind a missed nonce — probability e^-16 in production — can be exercised; same proof bytes).
  * status 1 for an unknown key or a value outside the key's range.  Flip a switch only while no proof is running in the process: a

@@ -73,6 +73,30 @@ def test_sharded_fri_layers_by_row_range(backend, oracle, tmp_path, world, fib_n
     inp.free()
 
 
+@pytest.mark.parametrize("world,fib_n,env", [
+    (2, 30_000, {"CM_SHARD_TREE_STREAM": "0"}),
+    (4, 3_000, {"CM_SHARD_TREE_STREAM": "0", "CM_SHARD_FRI_STREAM": "0", "CM_SHARD_SPLIT_MIN_LOG": "6", "CM_SHARD_FRI_STOP_LOG": "8"}),
+    (2, 30_000, {"CM_SHARD_FRI_STREAM": "0", "CM_SHARD_FRI_STOP_LOG": "9"}),
+    (8, 30_000, {"CM_SHARD_TREE_STREAM": "1", "CM_SHARD_SPLIT_MIN_LOG": "7", "CM_SHARD_FRI_STOP_LOG": "9", "CM_QUOT_LEAF": "0"}),
+])
+def test_sharded_transcript_forms(backend, oracle, tmp_path, world, fib_n, env):
+    """The transcript steps of the sharded prover either stay on the stream (device tree top + the single-GPU prover's step
+    kernels, host replay at the next wait: "shard_tree_stream" for the four commitment trees, "shard_fri_stream" for the FRI layers;
+    the default) or go through the host after every tree (0).  Every combination gives the single-GPU proof."""
+    inp = synth_fibonacci(fib_n)
+    p = backend.prove(inp)
+    want = p.words().copy()
+    p.free()
+    out = str(tmp_path / "proof")
+    log = _run_sharded(world, fib_n, out, extra_env=env)
+    for r in range(world):
+        got = np.load(f"{out}.{r}.npy")
+        assert got.size == want.size, (r, got.size, want.size, log[-500:])
+        diff = np.nonzero(got != want)[0]
+        assert diff.size == 0, f"rank {r}: first differing words {diff[:8]} of {got.size}"
+    inp.free()
+
+
 @pytest.mark.parametrize("world,fib_n,min_log", [(2, 200, 5), (4, 3_000, 6), (8, 30_000, 7), (4, 100_000, 12), (2, 30_000, 99)])
 def test_split_components_by_rows_and_columns(backend, oracle, tmp_path, world, fib_n, min_log):
     """Large opcode components are SPLIT over the ranks (ShardPlan): trace rows, lookup histograms, LogUp rows and constraint
