@@ -15,6 +15,7 @@ import ctypes as C
 import datetime
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -295,6 +296,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-timeout", type=int, default=300, help="N > 1: time limit in seconds of the sharded-mode child job")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the second mode (one proof sharded over all ranks)")
+    ap.add_argument("--sharded-one-rank-blocks", type=int, default=4,
+                    help="N = 1: alternating block pairs of the `sharded_one_rank` leg (cm_prove_sharded with one rank against the single-GPU prover); 0 = skip")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive `end_to_end` measurements")
     ap.add_argument("--no-kprof", action="store_true", help="debug: no in-library HIP-event kernel timing")
     ap.add_argument("--inflight", type=int, default=1,
@@ -328,6 +331,12 @@ def main():
                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # The contract is ONE JSON line on stdout.  Libraries write there too (this image's librccl prints a version banner from its C
+    # stdio buffer when its first communicator is created): keep the real stdout for the line and send everything else that is
+    # written to file descriptor 1 — by this process or its children — to stderr.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     dist = None
     if world > 1:
@@ -566,6 +575,51 @@ def main():
         p.free()
         if not verified:
             sys.exit(f"bench.py: the HIP proof of the bench workload does not verify: {verr}")
+    sharded_one = None
+    if rank == 0 and world == 1 and args.sharded_one_rank_blocks > 0:
+        # SURVEY 8e-2 on the one GPU there is: the SAME segment through cm_prove_sharded with ONE rank (the in-library stream-ordered
+        # RCCL communicator, world = 1) in blocks alternating with the single-GPU prover inside this process — what the sharded
+        # path costs by itself (collective plumbing, sub-root gathers, host-planned decommitment), before any rank is added.
+        # A failure here costs only this object.
+        try:
+            import numpy as np
+            from cairo_m_amd.sharded import RcclComm, prove_sharded, shard_plan
+            _, s_words = shard_plan(inp, 1, be.L, None)
+            idb = (C.c_uint8 * 128)()
+            be._ck(be.L.cm_rccl_unique_id(idb))
+            comm = RcclComm(be, s_words, rank=0, world=1, id_bytes=bytes(idb))
+            ps = prove_sharded(be, dev, comm)
+            s_same = bool(ps.words().size == hip_words.size and np.array_equal(ps.words(), hip_words))
+            ps.free()
+
+            def s_block(sh, n=4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    (prove_sharded(be, dev, comm) if sh else be.prove_device(dev)).free()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+            for _ in range(2):
+                s_block(True); s_block(False)
+            t_sh, t_one = [], []
+            for r in range(args.sharded_one_rank_blocks):
+                for sh in ((False, True) if r % 2 == 0 else (True, False)):
+                    s_block(sh, 2)   # untimed after every switch
+                    (t_sh if sh else t_one).append(s_block(sh))
+            ps = prove_sharded(be, dev, comm)   # (a warm proof's GPU-side phase times)
+            s_phases = {k: round(v, 3) for k, v in ps.stats()["phase_ms"].items()}
+            ps.free()
+            comm.free()
+            be.pool_trim()
+            sharded_one = {"ms_per_proof": statistics.median(t_sh), "single_gpu_ms_same_process": statistics.median(t_one),
+                           "paired_difference_ms": statistics.median([x - y for x, y in zip(t_sh, t_one)]),
+                           "blocks": args.sharded_one_rank_blocks, "proofs_per_block": 4, "world": 1, "comm": "in-library RCCL (stream-ordered)",
+                           "bit_identical_to_single_gpu_proof": s_same, "phase_ms": s_phases,
+                           "note": "cm_prove_sharded with one rank against cm_prove_device in alternating blocks of lone proofs inside this "
+                                   "process: the sharded path's own overhead (not a scaling figure; the multi-rank figures are the `sharded` "
+                                   "object of a --gpus N run)"}
+        except Exception as e:   # noqa: BLE001 — the bench line must survive
+            sharded_one = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_end_to_end:
         # PCIe-inclusive figures (never `value`): (a) cm_prove_segment from a host ProverInput = upload + prove;
         # (b) runner segment (trace + memory log in host memory) -> device adapter -> prove
@@ -690,7 +744,7 @@ def main():
                                "(constraints ... decommit phases of the last timed proof)"},
                "gpu_idle_traced": traced_idle(),
                "alt_reading": alt,
-               "phase_ms": phases, "roofline": roofline, "pipelined": pipelined, "with_cached_setup": cached_setup, "sharded": sharded, "end_to_end": end_to_end,
+               "phase_ms": phases, "roofline": roofline, "pipelined": pipelined, "with_cached_setup": cached_setup, "sharded": sharded, "sharded_one_rank": sharded_one, "end_to_end": end_to_end,
                "proof_verified": verified}
         if world == 1 and not args.no_cpu_baseline:
             same = args.cpu_sample_n == args.fib_n
@@ -704,12 +758,12 @@ def main():
                 except (OSError, ValueError):
                     pass
             if parity is False:
-                print(json.dumps(out))
+                print(json.dumps(out), file=line_out, flush=True)
                 sys.exit("bench.py: the HIP proof differs from the CPU oracle's proof of the same input")
         else:
             out["cpu_baseline"] = None
             out["parity_at_metric_config"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), file=line_out, flush=True)
     be.free_input(dev)
     inp.free()
     if dist is not None:

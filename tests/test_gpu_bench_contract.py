@@ -49,6 +49,10 @@ def test_single_gpu_line():
     assert abs(sum(x["bytes_per_cell"] for x in r["stages"]) - 52.0) < 1e-9 and all(0 < x["frac"] < 1 for x in r["stages"])
     latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().split()[0]
     assert r["traffic_source"] is None or os.path.basename(r["traffic_source"]).startswith(latest + "_")
+    # round 6: the same segment through cm_prove_sharded with one rank (in-library RCCL communicator), next to the single-GPU prover
+    so = d["sharded_one_rank"]
+    assert "error" not in so, so
+    assert so["bit_identical_to_single_gpu_proof"] is True and so["world"] == 1 and so["ms_per_proof"] > 0 and so["single_gpu_ms_same_process"] > 0
     e = d["end_to_end"]
     assert e["pipelined_from_host_ms_per_proof"] > 0 and e["pipelined_from_segments_ms_per_proof"] > 0 and e["streamed_vs_resident"] > 0.5
 

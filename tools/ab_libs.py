@@ -13,7 +13,7 @@ for r in range(a.rounds):
     for l in (a.libs if r % 2 == 0 else a.libs[::-1]):
         env = dict(os.environ, CAIROM_HIP_LIB=os.path.abspath(l))
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "16", "--warmup", "4", "--no-cpu-baseline", "--no-end-to-end",
-                              "--alt-fib-n", "0", "--big-fib-n", "0", "--cached-setup-steps", "0", "--no-kprof", "--pipelined", str(a.pipelined)], env=env, capture_output=True, text=True, cwd=root)
+                              "--alt-fib-n", "0", "--big-fib-n", "0", "--cached-setup-steps", "0", "--sharded-one-rank-blocks", "0", "--no-kprof", "--pipelined", str(a.pipelined)], env=env, capture_output=True, text=True, cwd=root)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception:
