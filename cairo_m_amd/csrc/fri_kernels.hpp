@@ -81,9 +81,12 @@ void fri_tail(const FriTailArgs& a, hipStream_t st);
 // fold_line of layer log_n into layer log_n - 1 fused with fold_circle_into_line of the quotient columns of log_n
 void fold_line_and_circle(uint32_t* const out[4], const uint32_t* const src[4], const uint32_t* const circle[4], uint32_t log_n,
                           const Twiddles& tw, hipStream_t st, const uint32_t* d_alpha, const uint32_t* d_alpha_circle);
+// (row0, n_rows: outputs [row0, row0 + n_rows) of the layer into arrays — values, sources, leaf hashes — that hold just that row range, the
+// sharded prover's slices; n_rows = 0: the whole layer)
 bool fold_circle_leaf(uint32_t* const out[4], const uint32_t* const circle[4], uint32_t log_n, const Twiddles& tw, hipStream_t st,
-                      const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes);
+                      const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes, uint32_t row0 = 0, uint32_t n_rows = 0);
 bool fold_line_leaf(uint32_t* const out[4], const uint32_t* const src[4], const uint32_t* const* circle, uint32_t log_n,
-                    const Twiddles& tw, hipStream_t st, const uint32_t* d_alpha, const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes);
+                    const Twiddles& tw, hipStream_t st, const uint32_t* d_alpha, const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes,
+                    uint32_t row0 = 0, uint32_t n_rows = 0);
 
 }  // namespace cm

@@ -352,7 +352,9 @@ __global__ void __launch_bounds__(256) k_fold_line_circle(Ptr4 out, CPtr4 src, C
 template <bool RFC, int MODE>
 __global__ void __launch_bounds__(256) k_fold_leaf(Ptr4 out, CPtr4 src, CPtr4 circle, uint32_t log_n, TwiddleView tw,
                                                    const uint32_t* __restrict__ alpha_dev, const uint32_t* __restrict__ alpha_c_dev,
-                                                   uint32_t* __restrict__ hashes, uint32_t npw) {
+                                                   uint32_t* __restrict__ hashes, uint32_t npw, uint32_t row0) {
+  // (row0: the launch computes outputs [row0, row0 + grid * 256 * npw) of the layer into arrays — values, sources, hashes — that hold
+  // just that row range: a rank's slices in the sharded prover; the twiddles are read at the global row.  Whole layer: row0 = 0)
   __shared__ uint4 stage[4][128];           // per wave: 64 leaves x 32 B
   const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   uint4* st = stage[w];
@@ -363,8 +365,8 @@ __global__ void __launch_bounds__(256) k_fold_leaf(Ptr4 out, CPtr4 src, CPtr4 ci
   QM31 ac, ac2;
   if (MODE >= 1) { ac = QM31::from_u32(alpha_c_dev); ac2 = ac * ac; }
   const uint32_t L = MODE == 2 ? 0u : tw.R - (log_n + 1);
-  const uint32_t* __restrict__ ixt = tw.ixtw + ((1u << (tw.R - 1)) - (1u << (tw.R - 1 - L)));
-  const uint32_t* __restrict__ iyt = tw.iytw + (1u << (log_n - 1));
+  const uint32_t* __restrict__ ixt = tw.ixtw + ((1u << (tw.R - 1)) - (1u << (tw.R - 1 - L))) + row0;
+  const uint32_t* __restrict__ iyt = tw.iytw + (1u << (log_n - 1)) + row0;
   // (plain scalars: indexed arrays of loads captured by reference went to scratch in k_merkle_narrow)
   uint2 s0 = {0, 0}, s1 = {0, 0}, s2 = {0, 0}, s3 = {0, 0}, c0, c1, c2, c3;
   uint32_t xw = 0, yw = 0;
@@ -583,10 +585,11 @@ void fold_line_and_circle(uint32_t* const out[4], const uint32_t* const src[4], 
 // fold_line (circle == nullptr) or fold_line_and_circle, plus the leaf hashes of the tree over `out` (2^(log_n - 1) leaves of
 // four coordinate words); true if the launch was made (the layer must be large enough for the wave-per-chunk walk)
 bool fold_line_leaf(uint32_t* const out[4], const uint32_t* const src[4], const uint32_t* const* circle, uint32_t log_n,
-                    const Twiddles& tw, hipStream_t st, const uint32_t* d_alpha, const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes) {
+                    const Twiddles& tw, hipStream_t st, const uint32_t* d_alpha, const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes,
+                    uint32_t row0, uint32_t n_rows) {
   const bool on = tune(T_FRI_FOLD_LEAF) != 0;   // A/B: 0 = fold, then the leaf launch
-  if (!on || log_n < 15 || log_n + 1 > tw.R) return false;
-  const uint32_t n = 1u << (log_n - 1);
+  const uint32_t n = n_rows ? n_rows : 1u << (log_n - 1);   // (a row range: the sharded prover's slice, power of two, row0 a multiple)
+  if (!on || log_n < 15 || log_n + 1 > tw.R || n < (1u << 14) || (n & (n - 1)) != 0 || row0 % n != 0 || (uint64_t)row0 + n > ((uint64_t)1 << (log_n - 1))) return false;
   uint32_t npw = std::min(8u, std::max(1u, n >> 20));
   while (npw > 1 && (n % (256u * npw)) != 0) npw >>= 1;
   Ptr4 d; CPtr4 s, c;
@@ -595,7 +598,7 @@ bool fold_line_leaf(uint32_t* const out[4], const uint32_t* const src[4], const 
   KProfScope kp("k_fold_leaf", ((circle ? 64.0 : 32.0) + 16.0 + 32.0) * (double)n, st, /* Blake2s compressions */ (double)n);
   const dim3 grid(n / (256u * npw));
   const bool rfc = framing().hash_node_rfc;
-#define CM_FL(R, M) hipLaunchKernelGGL((k_fold_leaf<R, M>), grid, dim3(256), 0, st, d, s, c, log_n, view(tw), d_alpha, d_alpha_circle, d_leaf_hashes, npw)
+#define CM_FL(R, M) hipLaunchKernelGGL((k_fold_leaf<R, M>), grid, dim3(256), 0, st, d, s, c, log_n, view(tw), d_alpha, d_alpha_circle, d_leaf_hashes, npw, row0)
   if (circle) { if (rfc) CM_FL(true, 1); else CM_FL(false, 1); }
   else { if (rfc) CM_FL(true, 0); else CM_FL(false, 0); }
 #undef CM_FL
@@ -604,10 +607,10 @@ bool fold_line_leaf(uint32_t* const out[4], const uint32_t* const src[4], const 
 }
 // fold_circle_into_line of ONE group of quotient columns (2^log_n circle evaluations) into a blank layer + its leaf hashes
 bool fold_circle_leaf(uint32_t* const out[4], const uint32_t* const circle[4], uint32_t log_n, const Twiddles& tw, hipStream_t st,
-                      const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes) {
+                      const uint32_t* d_alpha_circle, uint32_t* d_leaf_hashes, uint32_t row0, uint32_t n_rows) {
   const bool on = tune(T_FRI_FOLD_LEAF) != 0;
-  if (!on || log_n < 15 || log_n > tw.R) return false;
-  const uint32_t n = 1u << (log_n - 1);
+  const uint32_t n = n_rows ? n_rows : 1u << (log_n - 1);
+  if (!on || log_n < 15 || log_n > tw.R || n < (1u << 14) || (n & (n - 1)) != 0 || row0 % n != 0 || (uint64_t)row0 + n > ((uint64_t)1 << (log_n - 1))) return false;
   uint32_t npw = std::min(8u, std::max(1u, n >> 20));
   while (npw > 1 && (n % (256u * npw)) != 0) npw >>= 1;
   Ptr4 d; CPtr4 s, c;
@@ -615,9 +618,9 @@ bool fold_circle_leaf(uint32_t* const out[4], const uint32_t* const circle[4], u
   KProfScope kp("k_fold_leaf", (32.0 + 16.0 + 32.0) * (double)n, st, /* Blake2s compressions */ (double)n);
   const dim3 grid(n / (256u * npw));
   if (framing().hash_node_rfc)
-    hipLaunchKernelGGL((k_fold_leaf<true, 2>), grid, dim3(256), 0, st, d, s, c, log_n, view(tw), (const uint32_t*)nullptr, d_alpha_circle, d_leaf_hashes, npw);
+    hipLaunchKernelGGL((k_fold_leaf<true, 2>), grid, dim3(256), 0, st, d, s, c, log_n, view(tw), (const uint32_t*)nullptr, d_alpha_circle, d_leaf_hashes, npw, row0);
   else
-    hipLaunchKernelGGL((k_fold_leaf<false, 2>), grid, dim3(256), 0, st, d, s, c, log_n, view(tw), (const uint32_t*)nullptr, d_alpha_circle, d_leaf_hashes, npw);
+    hipLaunchKernelGGL((k_fold_leaf<false, 2>), grid, dim3(256), 0, st, d, s, c, log_n, view(tw), (const uint32_t*)nullptr, d_alpha_circle, d_leaf_hashes, npw, row0);
   CM_HIP(hipGetLastError());
   return true;
 }
