@@ -11,6 +11,9 @@ of the same input made alone).  Per round, until the time is up:
   3. cm_prove_many_host  streaming ingest of 12 host inputs, 4 in flight (uploads under proofs, inputs recycled through the pool)
   4. thread churn        3 NEW host threads (fresh thread-local streams, pools, pinned slots, ticket rings on recycled memory)
   5. framing freeze      cm_set_framing called every 2 ms while proofs run: refused whenever a prover is alive
+  6. sharded, one rank   (round 6) two segments through cm_prove_sharded over the in-library RCCL communicator with world = 1 — the
+                         device-side transcript steps and their host replays, the pipelined decommitment gathers — between the
+                         pipelines above, on the pool and the pinned slots they leave behind
 
     python tools/stress_pipeline.py --minutes 10 > gpurun_out/<tag>_stress.txt      (one JSON summary line at the end)
 """
@@ -50,8 +53,12 @@ def main():
         v = C.cast(bad_inps[i].view, C.POINTER(ProverInputView)).contents
         acc = np.ctypeslib.as_array(C.cast(v.data_accesses, C.POINTER(C.c_uint32)), shape=(int(v.n_data_accesses), 4))
         acc[20:40, 3] ^= 1
+    from cairo_m_amd.sharded import RcclComm, prove_sharded, shard_plan
+    idb = (C.c_uint8 * 128)()
+    be._ck(be.L.cm_rccl_unique_id(idb))
+    comm = RcclComm(be, max(shard_plan(i, 1, be.L, None)[1] for i in inps), rank=0, world=1, id_bytes=bytes(idb))
     rng = np.random.default_rng(0)
-    stats = {"rounds": 0, "proofs": 0, "mismatches": 0, "injected_failures": 0, "failures_reported": 0, "framing_refused": 0,
+    stats = {"sharded_one_rank": 0, "rounds": 0, "proofs": 0, "mismatches": 0, "injected_failures": 0, "failures_reported": 0, "framing_refused": 0,
              "framing_slipped": 0, "streamed": 0, "churn_threads": 0}
     t_end = time.time() + 60 * a.minutes
 
@@ -143,6 +150,10 @@ def main():
         for i, (k, p) in res.items():
             check(k, p)
         stats["churn_threads"] += len(ts)
+        # 6. the sharded prover with one rank
+        for k in [int(x) for x in rng.integers(0, len(devs), size=2)]:
+            check(k, prove_sharded(be, devs[k], comm))
+            stats["sharded_one_rank"] += 1
         stats["rounds"] += 1
         # a leak must end the soak, not the box: the thread-churn part once lost ~35 MB of pinned memory per thread (fixed:
         # engine.hpp at_thread_exit) and took the test box down after four minutes
