@@ -11,8 +11,8 @@
 // xGMI is point to point: the grouped send/recv pairs of one all-to-all use all seven links of a GPU at once, and no ring is
 // involved (an all-to-all of a tree's LDE is 1.6 GB / N per rank at the metric size).
 //
-// librccl is loaded with dlopen on first use (a copy already mapped by the process — e.g. PyTorch's — is reused): the library
-// has no link-time dependency on RCCL and single-GPU users never load it.
+// librccl is loaded with dlopen on first use — the copy next to the HIP runtime in use, else one the process has mapped, else the
+// system's: the library has no link-time dependency on RCCL and single-GPU users never load it.
 #include <dlfcn.h>
 #include <string.h>
 #include <memory>
@@ -48,8 +48,24 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+    // FIRST the librccl that sits next to the HIP runtime THIS library runs on (dladdr of a runtime entry point): a process can
+    // hold two ROCm stacks — the system's and the one a PyTorch wheel bundles — and whichever libamdhip64 was mapped first serves
+    // both; an RCCL built for the other one fails in ncclCommInitRank ("unhandled cuda error": seen with the wheel's RCCL 2.26 on
+    // the system's HIP 7.2 after a late `import torch`).  An absolute path maps that copy even when another librccl.so.1 is loaded.
+    {
+      Dl_info di;
+      if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+        std::string dir(di.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+          dir.resize(slash + 1);
+          for (const char* n : {"librccl.so.1", "librccl.so"})
+            if ((r.h = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL))) break;
+        }
+      }
+    }
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) if ((r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;    // a copy the process already has
+    if (!r.h) for (const char* n : names) if ((r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;    // a copy the process already has
     if (!r.h) for (const char* n : names) if ((r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!r.h) return;
     auto sym = [&](const char* s) { return dlsym(r.h, s); };

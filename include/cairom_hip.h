@@ -309,8 +309,10 @@ typedef struct cm_comm {
   int32_t (*all_to_all_v)(void* ctx, const uint64_t* send_words, const uint64_t* recv_words);
   int32_t (*all_gather)(void* ctx, uint64_t words_per_rank);
   /* Optional (zero / NULL = the blocking form above).  CM_COMM_STREAM_ORDERED: the callbacks only ENQUEUE the exchange on the
-   * stream given through set_stream (the prover calls it once with its own stream) and return at once; the prover then neither
-   * drains its stream before a collective nor waits after it — everything stays ordered on that one stream. */
+   * stream given through set_stream and return at once; the prover then neither drains its stream before a collective nor waits
+   * after it — everything stays ordered on that stream.  The prover calls set_stream with its own stream when a proof starts and
+   * MAY call it again between two collectives (round 6: the claimed sums' all-gather follows the LogUp tail onto a side stream and
+   * the communicator is handed back to the main stream right behind it): a callback always uses the stream of the latest call. */
   uint32_t flags;
   int32_t (*set_stream)(void* ctx, cm_stream_t stream);
   /* Optional.  Called when THIS rank fails inside cm_prove_sharded, before the error is returned: the other ranks are about to
