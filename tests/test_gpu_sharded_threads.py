@@ -18,7 +18,7 @@ from cairo_m_amd.lib import Proof, synth_fibonacci
 from cairo_m_amd.sharded import CmComm, _A2A, _AG, _SETSTREAM, _ABORT, shard_plan
 
 pytestmark = pytest.mark.gpu
-HIP = C.CDLL("libamdhip64.so")
+HIP = None   # libamdhip64, loaded by the first Loopback (not at collection: a box without a GPU only deselects this file)
 hipMemcpyDeviceToDevice = 3
 hipEventDisableTiming = 2
 
@@ -31,6 +31,9 @@ class Loopback:
     """shared state of `world` loop-back ranks"""
 
     def __init__(self, backend, world, words):
+        global HIP
+        if HIP is None:
+            HIP = C.CDLL("libamdhip64.so")
         self.world, self.words = world, words
         self.send = [backend.col_alloc(words) for _ in range(world)]
         self.recv = [backend.col_alloc(words) for _ in range(world)]
